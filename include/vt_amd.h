@@ -1,0 +1,269 @@
+/*
+ * vt_amd.h -- C-ABI of libvt_amd.so: the MI355X (gfx950) hot path of the
+ * Darknet / CSPDarknet / VoVNet backbones.
+ *
+ * The reference (gau-nernst/vision-toolbox) has NO native layer: every entry
+ * point below replaces a torch.nn / ATen call made from the reference's Python.
+ * The call site it replaces is cited per function as `file:line` relative to
+ * the reference checkout.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch's caching
+ *     allocator in our host code); the library allocates nothing persistent.
+ *   - `stream` is a hipStream_t passed as void*; all work is asynchronous on it,
+ *     no entry point synchronises.
+ *   - activations are NHWC ("channels_last"): element (b,h,w,c) of a tensor
+ *     with pixel stride `ld` lives at ((b*H + h)*W + w)*ld + c.  `ld >= C`
+ *     lets a tensor be a channel slice of a wider concat buffer.
+ *   - dtype: VT_F32 (exact-f32 MFMA, parity mode) or VT_BF16 (bf16 storage,
+ *     f32 accumulate).  Channel counts / strides / offsets must be multiples
+ *     of 16 bytes' worth of elements (4 for f32, 8 for bf16).
+ *   - conv weights are [Cout][taps][Cin] ("KRSC"), i.e. the memory image of a
+ *     torch OIHW weight held in channels_last format.
+ *   - return value: VT_OK or a VT_ERR_* code; vt_last_error() gives the text.
+ *     Nothing aborts.  Stateless and re-entrant apart from that thread-local
+ *     error string.
+ */
+#ifndef VT_AMD_H
+#define VT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VT_OK 0
+#define VT_ERR_INVALID 1     /* bad argument: null pointer, misalignment, size  */
+#define VT_ERR_UNSUPPORTED 2 /* shape / dtype this library has no kernel for    */
+#define VT_ERR_HIP 3         /* HIP runtime reported an error                   */
+
+#define VT_F32 0
+#define VT_BF16 1
+
+#define VT_MAX_TAPS 36 /* 6x6 stem of DarknetYOLOv5 (darknet.py:109) */
+
+/* epilogue flags of vt_conv_igemm */
+#define VT_CONV_RELU 1     /* y = max(y, 0) after scale/shift                   */
+#define VT_CONV_STATS 2    /* accumulate per-channel sum / sum-of-squares       */
+#define VT_CONV_RESIDUAL 4 /* y += residual (after relu)                        */
+#define VT_CONV_AFFINE 8   /* y = y*scale[c] + shift[c]; scale==NULL means 1    */
+
+#define VT_STAT_REPLICAS 32 /* stats buffers are float[VT_STAT_REPLICAS][2][C]  */
+
+/*
+ * Geometry of one implicit-GEMM convolution launch.  One descriptor covers the
+ * forward conv, the data gradient (run on dz with a re-packed filter) and the
+ * per-parity-class data gradient of stride-2 convs.
+ *
+ *   out(b, i*oHs+oh0, j*oWs+ow0, n) =
+ *       sum_{t<ntaps} sum_{c<Cin} in(b, i*sh+h0+dh[t], j*sw+w0+dw[t], c) * w[n][t][c]
+ *   for i<Ho, j<Wo; taps that fall outside [0,Hi)x[0,Wi) read zero.
+ */
+typedef struct vt_conv_desc {
+    int32_t dtype;
+    int32_t B, Hi, Wi, Cin, ldx; /* gather source                              */
+    int32_t Ho, Wo;              /* output grid iterated (GEMM M = B*Ho*Wo)    */
+    int32_t sh, sw, h0, w0;      /* input step / origin                        */
+    int32_t Cout, ldy;           /* GEMM N and output pixel stride             */
+    int32_t oH, oW;              /* extent of the tensor written               */
+    int32_t oHs, oWs, oh0, ow0;  /* placement of grid point (i,j) in it        */
+    int32_t ldw;                 /* weight row stride, elements (>= ntaps*Cin) */
+    int32_t ldr;                 /* residual pixel stride                      */
+    int32_t flags;               /* VT_CONV_*                                  */
+    int32_t ntaps;
+    int8_t dh[VT_MAX_TAPS];
+    int8_t dw[VT_MAX_TAPS];
+} vt_conv_desc;
+
+/* ---- library ------------------------------------------------------------ */
+int vt_version(void);
+const char* vt_last_error(void);
+/* number of kernel launches issued by this process through the library; the
+ * GPU tests assert it advances, i.e. that the HIP path is what ran. */
+uint64_t vt_launch_count(void);
+int vt_memset(void* ptr, int value, uint64_t bytes, void* stream);
+
+/* ---- convolution --------------------------------------------------------
+ * Replaces nn.Conv2d inside ConvNormAct (components.py:26-35) and, with the
+ * AFFINE/RELU/RESIDUAL epilogue, the eval-mode BatchNorm2d + ReLU that follow
+ * it (components.py:36-44) and DarknetBlock's add (darknet.py:28).  With
+ * VT_CONV_STATS it also produces the batch statistics BatchNorm2d needs in
+ * training mode.  The same entry point computes conv data gradients.
+ * `stats` is float[VT_STAT_REPLICAS][2][Cout], zeroed by the caller. */
+int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w, void* y,
+                  const float* scale, const float* shift, const void* residual,
+                  float* stats, void* stream);
+
+/* Filter gradient: dw[n][t][c] += sum_pixels dz(pix,n) * x_gathered(pix,t,c),
+ * fp32 accumulation straight into the (channels_last) .grad of the weight.
+ * `d` is the forward descriptor (ldy = pixel stride of dz).  Replaces the
+ * autograd backward of nn.Conv2d (components.py:26-35). */
+int vt_conv_wgrad(const vt_conv_desc* d, const void* x, const void* dz, float* dw,
+                  int32_t ldgw, void* stream);
+
+/* Re-pack a [Cout][ntaps][Cin] filter (f32 master or dtype mirror) into the
+ * [Cin][nsel][Cout] image the data-gradient launch reads; sel[i] is the source
+ * tap of packed tap i. */
+int vt_pack_dgrad_filter(const void* w, int32_t src_dtype, int32_t ldw, void* out,
+                         int32_t dst_dtype, const int32_t* sel_host, int32_t nsel,
+                         int32_t Cout, int32_t ntaps, int32_t Cin, void* stream);
+
+/* ---- BatchNorm2d + ReLU (components.py:36-44) --------------------------- */
+/* training: stats -> batch mean/var, running-stat update (momentum, unbiased
+ * var), scale = gamma*invstd, shift = beta - mean*scale. */
+int vt_bn_finalize(const float* stats, int32_t C, double count, const float* gamma,
+                   const float* beta, float eps, float momentum, float* running_mean,
+                   float* running_var, int64_t* num_batches_tracked, float* scale,
+                   float* shift, float* mean, float* invstd, void* stream);
+/* eval: coefficients from the running statistics. */
+int vt_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, int32_t C, float* scale,
+                      float* shift, float* mean, float* invstd, void* stream);
+/* y = [relu](z*scale + shift) [+ residual] */
+int vt_bn_act_apply(const void* z, int32_t ldz, const float* scale, const float* shift,
+                    const void* residual, int32_t ldr, void* y, int32_t ldy, int64_t M,
+                    int32_t C, int32_t relu, int32_t dtype, void* stream);
+/* sums[rep][0][c] += sum g, sums[rep][1][c] += sum g*xhat, g = dy*[z*scale+shift>0] */
+int vt_bn_act_bwd_reduce(const void* dy, int32_t lddy, const void* z, int32_t ldz,
+                         const float* scale, const float* shift, const float* mean,
+                         const float* invstd, int64_t M, int32_t C, int32_t relu,
+                         int32_t dtype, float* sums, void* stream);
+/* dgamma += sum g*xhat; dbeta += sum g; coef[3][C] for vt_bn_act_bwd_apply.
+ * train!=0: full batch-norm gradient; train==0: statistics are constants. */
+int vt_bn_bwd_finalize(const float* sums, int32_t C, double count, const float* scale,
+                       const float* mean, const float* invstd, int32_t train,
+                       float* dgamma, float* dbeta, float* coef, void* stream);
+/* dz = coef0[c]*g - coef1[c]*z + coef2[c] */
+int vt_bn_act_bwd_apply(const void* dy, int32_t lddy, const void* z, int32_t ldz,
+                        const float* scale, const float* shift, const float* coef,
+                        void* dz, int32_t lddz, int64_t M, int32_t C, int32_t relu,
+                        int32_t dtype, void* stream);
+
+/* ---- pooling ------------------------------------------------------------ */
+/* nn.MaxPool2d(3, 2, 1) at the head of every VoVNet stage (vovnet.py:94). */
+int vt_maxpool3x3s2_fwd(const void* x, int32_t ldx, void* y, int32_t ldy, uint8_t* argmax,
+                        int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                        void* stream);
+int vt_maxpool3x3s2_bwd(const void* dy, int32_t lddy, const uint8_t* argmax, void* dx,
+                        int32_t lddx, int32_t B, int32_t H, int32_t W, int32_t C,
+                        int32_t accumulate, int32_t dtype, void* stream);
+/* nn.AdaptiveAvgPool2d((1,1)) of the classifier head (classifier.py:61) and of
+ * ESEBlock (vovnet.py:23). y is [B][C] with row stride ldy. */
+int vt_global_avgpool_fwd(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t B,
+                          int32_t HW, int32_t C, int32_t dtype, void* stream);
+int vt_global_avgpool_bwd(const void* dy, int32_t lddy, void* dx, int32_t lddx, int32_t B,
+                          int32_t HW, int32_t C, int32_t accumulate, int32_t dtype,
+                          void* stream);
+
+/* ---- ESEBlock gate (vovnet.py:20-28) ------------------------------------ */
+/* y = x * hardsigmoid(s[b][c]) [+ residual]; s is [B][C] (the biased 1x1 conv
+ * of the pooled map, computed with vt_conv_igemm). */
+int vt_ese_gate_fwd(const void* x, int32_t ldx, const void* s, int32_t lds,
+                    const void* residual, int32_t ldr, void* y, int32_t ldy, int32_t B,
+                    int32_t HW, int32_t C, int32_t dtype, void* stream);
+/* dx (=|+=) dy*hsig(s);  ds[b][c] = hsig'(s) * sum_hw dy*x  (f32 [B][C]) */
+int vt_ese_gate_bwd(const void* dy, int32_t lddy, const void* x, int32_t ldx, const void* s,
+                    int32_t lds, void* dx, int32_t lddx, float* ds, int32_t B, int32_t HW,
+                    int32_t C, int32_t accumulate, int32_t dtype, void* stream);
+
+/* ---- classifier head / loss (classifier.py:58-64, 92) ------------------- */
+/* per-column sums of a [M][C] matrix into out[C] (+=): bias gradients. */
+int vt_colsum(const void* a, int32_t lda, int64_t M, int32_t C, int32_t dtype, float* out,
+              void* stream);
+/* F.cross_entropy(logits, labels, label_smoothing) with mean reduction and its
+ * gradient times grad_scale; loss_sum[0] += sum_b loss_b / B. */
+int vt_softmax_xent(const void* logits, int32_t ldl, const int64_t* labels,
+                    float label_smoothing, float grad_scale, float* loss, void* dlogits,
+                    int32_t lddl, int32_t B, int32_t N, int32_t dtype, void* stream);
+
+/* ---- optimiser (classifier.py:161-169: torch.optim.SGD, momentum) -------- */
+/* g' = g*grad_scale + wd*p; m = mu*m + g'; p -= lr*m; mirror = cast(p).
+ * lr_dev (optional, device float[1]) overrides `lr`, so a captured graph can
+ * follow the warm-up/cosine schedule (classifier.py:171-190) without re-capture. */
+int vt_sgd_momentum(float* p, const float* g, float* m, void* mirror, int32_t mirror_dtype,
+                    int64_t n, float lr, float momentum, float weight_decay,
+                    float grad_scale, const float* lr_dev, void* stream);
+
+/* ---- layout / precision plumbing ---------------------------------------- */
+/* rows x cols block copy with dtype conversion: dst (=|+=) src */
+int vt_copy2d(const void* src, int32_t src_dtype, int64_t lds, void* dst, int32_t dst_dtype,
+              int64_t ldd, int64_t rows, int32_t cols, int32_t accumulate, void* stream);
+/* images: NCHW f32 -> NHWC dtype with channels zero-padded to Cpad
+ * (the `images.to(memory_format=channels_last)` of classifier.py:88-89). */
+int vt_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t H, int32_t W,
+                    int32_t Cpad, int32_t dtype, void* stream);
+/* dx[B][C][H][W] f32 (=) dy NHWC[..., :C] */
+int vt_nhwc_to_nchw(const void* y, int32_t ldy, float* x, int32_t B, int32_t C, int32_t H,
+                    int32_t W, int32_t dtype, void* stream);
+
+/* ---- native executor -----------------------------------------------------
+ * A step of the backbone is a static list of the calls above.  The host builds
+ * the list once per (model, input shape) and replays it with one call, or as a
+ * captured hipGraph.  Pointers are (base, byte offset) pairs so one list serves
+ * any arena placement. */
+#define VT_OP_MAX_PTR 12
+#define VT_OP_MAX_INT 110
+#define VT_OP_MAX_FLT 8
+#define VT_MAX_BASES 16
+
+enum vt_op_kind {
+    VT_OP_MEMSET = 1,
+    VT_OP_CONV_IGEMM,
+    VT_OP_CONV_WGRAD,
+    VT_OP_PACK_DGRAD,
+    VT_OP_BN_FINALIZE,
+    VT_OP_BN_EVAL_COEFFS,
+    VT_OP_BN_ACT_APPLY,
+    VT_OP_BN_BWD_REDUCE,
+    VT_OP_BN_BWD_FINALIZE,
+    VT_OP_BN_BWD_APPLY,
+    VT_OP_MAXPOOL_FWD,
+    VT_OP_MAXPOOL_BWD,
+    VT_OP_AVGPOOL_FWD,
+    VT_OP_AVGPOOL_BWD,
+    VT_OP_ESE_FWD,
+    VT_OP_ESE_BWD,
+    VT_OP_COLSUM,
+    VT_OP_XENT,
+    VT_OP_SGD,
+    VT_OP_COPY2D,
+    VT_OP_NCHW_TO_NHWC,
+    VT_OP_NHWC_TO_NCHW,
+    VT_OP_KIND_END
+};
+
+typedef struct vt_ptr {
+    int32_t base; /* index into the bases[] passed at run time; -1 = NULL */
+    int32_t pad;
+    int64_t offset; /* bytes */
+} vt_ptr;
+
+typedef struct vt_op {
+    int32_t kind;
+    int32_t tag; /* host-defined id (layer index), echoed in error messages */
+    vt_ptr ptr[VT_OP_MAX_PTR];
+    int32_t i[VT_OP_MAX_INT];
+    double f[VT_OP_MAX_FLT];
+} vt_op;
+
+/* run ops[0..n) in order on `stream`; argument order per kind is documented in
+ * vt_runtime.hip next to each case. */
+int vt_run_ops(const vt_op* ops, int32_t n, void* const* bases, int32_t nbases, void* stream);
+
+/* hipGraph capture of an op list: capture once, replay with one launch. */
+int vt_graph_create(const vt_op* ops, int32_t n, void* const* bases, int32_t nbases,
+                    void** graph_out);
+int vt_graph_launch(void* graph, void* stream);
+int vt_graph_destroy(void* graph);
+
+/* ---- timing helpers for bench.py (HIP events on the launch stream) ------- */
+int vt_event_create(void** ev);
+int vt_event_record(void* ev, void* stream);
+int vt_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on stop */
+int vt_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VT_AMD_H */

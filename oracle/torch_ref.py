@@ -1,0 +1,297 @@
+"""TEST INFRASTRUCTURE -- CPU oracle for the Darknet / VoVNet backbone hot path.
+
+A functional restatement (plain functions over a state_dict, torch CPU fp32) of the
+reference's hot path.  The arithmetic of the reference lives in a third-party dependency,
+`torch` (ATen CPU kernels; the reference leaves it unpinned in setup.cfg:10-12, its CI
+uses 1.13/2.0, this container has 2.10.0): the reference's own code only wires
+nn.Conv2d / nn.BatchNorm2d / nn.ReLU / torch.cat / + / nn.MaxPool2d / Hardsigmoid.
+This file restates that wiring call site by call site (cited below) on
+torch.nn.functional, and restates the constructors as `spec()` (key -> shape tables).
+
+PARITY PINNED: tests/test_oracle.py checks this oracle against golden vectors produced
+by importing the UNMODIFIED reference source in the build container
+(tools/gen_golden.py -> tests/golden/*.npz): state_dict manifests, parameter counts
+(README.md:128-135,176-183), feature maps, logits, loss, gradients, running statistics.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module; the shipped package (vision-toolbox_amd/) never does.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1  # nn.BatchNorm2d defaults used by components.py:36
+
+# ---- variant tables (darknet.py:91-95,124-133; vovnet.py:108-117) ------------------------
+DARKNET = {
+    "darknet19": ((0, 1, 1, 2, 2), False),
+    "darknet53": ((1, 2, 8, 8, 4), False),
+    "cspdarknet53": ((1, 2, 8, 8, 4), True),
+}
+DARKNET_WIDTHS = (64, 128, 256, 512, 1024)
+YOLOV5 = {"n": (1 / 3, 1 / 4), "s": (1 / 3, 1 / 2), "m": (2 / 3, 3 / 4), "l": (1.0, 1.0), "x": (4 / 3, 5 / 4)}
+VOVNET_DEPTH = {
+    19: ((1, 1, 1, 1), 3),
+    27: ((1, 1, 1, 1), 5),
+    39: ((1, 1, 2, 2), 5),
+    57: ((1, 1, 4, 3), 5),
+    99: ((1, 3, 9, 3), 5),
+}
+FACTORIES = {
+    "darknet19": ("darknet", "darknet19"),
+    "darknet53": ("darknet", "darknet53"),
+    "cspdarknet53": ("darknet", "cspdarknet53"),
+    **{f"darknet_yolov5{v}": ("yolov5", v) for v in "nsmlx"},
+    "vovnet27_slim": ("vovnet", (27, True, False)),
+    "vovnet39": ("vovnet", (39, False, False)),
+    "vovnet57": ("vovnet", (57, False, False)),
+    "vovnet19_slim_ese": ("vovnet", (19, True, True)),
+    "vovnet19_ese": ("vovnet", (19, False, True)),
+    "vovnet39_ese": ("vovnet", (39, False, True)),
+    "vovnet57_ese": ("vovnet", (57, False, True)),
+    "vovnet99_ese": ("vovnet", (99, False, True)),
+}
+
+
+def yolov5_cfg(v):
+    d, w = YOLOV5[v]
+    return int(64 * w), [(int(a * d), int(b * w)) for a, b in zip((3, 6, 9, 3), (128, 256, 512, 1024))]
+
+
+def vovnet_cfg(variant, slim):
+    blocks, layers = VOVNET_DEPTH[variant]
+    mids = (64, 80, 96, 112) if slim else (128, 160, 192, 224)
+    outs = (128, 256, 384, 512) if slim else (256, 512, 768, 1024)
+    return 128, list(zip(blocks, mids, [layers] * 4, outs))
+
+
+# ---- constructors restated as key -> shape tables ----------------------------------------
+def _cna_spec(out, p, cin, cout, k):
+    out[p + "conv.weight"] = (cout, cin, k, k)
+    for leaf in ("weight", "bias", "running_mean", "running_var"):
+        out[p + "norm." + leaf] = (cout,)
+    out[p + "norm.num_batches_tracked"] = ()
+
+
+def _block_spec(out, p, c, expansion):
+    mid = int(c * expansion)
+    _cna_spec(out, p + "conv1.", c, mid, 1)
+    _cna_spec(out, p + "conv2.", mid, c, 3)
+
+
+def spec(name: str) -> "OrderedDict[str, tuple]":
+    """state_dict keys and shapes, in module registration order."""
+    kind, arg = FACTORIES[name]
+    out: "OrderedDict[str, tuple]" = OrderedDict()
+    if kind == "darknet":
+        depths, csp = DARKNET[arg]
+        stem, cfgs = 32, list(zip(depths, DARKNET_WIDTHS))
+        _cna_spec(out, "stem.", 3, stem, 3)
+    elif kind == "yolov5":
+        stem, cfgs = yolov5_cfg(arg)
+        csp = True
+        _cna_spec(out, "stem.", 3, stem, 6)
+    if kind in ("darknet", "yolov5"):
+        cin = stem
+        for i, (n, c) in enumerate(cfgs):
+            p = f"stages.{i}."
+            if n == 0:  # bare unit (darknet.py:79)
+                _cna_spec(out, p, cin, c, 3)
+            elif csp:
+                half = c // 2
+                _cna_spec(out, p + "conv.", cin, c, 3)
+                _cna_spec(out, p + "conv1.", c, half, 1)
+                _cna_spec(out, p + "conv2.", c, half, 1)
+                for j in range(n):
+                    _block_spec(out, p + f"blocks.{j}.", half, 1)
+                _cna_spec(out, p + "out_conv.", c, c, 1)
+            else:
+                _cna_spec(out, p + "conv.", cin, c, 3)
+                for j in range(n):
+                    _block_spec(out, p + f"blocks.{j}.", c, 0.5)
+            cin = c
+        return out
+    variant, slim, ese = arg
+    stem, cfgs = vovnet_cfg(variant, slim)
+    _cna_spec(out, "stem.0.", 3, stem // 2, 3)
+    _cna_spec(out, "stem.1.", stem // 2, stem // 2, 3)
+    _cna_spec(out, "stem.2.", stem // 2, stem, 3)
+    cin = stem
+    for i, (nb, mid, nl, c) in enumerate(cfgs):
+        for j in range(nb):
+            p = f"stages.{i}.module_{j}."
+            for l in range(nl):
+                _cna_spec(out, p + f"convs.{l}.", cin if l == 0 else mid, mid, 3)
+            _cna_spec(out, p + "out_conv.", cin + mid * nl, c, 1)
+            if ese:
+                out[p + "ese.linear.weight"] = (c, c, 1, 1)
+                out[p + "ese.linear.bias"] = (c,)
+            cin = c
+    return out
+
+
+def out_channels_list(name: str) -> tuple:
+    kind, arg = FACTORIES[name]
+    if kind == "darknet":
+        return DARKNET_WIDTHS
+    if kind == "yolov5":
+        stem, cfgs = yolov5_cfg(arg)
+        return (stem,) + tuple(c for _, c in cfgs)
+    stem, cfgs = vovnet_cfg(arg[0], arg[1])
+    return (stem,) + tuple(c[3] for c in cfgs)
+
+
+def empty_state_dict(name: str) -> "OrderedDict[str, torch.Tensor]":
+    sd = OrderedDict()
+    for k, shape in spec(name).items():
+        sd[k] = torch.zeros(shape, dtype=torch.int64 if k.endswith("num_batches_tracked") else torch.float32)
+    return sd
+
+
+def num_parameters(name: str) -> int:
+    return sum(math.prod(s) for k, s in spec(name).items()
+               if not k.endswith(("running_mean", "running_var", "num_batches_tracked")))
+
+
+# ---- forward, call site by call site ------------------------------------------------------
+def cna(sd, p, x, stride, training):
+    """ConvNormAct with the defaults the hot path uses: bn + relu (components.py:26-44)."""
+    w = sd[p + "conv.weight"]
+    k = w.shape[-1]
+    pad = math.ceil((k - stride) / 2)  # components.py:31
+    z = F.conv2d(x, w, None, stride, pad)
+    if training:
+        sd[p + "norm.num_batches_tracked"] += 1
+    y = F.batch_norm(z, sd[p + "norm.running_mean"], sd[p + "norm.running_var"], sd[p + "norm.weight"],
+                     sd[p + "norm.bias"], training, BN_MOMENTUM, BN_EPS)
+    return F.relu(y)
+
+
+def darknet_block(sd, p, x, training):
+    return x + cna(sd, p + "conv2.", cna(sd, p + "conv1.", x, 1, training), 1, training)  # darknet.py:27-28
+
+
+def _count(sd, p, stem):
+    n = 0
+    while f"{p}{stem}{n}.conv1.conv.weight" in sd:
+        n += 1
+    return n
+
+
+def darknet_stage(sd, p, x, training):
+    x = cna(sd, p + "conv.", x, 2, training)  # darknet.py:34
+    for j in range(_count(sd, p, "blocks.")):
+        x = darknet_block(sd, p + f"blocks.{j}.", x, training)
+    return x
+
+
+def csp_stage(sd, p, x, training):
+    out = cna(sd, p + "conv.", x, 2, training)  # darknet.py:52
+    a = cna(sd, p + "conv1.", out, 1, training)
+    b = cna(sd, p + "conv2.", out, 1, training)
+    for j in range(_count(sd, p, "blocks.")):
+        b = darknet_block(sd, p + f"blocks.{j}.", b, training)
+    return cna(sd, p + "out_conv.", torch.cat([a, b], dim=1), 1, training)  # darknet.py:53-54
+
+
+def _darknet_like(sd, x, training, stem_stride, csp, keep_stem, prefix=""):
+    outs = [cna(sd, prefix + "stem.", x, stem_stride, training)]
+    i = 0
+    while any(k.startswith(f"{prefix}stages.{i}.") for k in sd):
+        p = f"{prefix}stages.{i}."
+        if p + "conv.weight" in sd:  # bare ConvNormAct stage (darknet.py:79)
+            o = cna(sd, p, outs[-1], 2, training)
+        elif csp:
+            o = csp_stage(sd, p, outs[-1], training)
+        else:
+            o = darknet_stage(sd, p, outs[-1], training)
+        outs.append(o)
+        i += 1
+    return outs if keep_stem else outs[1:]  # darknet.py:87 vs :120
+
+
+def ese_block(sd, p, x):
+    s = F.conv2d(F.adaptive_avg_pool2d(x, 1), sd[p + "linear.weight"], sd[p + "linear.bias"])
+    return x * F.hardsigmoid(s)  # vovnet.py:27-28
+
+
+def osa_block(sd, p, x, training):
+    outs = [x]
+    l = 0
+    while f"{p}convs.{l}.conv.weight" in sd:
+        outs.append(cna(sd, p + f"convs.{l}.", outs[-1], 1, training))  # vovnet.py:52-53
+        l += 1
+    out = cna(sd, p + "out_conv.", torch.cat(outs, dim=1), 1, training)  # vovnet.py:55-56
+    if p + "ese.linear.weight" in sd:
+        out = ese_block(sd, p + "ese.", out)
+    if out.shape[1] == x.shape[1]:  # residual iff in == out (vovnet.py:48,60-61)
+        out = out + x
+    return out
+
+
+def vovnet(sd, x, training, prefix=""):
+    x = cna(sd, prefix + "stem.0.", x, 2, training)  # vovnet.py:84-88
+    x = cna(sd, prefix + "stem.1.", x, 1, training)
+    x = cna(sd, prefix + "stem.2.", x, 1, training)
+    outs = [x]
+    i = 0
+    while any(k.startswith(f"{prefix}stages.{i}.") for k in sd):
+        o = F.max_pool2d(outs[-1], 3, 2, 1)  # vovnet.py:94
+        j = 0
+        while f"{prefix}stages.{i}.module_{j}.out_conv.conv.weight" in sd:
+            o = osa_block(sd, f"{prefix}stages.{i}.module_{j}.", o, training)
+            j += 1
+        outs.append(o)
+        i += 1
+    return outs  # vovnet.py:100-104
+
+
+def feature_maps(name: str, sd, x, training: bool, prefix: str = ""):
+    """get_feature_maps() of backbones.<name>() (base.py:16-21)."""
+    kind, arg = FACTORIES[name]
+    if kind == "darknet":
+        return _darknet_like(sd, x, training, 1, DARKNET[arg][1], False, prefix)
+    if kind == "yolov5":
+        return _darknet_like(sd, x, training, 2, True, True, prefix)
+    return vovnet(sd, x, training, prefix)
+
+
+# ---- harness contract (classifier.py:58-64, 91-92) ---------------------------------------
+def classifier_spec(name: str, num_classes: int) -> "OrderedDict[str, tuple]":
+    """nn.Sequential(backbone, AdaptiveAvgPool2d, Flatten, Linear) -> keys '0.*', '3.*'."""
+    out = OrderedDict(("0." + k, s) for k, s in spec(name).items())
+    out["3.weight"] = (num_classes, out_channels_list(name)[-1])
+    out["3.bias"] = (num_classes,)
+    return out
+
+
+def classifier_logits(name: str, sd, x, training: bool):
+    f = feature_maps(name, sd, x, training, prefix="0.")[-1]
+    return F.linear(torch.flatten(F.adaptive_avg_pool2d(f, 1), 1), sd["3.weight"], sd["3.bias"])
+
+
+def classifier_loss(name: str, sd, x, labels, label_smoothing: float, training: bool = True):
+    logits = classifier_logits(name, sd, x, training)
+    return F.cross_entropy(logits, labels, label_smoothing=label_smoothing), logits
+
+
+def sgd_step(params: dict, grads: dict, momenta: dict, lr: float, momentum: float, weight_decay_of) -> None:
+    """torch.optim.SGD(momentum) as configured by classifier.py:161-169 (dampening 0, no nesterov)."""
+    with torch.no_grad():
+        for k, p in params.items():
+            g = grads[k] + weight_decay_of(k) * p
+            momenta[k] = g.clone() if k not in momenta else momenta[k].mul_(momentum).add_(g)
+            p.sub_(lr * momenta[k])
+
+
+def weight_decay_group(key: str, wd: float, norm_wd: float, bias_wd: float) -> float:
+    """parameter grouping of classifier.py:111-155: norm params / biases / everything else."""
+    if ".norm." in key:
+        return norm_wd
+    if key.endswith(".bias"):
+        return bias_wd
+    return wd

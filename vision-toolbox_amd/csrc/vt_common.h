@@ -1,0 +1,100 @@
+// vt_common.h -- shared device/host helpers for libvt_amd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/vt_amd.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---- host side error plumbing ----------------------------------------------
+void vt_set_error(const char* fmt, ...);
+void vt_count_launch();
+
+#define VT_REQUIRE(cond, code, ...)   \
+    do {                              \
+        if (!(cond)) {                \
+            vt_set_error(__VA_ARGS__); \
+            return (code);            \
+        }                             \
+    } while (0)
+
+#define VT_CHECK_LAUNCH(name)                                                     \
+    do {                                                                          \
+        hipError_t e__ = hipGetLastError();                                       \
+        if (e__ != hipSuccess) {                                                  \
+            vt_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return VT_ERR_HIP;                                                    \
+        }                                                                         \
+        vt_count_launch();                                                        \
+    } while (0)
+
+static inline bool vt_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+static inline int vt_elem_size(int dtype) { return dtype == VT_BF16 ? 2 : 4; }
+static inline int vt_epc(int dtype) { return dtype == VT_BF16 ? 8 : 4; }  // elements per 16 B
+
+// ---- device helpers ----------------------------------------------------------
+template <typename T>
+struct VecIO;  // 16-byte chunk <-> float[EPC]
+
+template <>
+struct VecIO<float> {
+    static constexpr int EPC = 4;
+    __device__ static inline void unpack(const uint4& v, float* f) {
+        f[0] = __uint_as_float(v.x);
+        f[1] = __uint_as_float(v.y);
+        f[2] = __uint_as_float(v.z);
+        f[3] = __uint_as_float(v.w);
+    }
+    __device__ static inline uint4 pack(const float* f) {
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]),
+                          __float_as_uint(f[3]));
+    }
+    __device__ static inline float round(float v) { return v; }
+};
+
+__device__ static inline float bf16_bits_to_float(uint32_t lo16) { return __uint_as_float(lo16 << 16); }
+
+template <>
+struct VecIO<bf16_t> {
+    static constexpr int EPC = 8;
+    __device__ static inline void unpack(const uint4& v, float* f) {
+        f[0] = __uint_as_float(v.x << 16);
+        f[1] = __uint_as_float(v.x & 0xffff0000u);
+        f[2] = __uint_as_float(v.y << 16);
+        f[3] = __uint_as_float(v.y & 0xffff0000u);
+        f[4] = __uint_as_float(v.z << 16);
+        f[5] = __uint_as_float(v.z & 0xffff0000u);
+        f[6] = __uint_as_float(v.w << 16);
+        f[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+    __device__ static inline uint32_t pack2(float a, float b) {
+        // plain casts lower to v_cvt_pk_bf16_f32 (RNE, NaN preserving) on gfx950
+        bf16_t x = (bf16_t)a, y = (bf16_t)b;
+        return (uint32_t)__builtin_bit_cast(unsigned short, x) |
+               ((uint32_t)__builtin_bit_cast(unsigned short, y) << 16);
+    }
+    __device__ static inline uint4 pack(const float* f) {
+        return make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
+    }
+    __device__ static inline float round(float v) { return (float)(bf16_t)v; }
+};
+
+template <typename T>
+__device__ static inline T from_float(float v);
+template <>
+__device__ inline float from_float<float>(float v) { return v; }
+template <>
+__device__ inline bf16_t from_float<bf16_t>(float v) { return (bf16_t)v; }
+
+__device__ static inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

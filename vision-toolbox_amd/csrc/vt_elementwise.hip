@@ -1,0 +1,1063 @@
+// vt_elementwise.hip -- the HBM-bound kernels around the MFMA convolutions:
+// BatchNorm statistics / normalise / backward, ReLU, residual add, pooling,
+// ESE gate, classifier loss, SGD, and the layout / precision plumbing.
+//
+// All activation kernels use one thread mapping ("RowMap"): a thread owns ONE
+// 16-byte channel chunk column and walks rows (pixels), so per-channel
+// coefficients live in registers and consecutive lanes touch consecutive
+// 16-byte chunks of a pixel row (full-line coalesced NHWC accesses, G13).
+#include "vt_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// thread -> (channel chunk column, row lane) for an [M][C] matrix of 16-byte chunks
+struct RowMap {
+    int CPR;  // chunks per row
+    int CT;   // threads along the row
+    int RT;   // rows per block pass
+    int iters;
+    __host__ static RowMap make(int C, int epc, long M, int target_blocks = 4096) {
+        RowMap r;
+        r.CPR = C / epc;
+        r.CT = r.CPR < kThreads ? r.CPR : kThreads;
+        r.RT = kThreads / r.CT;
+        long it = (M + (long)r.RT * target_blocks - 1) / ((long)r.RT * target_blocks);
+        if (it < 1) it = 1;
+        if (it > 64) it = 64;
+        r.iters = (int)it;
+        return r;
+    }
+    __host__ unsigned blocks(long M) const {
+        const long rows_per_block = (long)RT * iters;
+        return (unsigned)((M + rows_per_block - 1) / rows_per_block);
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ uint4 ld16(const T* p) { return *(const uint4*)p; }
+template <typename T>
+__device__ __forceinline__ void st16(T* p, const uint4& v) { *(uint4*)p = v; }
+
+// ---------------------------------------------------------------------------------
+// BatchNorm finalize (training): stats -> mean / invstd / scale / shift + running stats
+// ---------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float eps, float momentum, float* running_mean, float* running_var,
+                                   int64_t* nbt, float* scale, float* shift, float* mean, float* invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) nbt[0] += 1;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int r = 0; r < VT_STAT_REPLICAS; ++r) {
+        s += (double)stats[((long)r * 2 + 0) * C + c];
+        ss += (double)stats[((long)r * 2 + 1) * C + c];
+    }
+    const double mu = s / count;
+    double var = ss / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float istd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * istd;
+    scale[c] = sc;
+    shift[c] = b - (float)mu * sc;
+    mean[c] = (float)mu;
+    invstd[c] = istd;
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, int C, float* scale, float* shift, float* mean, float* invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float istd = 1.f / sqrtf(rv[c] + eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * istd;
+    scale[c] = sc;
+    shift[c] = b - rm[c] * sc;
+    if (mean) mean[c] = rm[c];
+    if (invstd) invstd[c] = istd;
+}
+
+// ---------------------------------------------------------------------------------
+// y = [relu](z*scale + shift) [+ residual]
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+bn_act_apply_kernel(const T* __restrict__ z, int ldz, const float* __restrict__ scale,
+                    const float* __restrict__ shift, const T* __restrict__ res, int ldr, T* __restrict__ y,
+                    int ldy, long M, RowMap rm, int relu) {
+    constexpr int EPC = VecIO<T>::EPC;
+    const int t = threadIdx.x;
+    const int r = t / rm.CT;
+    if (r >= rm.RT) return;
+    const long row0 = (long)blockIdx.x * rm.RT * rm.iters + r;
+    for (int col = t % rm.CT; col < rm.CPR; col += rm.CT) {
+        float sc[EPC], sf[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            sc[e] = scale ? scale[col * EPC + e] : 1.f;
+            sf[e] = shift ? shift[col * EPC + e] : 0.f;
+        }
+        for (int it = 0; it < rm.iters; ++it) {
+            const long row = row0 + (long)it * rm.RT;
+            if (row >= M) break;
+            float v[EPC];
+            VecIO<T>::unpack(ld16(z + row * ldz + col * EPC), v);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                v[e] = fmaf(v[e], sc[e], sf[e]);
+                if (relu) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (res) {
+                float rr[EPC];
+                VecIO<T>::unpack(ld16(res + row * ldr + col * EPC), rr);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] += rr[e];
+            }
+            st16(y + row * ldy + col * EPC, VecIO<T>::pack(v));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// BN backward, pass 1: per-channel sum(g) and sum(g*xhat), g = dy * [z*scale+shift > 0]
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z, int ldz,
+                     const float* __restrict__ scale, const float* __restrict__ shift,
+                     const float* __restrict__ mean, const float* __restrict__ invstd, long M, int C,
+                     RowMap rm, int relu, float* __restrict__ sums) {
+    constexpr int EPC = VecIO<T>::EPC;
+    extern __shared__ float sred[];  // [2][CT*EPC]
+    const int t = threadIdx.x;
+    const int r = t / rm.CT;
+    const long row0 = (long)blockIdx.x * rm.RT * rm.iters + r;
+    const int rep = blockIdx.x % VT_STAT_REPLICAS;
+    for (int cbase = 0; cbase < rm.CPR; cbase += rm.CT) {
+        const int col = cbase + t % rm.CT;
+        const bool active = (r < rm.RT) && (col < rm.CPR);
+        for (int i = t; i < 2 * rm.CT * EPC; i += kThreads) sred[i] = 0.f;
+        __syncthreads();
+        if (active) {
+            float sc[EPC], sf[EPC], mu[EPC], is[EPC], s1[EPC], s2[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                sc[e] = scale[col * EPC + e];
+                sf[e] = shift[col * EPC + e];
+                mu[e] = mean[col * EPC + e];
+                is[e] = invstd[col * EPC + e];
+                s1[e] = 0.f;
+                s2[e] = 0.f;
+            }
+            for (int it = 0; it < rm.iters; ++it) {
+                const long row = row0 + (long)it * rm.RT;
+                if (row >= M) break;
+                float g[EPC], zz[EPC];
+                VecIO<T>::unpack(ld16(dy + row * lddy + col * EPC), g);
+                VecIO<T>::unpack(ld16(z + row * ldz + col * EPC), zz);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float gg = (!relu || fmaf(zz[e], sc[e], sf[e]) > 0.f) ? g[e] : 0.f;
+                    s1[e] += gg;
+                    s2[e] += gg * ((zz[e] - mu[e]) * is[e]);
+                }
+            }
+            const int lc = (t % rm.CT) * EPC;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                atomicAdd(&sred[lc + e], s1[e]);
+                atomicAdd(&sred[rm.CT * EPC + lc + e], s2[e]);
+            }
+        }
+        __syncthreads();
+        for (int i = t; i < 2 * rm.CT * EPC; i += kThreads) {
+            const int which = i / (rm.CT * EPC), lc = i % (rm.CT * EPC);
+            const int c = cbase * EPC + lc;
+            if (c < C) atomicAdd(&sums[((long)rep * 2 + which) * C + c], sred[i]);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, double count,
+                                       const float* __restrict__ scale, const float* __restrict__ mean,
+                                       const float* __restrict__ invstd, int train, float* dgamma,
+                                       float* dbeta, float* coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < VT_STAT_REPLICAS; ++r) {
+        s1 += (double)sums[((long)r * 2 + 0) * C + c];
+        s2 += (double)sums[((long)r * 2 + 1) * C + c];
+    }
+    if (dgamma) dgamma[c] += (float)s2;
+    if (dbeta) dbeta[c] += (float)s1;
+    const float a = scale[c];
+    float b = 0.f, d = 0.f;
+    if (train) {
+        const double c1 = s1 / count, c2 = s2 / count;
+        const double bb = (double)a * c2 * (double)invstd[c];
+        b = (float)bb;
+        d = (float)(bb * (double)mean[c] - (double)a * c1);
+    }
+    coef[c] = a;
+    coef[C + c] = b;
+    coef[2 * C + c] = d;
+}
+
+// dz = a*g - b*z + d
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z, int ldz,
+                    const float* __restrict__ scale, const float* __restrict__ shift,
+                    const float* __restrict__ coef, T* __restrict__ dz, int lddz, long M, int C, RowMap rm,
+                    int relu) {
+    constexpr int EPC = VecIO<T>::EPC;
+    const int t = threadIdx.x;
+    const int r = t / rm.CT;
+    if (r >= rm.RT) return;
+    const long row0 = (long)blockIdx.x * rm.RT * rm.iters + r;
+    for (int col = t % rm.CT; col < rm.CPR; col += rm.CT) {
+        float sc[EPC], sf[EPC], ca[EPC], cb[EPC], cd[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const int c = col * EPC + e;
+            sc[e] = scale[c];
+            sf[e] = shift[c];
+            ca[e] = coef[c];
+            cb[e] = coef[C + c];
+            cd[e] = coef[2 * C + c];
+        }
+        for (int it = 0; it < rm.iters; ++it) {
+            const long row = row0 + (long)it * rm.RT;
+            if (row >= M) break;
+            float g[EPC], zz[EPC];
+            VecIO<T>::unpack(ld16(dy + row * lddy + col * EPC), g);
+            VecIO<T>::unpack(ld16(z + row * ldz + col * EPC), zz);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float gg = (!relu || fmaf(zz[e], sc[e], sf[e]) > 0.f) ? g[e] : 0.f;
+                g[e] = fmaf(ca[e], gg, fmaf(-cb[e], zz[e], cd[e]));
+            }
+            st16(dz + row * lddz + col * EPC, VecIO<T>::pack(g));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// MaxPool2d(3, 2, 1)
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+maxpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, uint8_t* __restrict__ amax,
+                   int H, int W, int Ho, int Wo, int C, long Mo, RowMap rm) {
+    constexpr int EPC = VecIO<T>::EPC;
+    const int t = threadIdx.x;
+    const int r = t / rm.CT;
+    if (r >= rm.RT) return;
+    const long row0 = (long)blockIdx.x * rm.RT * rm.iters + r;
+    for (int col = t % rm.CT; col < rm.CPR; col += rm.CT) {
+        for (int it = 0; it < rm.iters; ++it) {
+            const long row = row0 + (long)it * rm.RT;
+            if (row >= Mo) break;
+            const int wo = (int)(row % Wo);
+            const long t2 = row / Wo;
+            const int ho = (int)(t2 % Ho);
+            const long b = t2 / Ho;
+            float best[EPC];
+            int bi[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                best[e] = -INFINITY;
+                bi[e] = 0;
+            }
+            bool first = true;
+#pragma unroll
+            for (int dr = 0; dr < 3; ++dr) {
+#pragma unroll
+                for (int dc = 0; dc < 3; ++dc) {
+                    const int h = ho * 2 - 1 + dr, w = wo * 2 - 1 + dc;
+                    if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+                        float v[EPC];
+                        VecIO<T>::unpack(ld16(x + ((b * H + h) * W + w) * ldx + col * EPC), v);
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) {
+                            // ATen: first max in (kh, kw) scan order wins; NaN propagates
+                            if (first || v[e] > best[e] || v[e] != v[e]) {
+                                best[e] = v[e];
+                                bi[e] = dr * 3 + dc;
+                            }
+                        }
+                        first = false;
+                    }
+                }
+            }
+            st16(y + row * ldy + col * EPC, VecIO<T>::pack(best));
+            uint8_t* ap = amax + row * C + col * EPC;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) ap[e] = (uint8_t)bi[e];
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+maxpool_bwd_kernel(const T* __restrict__ dy, int lddy, const uint8_t* __restrict__ amax, T* __restrict__ dx,
+                   int lddx, int H, int W, int Ho, int Wo, int C, long Mi, RowMap rm, int accumulate) {
+    constexpr int EPC = VecIO<T>::EPC;
+    const int t = threadIdx.x;
+    const int r = t / rm.CT;
+    if (r >= rm.RT) return;
+    const long row0 = (long)blockIdx.x * rm.RT * rm.iters + r;
+    for (int col = t % rm.CT; col < rm.CPR; col += rm.CT) {
+        for (int it = 0; it < rm.iters; ++it) {
+            const long row = row0 + (long)it * rm.RT;
+            if (row >= Mi) break;
+            const int w = (int)(row % W);
+            const long t2 = row / W;
+            const int h = (int)(t2 % H);
+            const long b = t2 / H;
+            float acc[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+            if (accumulate) VecIO<T>::unpack(ld16(dx + row * lddx + col * EPC), acc);
+            // windows (ho, wo) with ho*2-1 <= h <= ho*2+1
+            const int ho_lo = h >> 1, ho_hi = (h + 1) >> 1;
+            const int wo_lo = w >> 1, wo_hi = (w + 1) >> 1;
+            for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+                if (ho >= Ho) continue;
+                for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                    if (wo >= Wo) continue;
+                    const int tap = (h - (ho * 2 - 1)) * 3 + (w - (wo * 2 - 1));
+                    const long orow = (b * Ho + ho) * Wo + wo;
+                    float g[EPC];
+                    VecIO<T>::unpack(ld16(dy + orow * lddy + col * EPC), g);
+                    const uint8_t* ap = amax + orow * C + col * EPC;
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e)
+                        if (ap[e] == tap) acc[e] += g[e];
+                }
+            }
+            st16(dx + row * lddx + col * EPC, VecIO<T>::pack(acc));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// global average pool: y[b][c] = mean_hw x[b][hw][c]; one block per (b, column group)
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+avgpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int HW, int C, int CT) {
+    constexpr int EPC = VecIO<T>::EPC;
+    extern __shared__ float sred[];  // [CT*EPC]
+    const int t = threadIdx.x;
+    const int RT = kThreads / CT;
+    const int b = blockIdx.x;
+    const int col = blockIdx.y * CT + t % CT;
+    const int r = t / CT;
+    const int CPR = C / EPC;
+    for (int i = t; i < CT * EPC; i += kThreads) sred[i] = 0.f;
+    __syncthreads();
+    if (r < RT && col < CPR) {
+        float s[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s[e] = 0.f;
+        for (int hw = r; hw < HW; hw += RT) {
+            float v[EPC];
+            VecIO<T>::unpack(ld16(x + ((long)b * HW + hw) * ldx + col * EPC), v);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) s[e] += v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) atomicAdd(&sred[(t % CT) * EPC + e], s[e]);
+    }
+    __syncthreads();
+    if (r == 0 && col < CPR) {
+        float v[EPC];
+        const float inv = 1.f / (float)HW;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] = sred[(t % CT) * EPC + e] * inv;
+        st16(y + (long)b * ldy + col * EPC, VecIO<T>::pack(v));
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+avgpool_bwd_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx, int lddx, int HW, long M, RowMap rm,
+                   int accumulate) {
+    constexpr int EPC = VecIO<T>::EPC;
+    const int t = threadIdx.x;
+    const int r = t / rm.CT;
+    if (r >= rm.RT) return;
+    const long row0 = (long)blockIdx.x * rm.RT * rm.iters + r;
+    const float inv = 1.f / (float)HW;
+    for (int col = t % rm.CT; col < rm.CPR; col += rm.CT) {
+        for (int it = 0; it < rm.iters; ++it) {
+            const long row = row0 + (long)it * rm.RT;
+            if (row >= M) break;
+            const long b = row / HW;
+            float g[EPC], a[EPC];
+            VecIO<T>::unpack(ld16(dy + b * lddy + col * EPC), g);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) a[e] = 0.f;
+            if (accumulate) VecIO<T>::unpack(ld16(dx + row * lddx + col * EPC), a);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) a[e] += g[e] * inv;
+            st16(dx + row * lddx + col * EPC, VecIO<T>::pack(a));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// ESE gate: y = x * hardsigmoid(s[b][c]) [+ residual]
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float hsig(float v) { return fminf(fmaxf(v * (1.f / 6.f) + 0.5f, 0.f), 1.f); }
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+ese_fwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ s, int lds, const T* __restrict__ res,
+               int ldr, T* __restrict__ y, int ldy, int HW, long M, RowMap rm) {
+    constexpr int EPC = VecIO<T>::EPC;
+    const int t = threadIdx.x;
+    const int r = t / rm.CT;
+    if (r >= rm.RT) return;
+    const long row0 = (long)blockIdx.x * rm.RT * rm.iters + r;
+    for (int col = t % rm.CT; col < rm.CPR; col += rm.CT) {
+        for (int it = 0; it < rm.iters; ++it) {
+            const long row = row0 + (long)it * rm.RT;
+            if (row >= M) break;
+            const long b = row / HW;
+            float v[EPC], g[EPC];
+            VecIO<T>::unpack(ld16(x + row * ldx + col * EPC), v);
+            VecIO<T>::unpack(ld16(s + b * lds + col * EPC), g);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) v[e] *= hsig(g[e]);
+            if (res) {
+                float rr[EPC];
+                VecIO<T>::unpack(ld16(res + row * ldr + col * EPC), rr);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] += rr[e];
+            }
+            st16(y + row * ldy + col * EPC, VecIO<T>::pack(v));
+        }
+    }
+}
+
+// one block per (b, column group): dx (=|+=) dy*hsig(s); ds[b][c] = hsig'(s) * sum_hw dy*x
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+ese_bwd_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int ldx, const T* __restrict__ s,
+               int lds, T* __restrict__ dx, int lddx, float* __restrict__ ds, int HW, int C, int CT,
+               int accumulate) {
+    constexpr int EPC = VecIO<T>::EPC;
+    extern __shared__ float sred[];
+    const int t = threadIdx.x;
+    const int RT = kThreads / CT;
+    const int b = blockIdx.x;
+    const int col = blockIdx.y * CT + t % CT;
+    const int r = t / CT;
+    const int CPR = C / EPC;
+    for (int i = t; i < CT * EPC; i += kThreads) sred[i] = 0.f;
+    __syncthreads();
+    float sv[EPC];
+    if (r < RT && col < CPR) {
+        VecIO<T>::unpack(ld16(s + (long)b * lds + col * EPC), sv);
+        float acc[EPC], gate[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            acc[e] = 0.f;
+            gate[e] = hsig(sv[e]);
+        }
+        for (int hw = r; hw < HW; hw += RT) {
+            const long row = (long)b * HW + hw;
+            float g[EPC], xv[EPC], o[EPC];
+            VecIO<T>::unpack(ld16(dy + row * lddy + col * EPC), g);
+            VecIO<T>::unpack(ld16(x + row * ldx + col * EPC), xv);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o[e] = 0.f;
+            if (accumulate) VecIO<T>::unpack(ld16(dx + row * lddx + col * EPC), o);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                acc[e] += g[e] * xv[e];
+                o[e] += g[e] * gate[e];
+            }
+            st16(dx + row * lddx + col * EPC, VecIO<T>::pack(o));
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) atomicAdd(&sred[(t % CT) * EPC + e], acc[e]);
+    }
+    __syncthreads();
+    if (r == 0 && col < CPR) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float d = (sv[e] > -3.f && sv[e] < 3.f) ? (1.f / 6.f) : 0.f;
+            ds[(long)b * C + col * EPC + e] = sred[(t % CT) * EPC + e] * d;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// column sums (bias gradients)
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+colsum_kernel(const T* __restrict__ a, int lda, long M, int C, RowMap rm, float* __restrict__ out) {
+    constexpr int EPC = VecIO<T>::EPC;
+    const int t = threadIdx.x;
+    const int r = t / rm.CT;
+    if (r >= rm.RT) return;
+    const long row0 = (long)blockIdx.x * rm.RT * rm.iters + r;
+    for (int col = t % rm.CT; col < rm.CPR; col += rm.CT) {
+        float s[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s[e] = 0.f;
+        for (int it = 0; it < rm.iters; ++it) {
+            const long row = row0 + (long)it * rm.RT;
+            if (row >= M) break;
+            float v[EPC];
+            VecIO<T>::unpack(ld16(a + row * lda + col * EPC), v);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) s[e] += v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) atomicAdd(&out[col * EPC + e], s[e]);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// softmax cross entropy with label smoothing, mean reduction, fused gradient
+// ---------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ float ldf(const T* p) { return (float)(*p); }
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+xent_kernel(const T* __restrict__ logits, int ldl, const int64_t* __restrict__ labels, float eps,
+            float grad_scale, float* __restrict__ loss, T* __restrict__ dlogits, int lddl, int B, int N) {
+    __shared__ float sred[kThreads / 64];
+    __shared__ float sbc;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const T* lp = logits + (long)b * ldl;
+    float mx = -INFINITY;
+    for (int i = t; i < N; i += kThreads) mx = fmaxf(mx, ldf(lp + i));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((t & 63) == 0) sred[t >> 6] = mx;
+    __syncthreads();
+    if (t == 0) {
+        float m = sred[0];
+        for (int i = 1; i < kThreads / 64; ++i) m = fmaxf(m, sred[i]);
+        sbc = m;
+    }
+    __syncthreads();
+    mx = sbc;
+    __syncthreads();
+    float se = 0.f, sz = 0.f;
+    for (int i = t; i < N; i += kThreads) {
+        const float v = ldf(lp + i);
+        se += expf(v - mx);
+        sz += v;
+    }
+    se = wave_sum(se);
+    sz = wave_sum(sz);
+    __shared__ float sred2[kThreads / 64];
+    if ((t & 63) == 0) {
+        sred[t >> 6] = se;
+        sred2[t >> 6] = sz;
+    }
+    __syncthreads();
+    float tse = 0.f, tsz = 0.f;
+    for (int i = 0; i < kThreads / 64; ++i) {
+        tse += sred[i];
+        tsz += sred2[i];
+    }
+    const float lse = mx + logf(tse);
+    const int64_t yb = labels[b];
+    if (t == 0) {
+        const float zy = ldf(lp + yb);
+        const float l = lse - (1.f - eps) * zy - (eps / (float)N) * tsz;
+        atomicAdd(loss, l / (float)B);
+    }
+    if (dlogits) {
+        T* dp = dlogits + (long)b * lddl;
+        const float q0 = eps / (float)N;
+        for (int i = t; i < N; i += kThreads) {
+            const float pr = expf(ldf(lp + i) - lse);
+            const float q = q0 + ((int64_t)i == yb ? 1.f - eps : 0.f);
+            dp[i] = from_float<T>((pr - q) * grad_scale);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// SGD with momentum over a flat f32 buffer (+ optional low-precision mirror)
+// ---------------------------------------------------------------------------------
+template <typename MT>
+__global__ void __launch_bounds__(kThreads)
+sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, MT* __restrict__ mirror,
+           long n, float lr, float mu, float wd, float gs, const float* __restrict__ lr_dev) {
+    if (lr_dev) lr = lr_dev[0];
+    const long stride = (long)gridDim.x * kThreads * 4;
+    for (long i = ((long)blockIdx.x * kThreads + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n) {
+            float4 pv = *(float4*)(p + i);
+            const float4 gv = *(const float4*)(g + i);
+            float4 mv = *(float4*)(m + i);
+            float* pp = (float*)&pv;
+            const float* gp = (const float*)&gv;
+            float* mp = (float*)&mv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gg = fmaf(wd, pp[e], gp[e] * gs);
+                mp[e] = fmaf(mu, mp[e], gg);
+                pp[e] = fmaf(-lr, mp[e], pp[e]);
+            }
+            *(float4*)(p + i) = pv;
+            *(float4*)(m + i) = mv;
+            if (mirror) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mirror[i + e] = from_float<MT>(pp[e]);
+            }
+        } else {
+            for (long j = i; j < n; ++j) {
+                const float gg = fmaf(wd, p[j], g[j] * gs);
+                m[j] = fmaf(mu, m[j], gg);
+                p[j] = fmaf(-lr, m[j], p[j]);
+                if (mirror) mirror[j] = from_float<MT>(p[j]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// layout / precision plumbing
+// ---------------------------------------------------------------------------------
+template <typename S, typename D>
+__global__ void __launch_bounds__(kThreads)
+copy2d_kernel(const S* __restrict__ src, long lds, D* __restrict__ dst, long ldd, long rows, int cols,
+              int accumulate) {
+    const long total = rows * cols;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+        const long r = i / cols;
+        const int c = (int)(i - r * cols);
+        float v = (float)src[r * lds + c];
+        if (accumulate) v += (float)dst[r * ldd + c];
+        dst[r * ldd + c] = from_float<D>(v);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int C, long HW, int Cpad, long total) {
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+        const long b = i / HW, hw = i - b * HW;
+        for (int c = 0; c < Cpad; ++c) {
+            const float v = c < C ? x[(b * C + c) * HW + hw] : 0.f;
+            y[i * Cpad + c] = from_float<T>(v);
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+nhwc_to_nchw_kernel(const T* __restrict__ y, int ldy, float* __restrict__ x, int C, long HW, long total) {
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+        const long b = i / HW, hw = i - b * HW;
+        for (int c = 0; c < C; ++c) x[(b * C + c) * HW + hw] = (float)y[i * ldy + c];
+    }
+}
+
+struct SelTable {
+    int sel[VT_MAX_TAPS];
+};
+
+// out[c][i][n] = w[n][sel[i]][c]
+template <typename S, typename D>
+__global__ void __launch_bounds__(kThreads)
+pack_dgrad_kernel(const S* __restrict__ w, int ldw, D* __restrict__ out, SelTable st, int nsel, int Cout,
+                  int Cin, long total) {
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+        const int n = (int)(i % Cout);
+        const long t2 = i / Cout;
+        const int s = (int)(t2 % nsel);
+        const int c = (int)(t2 / nsel);
+        out[i] = from_float<D>((float)w[(long)n * ldw + (long)st.sel[s] * Cin + c]);
+    }
+}
+
+inline unsigned flat_blocks(long total, int per_thread = 1) {
+    long b = (total + (long)kThreads * per_thread - 1) / ((long)kThreads * per_thread);
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+#define VT_DISPATCH_T(dtype, NAME, ...)                               \
+    do {                                                              \
+        if ((dtype) == VT_BF16) {                                     \
+            typedef bf16_t T;                                         \
+            __VA_ARGS__;                                              \
+        } else if ((dtype) == VT_F32) {                               \
+            typedef float T;                                          \
+            __VA_ARGS__;                                              \
+        } else {                                                      \
+            vt_set_error("%s: unsupported dtype %d", NAME, (dtype)); \
+            return VT_ERR_UNSUPPORTED;                                \
+        }                                                             \
+    } while (0)
+
+inline int check_mat(const char* name, const void* p, int ld, int C, int dtype) {
+    const int epc = vt_epc(dtype);
+    if (!p || !vt_aligned16(p)) {
+        vt_set_error("%s: null or misaligned pointer", name);
+        return VT_ERR_INVALID;
+    }
+    if (C <= 0 || C % epc || ld % epc || ld < C) {
+        vt_set_error("%s: C=%d ld=%d must be positive multiples of %d with ld>=C", name, C, ld, epc);
+        return VT_ERR_UNSUPPORTED;
+    }
+    return VT_OK;
+}
+#define VT_TRY(expr)              \
+    do {                          \
+        int rc__ = (expr);        \
+        if (rc__ != VT_OK) return rc__; \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int vt_bn_finalize(const float* stats, int32_t C, double count, const float* gamma, const float* beta,
+                   float eps, float momentum, float* running_mean, float* running_var,
+                   int64_t* num_batches_tracked, float* scale, float* shift, float* mean, float* invstd,
+                   void* stream) {
+    VT_REQUIRE(stats && scale && shift && mean && invstd && C > 0 && count > 0, VT_ERR_INVALID,
+               "vt_bn_finalize: bad argument");
+    VT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), VT_ERR_INVALID,
+               "vt_bn_finalize: running_mean/var must both be given or both NULL");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, C,
+                       count, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked,
+                       scale, shift, mean, invstd);
+    VT_CHECK_LAUNCH("vt_bn_finalize");
+    return VT_OK;
+}
+
+int vt_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, int32_t C, float* scale, float* shift,
+                      float* mean, float* invstd, void* stream) {
+    VT_REQUIRE(running_mean && running_var && scale && shift && C > 0, VT_ERR_INVALID,
+               "vt_bn_eval_coeffs: bad argument");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma,
+                       beta, running_mean, running_var, eps, C, scale, shift, mean, invstd);
+    VT_CHECK_LAUNCH("vt_bn_eval_coeffs");
+    return VT_OK;
+}
+
+int vt_bn_act_apply(const void* z, int32_t ldz, const float* scale, const float* shift, const void* residual,
+                    int32_t ldr, void* y, int32_t ldy, int64_t M, int32_t C, int32_t relu, int32_t dtype,
+                    void* stream) {
+    VT_REQUIRE(M > 0, VT_ERR_INVALID, "vt_bn_act_apply: M=%ld", (long)M);
+    VT_TRY(check_mat("vt_bn_act_apply(z)", z, ldz, C, dtype));
+    VT_TRY(check_mat("vt_bn_act_apply(y)", y, ldy, C, dtype));
+    if (residual) VT_TRY(check_mat("vt_bn_act_apply(residual)", residual, ldr, C, dtype));
+    const RowMap rm = RowMap::make(C, vt_epc(dtype), M);
+    VT_DISPATCH_T(dtype, "vt_bn_act_apply",
+                  hipLaunchKernelGGL(bn_act_apply_kernel<T>, dim3(rm.blocks(M)), dim3(kThreads), 0,
+                                     (hipStream_t)stream, (const T*)z, ldz, scale, shift, (const T*)residual,
+                                     ldr, (T*)y, ldy, (long)M, rm, relu));
+    VT_CHECK_LAUNCH("vt_bn_act_apply");
+    return VT_OK;
+}
+
+int vt_bn_act_bwd_reduce(const void* dy, int32_t lddy, const void* z, int32_t ldz, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, int64_t M, int32_t C,
+                         int32_t relu, int32_t dtype, float* sums, void* stream) {
+    VT_REQUIRE(M > 0 && scale && shift && mean && invstd && sums, VT_ERR_INVALID,
+               "vt_bn_act_bwd_reduce: bad argument");
+    VT_TRY(check_mat("vt_bn_act_bwd_reduce(dy)", dy, lddy, C, dtype));
+    VT_TRY(check_mat("vt_bn_act_bwd_reduce(z)", z, ldz, C, dtype));
+    const int epc = vt_epc(dtype);
+    const RowMap rm = RowMap::make(C, epc, M, 2048);
+    const int smem = 2 * rm.CT * epc * (int)sizeof(float);
+    VT_DISPATCH_T(dtype, "vt_bn_act_bwd_reduce",
+                  hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(rm.blocks(M)), dim3(kThreads), smem,
+                                     (hipStream_t)stream, (const T*)dy, lddy, (const T*)z, ldz, scale, shift,
+                                     mean, invstd, (long)M, C, rm, relu, sums));
+    VT_CHECK_LAUNCH("vt_bn_act_bwd_reduce");
+    return VT_OK;
+}
+
+int vt_bn_bwd_finalize(const float* sums, int32_t C, double count, const float* scale, const float* mean,
+                       const float* invstd, int32_t train, float* dgamma, float* dbeta, float* coef,
+                       void* stream) {
+    VT_REQUIRE(sums && scale && mean && invstd && coef && C > 0 && count > 0, VT_ERR_INVALID,
+               "vt_bn_bwd_finalize: bad argument");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums,
+                       C, count, scale, mean, invstd, train, dgamma, dbeta, coef);
+    VT_CHECK_LAUNCH("vt_bn_bwd_finalize");
+    return VT_OK;
+}
+
+int vt_bn_act_bwd_apply(const void* dy, int32_t lddy, const void* z, int32_t ldz, const float* scale,
+                        const float* shift, const float* coef, void* dz, int32_t lddz, int64_t M, int32_t C,
+                        int32_t relu, int32_t dtype, void* stream) {
+    VT_REQUIRE(M > 0 && scale && shift && coef, VT_ERR_INVALID, "vt_bn_act_bwd_apply: bad argument");
+    VT_TRY(check_mat("vt_bn_act_bwd_apply(dy)", dy, lddy, C, dtype));
+    VT_TRY(check_mat("vt_bn_act_bwd_apply(z)", z, ldz, C, dtype));
+    VT_TRY(check_mat("vt_bn_act_bwd_apply(dz)", dz, lddz, C, dtype));
+    const RowMap rm = RowMap::make(C, vt_epc(dtype), M);
+    VT_DISPATCH_T(dtype, "vt_bn_act_bwd_apply",
+                  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(rm.blocks(M)), dim3(kThreads), 0,
+                                     (hipStream_t)stream, (const T*)dy, lddy, (const T*)z, ldz, scale, shift,
+                                     coef, (T*)dz, lddz, (long)M, C, rm, relu));
+    VT_CHECK_LAUNCH("vt_bn_act_bwd_apply");
+    return VT_OK;
+}
+
+static inline int pool_out(int n) { return (n + 2 - 3) / 2 + 1; }
+
+int vt_maxpool3x3s2_fwd(const void* x, int32_t ldx, void* y, int32_t ldy, uint8_t* argmax, int32_t B,
+                        int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
+    VT_REQUIRE(B > 0 && H > 0 && W > 0 && argmax, VT_ERR_INVALID, "vt_maxpool3x3s2_fwd: bad argument");
+    VT_TRY(check_mat("vt_maxpool3x3s2_fwd(x)", x, ldx, C, dtype));
+    VT_TRY(check_mat("vt_maxpool3x3s2_fwd(y)", y, ldy, C, dtype));
+    const int Ho = pool_out(H), Wo = pool_out(W);
+    const long Mo = (long)B * Ho * Wo;
+    const RowMap rm = RowMap::make(C, vt_epc(dtype), Mo);
+    VT_DISPATCH_T(dtype, "vt_maxpool3x3s2_fwd",
+                  hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(rm.blocks(Mo)), dim3(kThreads), 0,
+                                     (hipStream_t)stream, (const T*)x, ldx, (T*)y, ldy, argmax, H, W, Ho, Wo,
+                                     C, Mo, rm));
+    VT_CHECK_LAUNCH("vt_maxpool3x3s2_fwd");
+    return VT_OK;
+}
+
+int vt_maxpool3x3s2_bwd(const void* dy, int32_t lddy, const uint8_t* argmax, void* dx, int32_t lddx,
+                        int32_t B, int32_t H, int32_t W, int32_t C, int32_t accumulate, int32_t dtype,
+                        void* stream) {
+    VT_REQUIRE(B > 0 && H > 0 && W > 0 && argmax, VT_ERR_INVALID, "vt_maxpool3x3s2_bwd: bad argument");
+    VT_TRY(check_mat("vt_maxpool3x3s2_bwd(dy)", dy, lddy, C, dtype));
+    VT_TRY(check_mat("vt_maxpool3x3s2_bwd(dx)", dx, lddx, C, dtype));
+    const int Ho = pool_out(H), Wo = pool_out(W);
+    const long Mi = (long)B * H * W;
+    const RowMap rm = RowMap::make(C, vt_epc(dtype), Mi);
+    VT_DISPATCH_T(dtype, "vt_maxpool3x3s2_bwd",
+                  hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(rm.blocks(Mi)), dim3(kThreads), 0,
+                                     (hipStream_t)stream, (const T*)dy, lddy, argmax, (T*)dx, lddx, H, W, Ho,
+                                     Wo, C, Mi, rm, accumulate));
+    VT_CHECK_LAUNCH("vt_maxpool3x3s2_bwd");
+    return VT_OK;
+}
+
+static inline int pool_ct(int C, int epc) {
+    int cpr = C / epc;
+    int ct = 1;
+    while (ct < cpr && ct < 64) ct <<= 1;
+    return ct;
+}
+
+int vt_global_avgpool_fwd(const void* x, int32_t ldx, void* y, int32_t ldy, int32_t B, int32_t HW, int32_t C,
+                          int32_t dtype, void* stream) {
+    VT_REQUIRE(B > 0 && HW > 0, VT_ERR_INVALID, "vt_global_avgpool_fwd: bad argument");
+    VT_TRY(check_mat("vt_global_avgpool_fwd(x)", x, ldx, C, dtype));
+    VT_TRY(check_mat("vt_global_avgpool_fwd(y)", y, ldy, C, dtype));
+    const int epc = vt_epc(dtype);
+    const int CT = pool_ct(C, epc);
+    const dim3 grid(B, (C / epc + CT - 1) / CT);
+    VT_DISPATCH_T(dtype, "vt_global_avgpool_fwd",
+                  hipLaunchKernelGGL(avgpool_fwd_kernel<T>, grid, dim3(kThreads), CT * epc * sizeof(float),
+                                     (hipStream_t)stream, (const T*)x, ldx, (T*)y, ldy, HW, C, CT));
+    VT_CHECK_LAUNCH("vt_global_avgpool_fwd");
+    return VT_OK;
+}
+
+int vt_global_avgpool_bwd(const void* dy, int32_t lddy, void* dx, int32_t lddx, int32_t B, int32_t HW,
+                          int32_t C, int32_t accumulate, int32_t dtype, void* stream) {
+    VT_REQUIRE(B > 0 && HW > 0, VT_ERR_INVALID, "vt_global_avgpool_bwd: bad argument");
+    VT_TRY(check_mat("vt_global_avgpool_bwd(dy)", dy, lddy, C, dtype));
+    VT_TRY(check_mat("vt_global_avgpool_bwd(dx)", dx, lddx, C, dtype));
+    const long M = (long)B * HW;
+    const RowMap rm = RowMap::make(C, vt_epc(dtype), M);
+    VT_DISPATCH_T(dtype, "vt_global_avgpool_bwd",
+                  hipLaunchKernelGGL(avgpool_bwd_kernel<T>, dim3(rm.blocks(M)), dim3(kThreads), 0,
+                                     (hipStream_t)stream, (const T*)dy, lddy, (T*)dx, lddx, HW, M, rm,
+                                     accumulate));
+    VT_CHECK_LAUNCH("vt_global_avgpool_bwd");
+    return VT_OK;
+}
+
+int vt_ese_gate_fwd(const void* x, int32_t ldx, const void* s, int32_t lds, const void* residual, int32_t ldr,
+                    void* y, int32_t ldy, int32_t B, int32_t HW, int32_t C, int32_t dtype, void* stream) {
+    VT_REQUIRE(B > 0 && HW > 0, VT_ERR_INVALID, "vt_ese_gate_fwd: bad argument");
+    VT_TRY(check_mat("vt_ese_gate_fwd(x)", x, ldx, C, dtype));
+    VT_TRY(check_mat("vt_ese_gate_fwd(s)", s, lds, C, dtype));
+    VT_TRY(check_mat("vt_ese_gate_fwd(y)", y, ldy, C, dtype));
+    if (residual) VT_TRY(check_mat("vt_ese_gate_fwd(residual)", residual, ldr, C, dtype));
+    const long M = (long)B * HW;
+    const RowMap rm = RowMap::make(C, vt_epc(dtype), M);
+    VT_DISPATCH_T(dtype, "vt_ese_gate_fwd",
+                  hipLaunchKernelGGL(ese_fwd_kernel<T>, dim3(rm.blocks(M)), dim3(kThreads), 0,
+                                     (hipStream_t)stream, (const T*)x, ldx, (const T*)s, lds,
+                                     (const T*)residual, ldr, (T*)y, ldy, HW, M, rm));
+    VT_CHECK_LAUNCH("vt_ese_gate_fwd");
+    return VT_OK;
+}
+
+int vt_ese_gate_bwd(const void* dy, int32_t lddy, const void* x, int32_t ldx, const void* s, int32_t lds,
+                    void* dx, int32_t lddx, float* ds, int32_t B, int32_t HW, int32_t C, int32_t accumulate,
+                    int32_t dtype, void* stream) {
+    VT_REQUIRE(B > 0 && HW > 0 && ds, VT_ERR_INVALID, "vt_ese_gate_bwd: bad argument");
+    VT_TRY(check_mat("vt_ese_gate_bwd(dy)", dy, lddy, C, dtype));
+    VT_TRY(check_mat("vt_ese_gate_bwd(x)", x, ldx, C, dtype));
+    VT_TRY(check_mat("vt_ese_gate_bwd(s)", s, lds, C, dtype));
+    VT_TRY(check_mat("vt_ese_gate_bwd(dx)", dx, lddx, C, dtype));
+    const int epc = vt_epc(dtype);
+    const int CT = pool_ct(C, epc);
+    const dim3 grid(B, (C / epc + CT - 1) / CT);
+    VT_DISPATCH_T(dtype, "vt_ese_gate_bwd",
+                  hipLaunchKernelGGL(ese_bwd_kernel<T>, grid, dim3(kThreads), CT * epc * sizeof(float),
+                                     (hipStream_t)stream, (const T*)dy, lddy, (const T*)x, ldx, (const T*)s,
+                                     lds, (T*)dx, lddx, ds, HW, C, CT, accumulate));
+    VT_CHECK_LAUNCH("vt_ese_gate_bwd");
+    return VT_OK;
+}
+
+int vt_colsum(const void* a, int32_t lda, int64_t M, int32_t C, int32_t dtype, float* out, void* stream) {
+    VT_REQUIRE(M > 0 && out, VT_ERR_INVALID, "vt_colsum: bad argument");
+    VT_TRY(check_mat("vt_colsum(a)", a, lda, C, dtype));
+    const RowMap rm = RowMap::make(C, vt_epc(dtype), M, 256);
+    VT_DISPATCH_T(dtype, "vt_colsum",
+                  hipLaunchKernelGGL(colsum_kernel<T>, dim3(rm.blocks(M)), dim3(kThreads), 0,
+                                     (hipStream_t)stream, (const T*)a, lda, (long)M, C, rm, out));
+    VT_CHECK_LAUNCH("vt_colsum");
+    return VT_OK;
+}
+
+int vt_softmax_xent(const void* logits, int32_t ldl, const int64_t* labels, float label_smoothing,
+                    float grad_scale, float* loss, void* dlogits, int32_t lddl, int32_t B, int32_t N,
+                    int32_t dtype, void* stream) {
+    VT_REQUIRE(logits && labels && loss && B > 0 && N > 0 && ldl >= N, VT_ERR_INVALID,
+               "vt_softmax_xent: bad argument");
+    VT_REQUIRE(!dlogits || lddl >= N, VT_ERR_INVALID, "vt_softmax_xent: lddl < N");
+    VT_DISPATCH_T(dtype, "vt_softmax_xent",
+                  hipLaunchKernelGGL(xent_kernel<T>, dim3(B), dim3(kThreads), 0, (hipStream_t)stream,
+                                     (const T*)logits, ldl, labels, label_smoothing, grad_scale, loss,
+                                     (T*)dlogits, lddl, B, N));
+    VT_CHECK_LAUNCH("vt_softmax_xent");
+    return VT_OK;
+}
+
+int vt_sgd_momentum(float* p, const float* g, float* m, void* mirror, int32_t mirror_dtype, int64_t n,
+                    float lr, float momentum, float weight_decay, float grad_scale, const float* lr_dev,
+                    void* stream) {
+    VT_REQUIRE(p && g && m && n > 0, VT_ERR_INVALID, "vt_sgd_momentum: bad argument");
+    VT_REQUIRE(vt_aligned16(p) && vt_aligned16(g) && vt_aligned16(m), VT_ERR_INVALID,
+               "vt_sgd_momentum: p/g/m must be 16-byte aligned");
+    const unsigned blocks = flat_blocks(n, 4);
+    if (mirror && mirror_dtype == VT_BF16)
+        hipLaunchKernelGGL(sgd_kernel<bf16_t>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, p, g, m,
+                           (bf16_t*)mirror, (long)n, lr, momentum, weight_decay, grad_scale, lr_dev);
+    else if (mirror && mirror_dtype != VT_F32) {
+        vt_set_error("vt_sgd_momentum: mirror dtype %d", mirror_dtype);
+        return VT_ERR_UNSUPPORTED;
+    } else
+        hipLaunchKernelGGL(sgd_kernel<float>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, p, g, m,
+                           (float*)mirror, (long)n, lr, momentum, weight_decay, grad_scale, lr_dev);
+    VT_CHECK_LAUNCH("vt_sgd_momentum");
+    return VT_OK;
+}
+
+int vt_copy2d(const void* src, int32_t src_dtype, int64_t lds, void* dst, int32_t dst_dtype, int64_t ldd,
+              int64_t rows, int32_t cols, int32_t accumulate, void* stream) {
+    VT_REQUIRE(src && dst && rows > 0 && cols > 0 && lds >= cols && ldd >= cols, VT_ERR_INVALID,
+               "vt_copy2d: bad argument");
+    const unsigned blocks = flat_blocks(rows * cols);
+    hipStream_t st = (hipStream_t)stream;
+#define VT_CP(S, D)                                                                                         \
+    hipLaunchKernelGGL((copy2d_kernel<S, D>), dim3(blocks), dim3(kThreads), 0, st, (const S*)src, (long)lds, \
+                       (D*)dst, (long)ldd, (long)rows, cols, accumulate)
+    if (src_dtype == VT_F32 && dst_dtype == VT_F32)
+        VT_CP(float, float);
+    else if (src_dtype == VT_F32 && dst_dtype == VT_BF16)
+        VT_CP(float, bf16_t);
+    else if (src_dtype == VT_BF16 && dst_dtype == VT_F32)
+        VT_CP(bf16_t, float);
+    else if (src_dtype == VT_BF16 && dst_dtype == VT_BF16)
+        VT_CP(bf16_t, bf16_t);
+    else {
+        vt_set_error("vt_copy2d: dtypes %d -> %d", src_dtype, dst_dtype);
+        return VT_ERR_UNSUPPORTED;
+    }
+#undef VT_CP
+    VT_CHECK_LAUNCH("vt_copy2d");
+    return VT_OK;
+}
+
+int vt_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t Cpad,
+                    int32_t dtype, void* stream) {
+    VT_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, VT_ERR_INVALID,
+               "vt_nchw_to_nhwc: bad argument");
+    const long total = (long)B * H * W;
+    VT_DISPATCH_T(dtype, "vt_nchw_to_nhwc",
+                  hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(flat_blocks(total)), dim3(kThreads), 0,
+                                     (hipStream_t)stream, x, (T*)y, C, (long)H * W, Cpad, total));
+    VT_CHECK_LAUNCH("vt_nchw_to_nhwc");
+    return VT_OK;
+}
+
+int vt_nhwc_to_nchw(const void* y, int32_t ldy, float* x, int32_t B, int32_t C, int32_t H, int32_t W,
+                    int32_t dtype, void* stream) {
+    VT_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0 && ldy >= C, VT_ERR_INVALID,
+               "vt_nhwc_to_nchw: bad argument");
+    const long total = (long)B * H * W;
+    VT_DISPATCH_T(dtype, "vt_nhwc_to_nchw",
+                  hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, dim3(flat_blocks(total)), dim3(kThreads), 0,
+                                     (hipStream_t)stream, (const T*)y, ldy, x, C, (long)H * W, total));
+    VT_CHECK_LAUNCH("vt_nhwc_to_nchw");
+    return VT_OK;
+}
+
+int vt_pack_dgrad_filter(const void* w, int32_t src_dtype, int32_t ldw, void* out, int32_t dst_dtype,
+                         const int32_t* sel_host, int32_t nsel, int32_t Cout, int32_t ntaps, int32_t Cin,
+                         void* stream) {
+    VT_REQUIRE(w && out && sel_host && nsel >= 1 && nsel <= VT_MAX_TAPS && Cout > 0 && Cin > 0 &&
+                   ntaps >= 1 && ntaps <= VT_MAX_TAPS && ldw >= ntaps * Cin,
+               VT_ERR_INVALID, "vt_pack_dgrad_filter: bad argument");
+    SelTable st;
+    for (int i = 0; i < nsel; ++i) {
+        VT_REQUIRE(sel_host[i] >= 0 && sel_host[i] < ntaps, VT_ERR_INVALID,
+                   "vt_pack_dgrad_filter: sel[%d]=%d outside [0,%d)", i, sel_host[i], ntaps);
+        st.sel[i] = sel_host[i];
+    }
+    const long total = (long)Cin * nsel * Cout;
+    const unsigned blocks = flat_blocks(total);
+    hipStream_t s = (hipStream_t)stream;
+#define VT_PK(S, D)                                                                                          \
+    hipLaunchKernelGGL((pack_dgrad_kernel<S, D>), dim3(blocks), dim3(kThreads), 0, s, (const S*)w, ldw, (D*)out, \
+                       st, nsel, Cout, Cin, total)
+    if (src_dtype == VT_F32 && dst_dtype == VT_F32)
+        VT_PK(float, float);
+    else if (src_dtype == VT_F32 && dst_dtype == VT_BF16)
+        VT_PK(float, bf16_t);
+    else if (src_dtype == VT_BF16 && dst_dtype == VT_BF16)
+        VT_PK(bf16_t, bf16_t);
+    else {
+        vt_set_error("vt_pack_dgrad_filter: dtypes %d -> %d", src_dtype, dst_dtype);
+        return VT_ERR_UNSUPPORTED;
+    }
+#undef VT_PK
+    VT_CHECK_LAUNCH("vt_pack_dgrad_filter");
+    return VT_OK;
+}
+
+}  // extern "C"

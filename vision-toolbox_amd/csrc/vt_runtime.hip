@@ -1,0 +1,251 @@
+// vt_runtime.hip -- library state (error text, launch counter), the native
+// op-list executor and hipGraph capture/replay, and HIP-event timing helpers.
+//
+// The executor is what replaces the reference's per-op Python dispatch: the
+// reference walks nn.Sequential in Python and dispatches 3 ATen ops per
+// ConvNormAct (vision_toolbox/components.py:26-44, backbones/darknet.py:83-87).
+// Here the host builds the launch list once per (model, input shape) and a
+// step is ONE call into vt_run_ops / vt_graph_launch.
+#include <stdarg.h>
+
+#include <atomic>
+
+#include "vt_common.h"
+
+static thread_local char g_err[512] = "";
+static std::atomic<uint64_t> g_launches{0};
+
+void vt_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+void vt_count_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
+
+namespace {
+
+inline void* rp(const vt_op& op, int k, void* const* bases, int nbases, bool* bad) {
+    const vt_ptr& p = op.ptr[k];
+    if (p.base < 0) return nullptr;
+    if (p.base >= nbases || bases[p.base] == nullptr) {
+        *bad = true;
+        return nullptr;
+    }
+    return (char*)bases[p.base] + p.offset;
+}
+
+int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
+    bool bad = false;
+    void* P[VT_OP_MAX_PTR];
+    for (int k = 0; k < VT_OP_MAX_PTR; ++k) P[k] = rp(op, k, bases, nbases, &bad);
+    if (bad) {
+        vt_set_error("vt_run_ops: op kind %d (tag %d) references an unbound base", op.kind, op.tag);
+        return VT_ERR_INVALID;
+    }
+    const int32_t* I = op.i;
+    const double* F = op.f;
+    switch (op.kind) {
+        case VT_OP_MEMSET:  // ptr: dst | i: value | f: bytes
+            return vt_memset(P[0], I[0], (uint64_t)F[0], st);
+        case VT_OP_CONV_IGEMM: {  // ptr: x w y scale shift residual stats | i: vt_conv_desc image
+            vt_conv_desc d;
+            memcpy(&d, I, sizeof(d));
+            return vt_conv_igemm(&d, P[0], P[1], P[2], (const float*)P[3], (const float*)P[4], P[5],
+                                 (float*)P[6], st);
+        }
+        case VT_OP_CONV_WGRAD: {  // ptr: x dz dw | i: vt_conv_desc image, then ldgw
+            vt_conv_desc d;
+            memcpy(&d, I, sizeof(d));
+            return vt_conv_wgrad(&d, P[0], P[1], (float*)P[2], I[sizeof(d) / 4], st);
+        }
+        case VT_OP_PACK_DGRAD:  // ptr: w out | i: src_dtype ldw dst_dtype nsel Cout ntaps Cin _ sel[36]
+            return vt_pack_dgrad_filter(P[0], I[0], I[1], P[1], I[2], I + 8, I[3], I[4], I[5], I[6], st);
+        case VT_OP_BN_FINALIZE:  // ptr: stats gamma beta rm rv nbt scale shift mean invstd | i: C | f: count eps momentum
+            return vt_bn_finalize((const float*)P[0], I[0], F[0], (const float*)P[1], (const float*)P[2],
+                                  (float)F[1], (float)F[2], (float*)P[3], (float*)P[4], (int64_t*)P[5],
+                                  (float*)P[6], (float*)P[7], (float*)P[8], (float*)P[9], st);
+        case VT_OP_BN_EVAL_COEFFS:  // ptr: gamma beta rm rv scale shift mean invstd | i: C | f: eps
+            return vt_bn_eval_coeffs((const float*)P[0], (const float*)P[1], (const float*)P[2],
+                                     (const float*)P[3], (float)F[0], I[0], (float*)P[4], (float*)P[5],
+                                     (float*)P[6], (float*)P[7], st);
+        case VT_OP_BN_ACT_APPLY:  // ptr: z scale shift residual y | i: ldz ldr ldy C relu dtype | f: M
+            return vt_bn_act_apply(P[0], I[0], (const float*)P[1], (const float*)P[2], P[3], I[1], P[4], I[2],
+                                   (int64_t)F[0], I[3], I[4], I[5], st);
+        case VT_OP_BN_BWD_REDUCE:  // ptr: dy z scale shift mean invstd sums | i: lddy ldz C relu dtype | f: M
+            return vt_bn_act_bwd_reduce(P[0], I[0], P[1], I[1], (const float*)P[2], (const float*)P[3],
+                                        (const float*)P[4], (const float*)P[5], (int64_t)F[0], I[2], I[3],
+                                        I[4], (float*)P[6], st);
+        case VT_OP_BN_BWD_FINALIZE:  // ptr: sums scale mean invstd dgamma dbeta coef | i: C train | f: count
+            return vt_bn_bwd_finalize((const float*)P[0], I[0], F[0], (const float*)P[1], (const float*)P[2],
+                                      (const float*)P[3], I[1], (float*)P[4], (float*)P[5], (float*)P[6], st);
+        case VT_OP_BN_BWD_APPLY:  // ptr: dy z scale shift coef dz | i: lddy ldz lddz C relu dtype | f: M
+            return vt_bn_act_bwd_apply(P[0], I[0], P[1], I[1], (const float*)P[2], (const float*)P[3],
+                                       (const float*)P[4], P[5], I[2], (int64_t)F[0], I[3], I[4], I[5], st);
+        case VT_OP_MAXPOOL_FWD:  // ptr: x y argmax | i: ldx ldy B H W C dtype
+            return vt_maxpool3x3s2_fwd(P[0], I[0], P[1], I[1], (uint8_t*)P[2], I[2], I[3], I[4], I[5], I[6], st);
+        case VT_OP_MAXPOOL_BWD:  // ptr: dy argmax dx | i: lddy lddx B H W C accumulate dtype
+            return vt_maxpool3x3s2_bwd(P[0], I[0], (const uint8_t*)P[1], P[2], I[1], I[2], I[3], I[4], I[5],
+                                       I[6], I[7], st);
+        case VT_OP_AVGPOOL_FWD:  // ptr: x y | i: ldx ldy B HW C dtype
+            return vt_global_avgpool_fwd(P[0], I[0], P[1], I[1], I[2], I[3], I[4], I[5], st);
+        case VT_OP_AVGPOOL_BWD:  // ptr: dy dx | i: lddy lddx B HW C accumulate dtype
+            return vt_global_avgpool_bwd(P[0], I[0], P[1], I[1], I[2], I[3], I[4], I[5], I[6], st);
+        case VT_OP_ESE_FWD:  // ptr: x s residual y | i: ldx lds ldr ldy B HW C dtype
+            return vt_ese_gate_fwd(P[0], I[0], P[1], I[1], P[2], I[2], P[3], I[3], I[4], I[5], I[6], I[7], st);
+        case VT_OP_ESE_BWD:  // ptr: dy x s dx ds | i: lddy ldx lds lddx B HW C accumulate dtype
+            return vt_ese_gate_bwd(P[0], I[0], P[1], I[1], P[2], I[2], P[3], I[3], (float*)P[4], I[4], I[5],
+                                   I[6], I[7], I[8], st);
+        case VT_OP_COLSUM:  // ptr: a out | i: lda C dtype | f: M
+            return vt_colsum(P[0], I[0], (int64_t)F[0], I[1], I[2], (float*)P[1], st);
+        case VT_OP_XENT:  // ptr: logits labels loss dlogits | i: ldl lddl B N dtype | f: eps grad_scale
+            return vt_softmax_xent(P[0], I[0], (const int64_t*)P[1], (float)F[0], (float)F[1], (float*)P[2],
+                                   P[3], I[1], I[2], I[3], I[4], st);
+        case VT_OP_SGD:  // ptr: p g m mirror lr_dev | i: mirror_dtype | f: n lr momentum wd grad_scale
+            return vt_sgd_momentum((float*)P[0], (const float*)P[1], (float*)P[2], P[3], I[0], (int64_t)F[0],
+                                   (float)F[1], (float)F[2], (float)F[3], (float)F[4], (const float*)P[4], st);
+        case VT_OP_COPY2D:  // ptr: src dst | i: src_dtype dst_dtype cols accumulate | f: lds ldd rows
+            return vt_copy2d(P[0], I[0], (int64_t)F[0], P[1], I[1], (int64_t)F[1], (int64_t)F[2], I[2], I[3], st);
+        case VT_OP_NCHW_TO_NHWC:  // ptr: x y | i: B C H W Cpad dtype
+            return vt_nchw_to_nhwc((const float*)P[0], P[1], I[0], I[1], I[2], I[3], I[4], I[5], st);
+        case VT_OP_NHWC_TO_NCHW:  // ptr: y x | i: ldy B C H W dtype
+            return vt_nhwc_to_nchw(P[0], I[0], (float*)P[1], I[1], I[2], I[3], I[4], I[5], st);
+        default:
+            vt_set_error("vt_run_ops: unknown op kind %d (tag %d)", op.kind, op.tag);
+            return VT_ERR_INVALID;
+    }
+}
+
+struct Graph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
+}  // namespace
+
+extern "C" {
+
+int vt_version(void) { return 100; }
+const char* vt_last_error(void) { return g_err; }
+uint64_t vt_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
+
+int vt_memset(void* ptr, int value, uint64_t bytes, void* stream) {
+    VT_REQUIRE(ptr || bytes == 0, VT_ERR_INVALID, "vt_memset: null pointer");
+    if (bytes == 0) return VT_OK;
+    hipError_t e = hipMemsetAsync(ptr, value, bytes, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        vt_set_error("vt_memset: %s", hipGetErrorString(e));
+        return VT_ERR_HIP;
+    }
+    vt_count_launch();
+    return VT_OK;
+}
+
+int vt_run_ops(const vt_op* ops, int32_t n, void* const* bases, int32_t nbases, void* stream) {
+    VT_REQUIRE(ops && n >= 0 && nbases >= 0 && nbases <= VT_MAX_BASES && (bases || nbases == 0),
+               VT_ERR_INVALID, "vt_run_ops: bad argument");
+    for (int i = 0; i < n; ++i) {
+        const int rc = run_one(ops[i], bases, nbases, stream);
+        if (rc != VT_OK) {
+            char msg[400];
+            snprintf(msg, sizeof(msg), "%s", g_err);
+            vt_set_error("op %d (kind %d, tag %d): %s", i, ops[i].kind, ops[i].tag, msg);
+            return rc;
+        }
+    }
+    return VT_OK;
+}
+
+int vt_graph_create(const vt_op* ops, int32_t n, void* const* bases, int32_t nbases, void** graph_out) {
+    VT_REQUIRE(ops && n > 0 && graph_out, VT_ERR_INVALID, "vt_graph_create: bad argument");
+    hipStream_t cs;
+    hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        vt_set_error("vt_graph_create: stream: %s", hipGetErrorString(e));
+        return VT_ERR_HIP;
+    }
+    e = hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(cs);
+        vt_set_error("vt_graph_create: begin capture: %s", hipGetErrorString(e));
+        return VT_ERR_HIP;
+    }
+    const int rc = vt_run_ops(ops, n, bases, nbases, cs);
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(cs, &g);
+    (void)hipStreamDestroy(cs);
+    if (rc != VT_OK) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc;
+    }
+    if (e != hipSuccess || !g) {
+        vt_set_error("vt_graph_create: end capture: %s", hipGetErrorString(e));
+        return VT_ERR_HIP;
+    }
+    hipGraphExec_t ex = nullptr;
+    e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        vt_set_error("vt_graph_create: instantiate: %s", hipGetErrorString(e));
+        return VT_ERR_HIP;
+    }
+    Graph* G = new Graph{g, ex};
+    *graph_out = G;
+    return VT_OK;
+}
+
+int vt_graph_launch(void* graph, void* stream) {
+    VT_REQUIRE(graph, VT_ERR_INVALID, "vt_graph_launch: null graph");
+    hipError_t e = hipGraphLaunch(((Graph*)graph)->exec, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        vt_set_error("vt_graph_launch: %s", hipGetErrorString(e));
+        return VT_ERR_HIP;
+    }
+    vt_count_launch();
+    return VT_OK;
+}
+
+int vt_graph_destroy(void* graph) {
+    if (!graph) return VT_OK;
+    Graph* G = (Graph*)graph;
+    (void)hipGraphExecDestroy(G->exec);
+    (void)hipGraphDestroy(G->graph);
+    delete G;
+    return VT_OK;
+}
+
+int vt_event_create(void** ev) {
+    VT_REQUIRE(ev, VT_ERR_INVALID, "vt_event_create: null");
+    hipEvent_t e;
+    hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) {
+        vt_set_error("vt_event_create: %s", hipGetErrorString(rc));
+        return VT_ERR_HIP;
+    }
+    *ev = (void*)e;
+    return VT_OK;
+}
+int vt_event_record(void* ev, void* stream) {
+    hipError_t rc = hipEventRecord((hipEvent_t)ev, (hipStream_t)stream);
+    if (rc != hipSuccess) {
+        vt_set_error("vt_event_record: %s", hipGetErrorString(rc));
+        return VT_ERR_HIP;
+    }
+    return VT_OK;
+}
+int vt_event_elapsed_ms(void* start, void* stop, float* ms) {
+    VT_REQUIRE(ms, VT_ERR_INVALID, "vt_event_elapsed_ms: null");
+    hipError_t rc = hipEventSynchronize((hipEvent_t)stop);
+    if (rc == hipSuccess) rc = hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+    if (rc != hipSuccess) {
+        vt_set_error("vt_event_elapsed_ms: %s", hipGetErrorString(rc));
+        return VT_ERR_HIP;
+    }
+    return VT_OK;
+}
+int vt_event_destroy(void* ev) {
+    if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+    return VT_OK;
+}
+
+}  // extern "C"

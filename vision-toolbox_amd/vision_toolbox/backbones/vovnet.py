@@ -1,0 +1,206 @@
+"""VoVNet (one-shot aggregation) V1 / V2(eSE) on libvt_amd.
+
+Module tree and variant tables follow the reference
+(vision_toolbox/backbones/vovnet.py:20-136).  The OSA block's defining cost in the
+reference is `torch.cat(outputs, dim=1)` over the input and all n intermediate maps
+(ref :55) -- up to 2144 channels copied per block.  Here the concat buffer is allocated
+FIRST and every producer (the max-pool / previous block for the input slice, each 3x3
+unit for its slice) writes its channels in place; the 1x1 aggregation conv then reads the
+buffer directly, and in backward its data gradient lands in the mirrored gradient buffer
+where each 3x3 unit accumulates into its predecessor's slice.
+"""
+from __future__ import annotations
+
+from typing import NamedTuple, Union
+
+from torch import nn
+
+from ..components import ConvNormAct, HipModule
+from .base import BaseBackbone
+
+__all__ = [
+    "VoVNet", "OSABlock", "ESEBlock", "VoVNetStageConfig",
+    "vovnet27_slim", "vovnet39", "vovnet57",
+    "vovnet19_slim_ese", "vovnet19_ese", "vovnet39_ese", "vovnet57_ese", "vovnet99_ese",
+]  # fmt: skip
+
+_RELEASE = "https://github.com/gau-nernst/vision-toolbox/releases/download/v0.0.1/"
+
+
+class ESEBlock(HipModule):
+    """effective squeeze-excitation: x * hardsigmoid(conv1x1(avgpool(x)))."""
+
+    def __init__(self, num_channels: int) -> None:
+        super().__init__()
+        self.pool = nn.AdaptiveAvgPool2d((1, 1))
+        self.linear = nn.Conv2d(num_channels, num_channels, 1)
+        self.gate = nn.Hardsigmoid(inplace=True)
+
+    def _vt_emit(self, b, x, out=None, residual=None, name: str = "ese"):
+        return b.ese(x, self.linear, residual=residual, out=out, name=name)
+
+    def _vt_emit_maps(self, b, x):
+        return [self._vt_emit(b, x)]
+
+
+class OSABlock(HipModule):
+    def __init__(self, in_channels: int, mid_channels: int, num_layers: int, out_channels: int,
+                 ese: bool = True) -> None:
+        super().__init__()
+        self.convs = nn.ModuleList(
+            ConvNormAct(mid_channels if i else in_channels, mid_channels) for i in range(num_layers)
+        )
+        self.out_conv = ConvNormAct(in_channels + mid_channels * num_layers, out_channels, 1)
+        self.ese = ESEBlock(out_channels) if ese else None
+        self.residual = in_channels == out_channels
+
+    # geometry of the aggregation buffer -------------------------------------------------
+    @property
+    def _in_channels(self) -> int:
+        return self.convs[0].conv.in_channels
+
+    def _vt_alloc_concat(self, b, B, H, W, name: str):
+        return b.act(B, H, W, self.out_conv.conv.in_channels, name + ".cat")
+
+    def _vt_emit_from_concat(self, b, joined, out=None, name: str = "osa"):
+        """`joined[:, :in]` already holds the block input; fill the rest and aggregate."""
+        cin = self._in_channels
+        x = joined.sl(0, cin)
+        prev, off = x, cin
+        for i, conv in enumerate(self.convs):
+            mid = conv.conv.out_channels
+            prev = conv._vt_emit(b, prev, out=joined.sl(off, mid), name=f"{name}.convs.{i}")
+            off += mid
+        shortcut = x if self.residual else None
+        if self.ese is None:
+            return self.out_conv._vt_emit(b, joined, out=out, residual=shortcut, name=name + ".out_conv")
+        t = self.out_conv._vt_emit(b, joined, name=name + ".out_conv")
+        return self.ese._vt_emit(b, t, out=out, residual=shortcut, name=name + ".ese")
+
+    def _vt_emit(self, b, x, out=None, name: str = "osa"):
+        joined = self._vt_alloc_concat(b, x.B, x.H, x.W, name)
+        b.copy(x, joined.sl(0, x.C))
+        return self._vt_emit_from_concat(b, joined, out=out, name=name)
+
+    def _vt_emit_maps(self, b, x):
+        return [self._vt_emit(b, x)]
+
+
+class VoVNetStageConfig(NamedTuple):
+    n_blocks: int
+    mid_channels: int
+    n_layers: int
+    out_channels: int
+
+
+_StageCfg = Union[VoVNetStageConfig, "tuple[int, int, int, int]"]
+
+
+def _pooled(n: int) -> int:
+    return (n + 2 - 3) // 2 + 1  # MaxPool2d(3, 2, 1)
+
+
+class VoVNet(BaseBackbone):
+    def __init__(self, stem_channels: int, stage_configs: "list[_StageCfg]", ese: bool = True) -> None:
+        super().__init__()
+        self.out_channels_list = (stem_channels,) + tuple(int(cfg[3]) for cfg in stage_configs)
+        self.stride = 2 ** len(self.out_channels_list)
+
+        half = stem_channels // 2
+        self.stem = nn.Sequential(
+            ConvNormAct(3, half, 3, 2),
+            ConvNormAct(half, half),
+            ConvNormAct(half, stem_channels),
+        )
+        self.stages = nn.ModuleList()
+        width = stem_channels
+        for n_blocks, mid_ch, n_layers, out_ch in stage_configs:
+            stage = nn.Sequential()
+            stage.add_module("max_pool", nn.MaxPool2d(3, 2, 1))
+            for i in range(n_blocks):
+                stage.add_module(f"module_{i}", OSABlock(width, mid_ch, n_layers, out_ch, ese))
+                width = out_ch
+            self.stages.append(stage)
+
+    def _vt_emit_maps(self, b, x):
+        o = x
+        for i, unit in enumerate(self.stem):
+            o = unit._vt_emit(b, o, name=f"stem.{i}")
+        maps = [o]
+        for si, stage in enumerate(self.stages):
+            blocks = [m for m in stage.children() if isinstance(m, OSABlock)]
+            src = maps[-1]
+            H, W = _pooled(src.H), _pooled(src.W)
+            joined = blocks[0]._vt_alloc_concat(b, src.B, H, W, f"stages.{si}.module_0")
+            b.maxpool3x3s2(src, out=joined.sl(0, src.C), name=f"stages.{si}.max_pool")
+            o = None
+            for bi, blk in enumerate(blocks):
+                nxt = None
+                if bi + 1 < len(blocks):
+                    nxt = blocks[bi + 1]._vt_alloc_concat(b, src.B, H, W, f"stages.{si}.module_{bi + 1}")
+                out = nxt.sl(0, blk.out_conv.conv.out_channels) if nxt is not None else None
+                o = blk._vt_emit_from_concat(b, joined, out=out, name=f"stages.{si}.module_{bi}")
+                joined = nxt
+            maps.append(o)
+        return maps
+
+    _DEPTHS = {
+        # variant: (blocks per stage, 3x3 layers per block)
+        19: ((1, 1, 1, 1), (3, 3, 3, 3)),
+        27: ((1, 1, 1, 1), (5, 5, 5, 5)),
+        39: ((1, 1, 2, 2), (5, 5, 5, 5)),
+        57: ((1, 1, 4, 3), (5, 5, 5, 5)),
+        99: ((1, 3, 9, 3), (5, 5, 5, 5)),
+    }
+    _CKPTS = {
+        (27, True, False): "vovnet27_slim-dd43306a.pth",
+        (39, False, False): "vovnet39-4c79d629.pth",
+        (57, False, False): "vovnet57-ecb9cc34.pth",
+        (19, True, True): "vovnet19_slim_ese-f8075640.pth",
+        (19, False, True): "vovnet19_ese-a077657e.pth",
+        (39, False, True): "vovnet39_ese-9ce81b0d.pth",
+        (57, False, True): "vovnet57_ese-ae1a7f89.pth",
+        (99, False, True): "vovnet99_ese-713f3062.pth",
+    }
+
+    @staticmethod
+    def from_config(variant: int, slim: bool = False, ese: bool = False, pretrained: bool = False) -> "VoVNet":
+        n_blocks, n_layers = VoVNet._DEPTHS[variant]
+        mids = (64, 80, 96, 112) if slim else (128, 160, 192, 224)
+        outs = (128, 256, 384, 512) if slim else (256, 512, 768, 1024)
+        m = VoVNet(128, list(zip(n_blocks, mids, n_layers, outs)), ese)
+        if pretrained:
+            m._load_state_dict_from_url(_RELEASE + VoVNet._CKPTS[(variant, slim, ese)])
+        return m
+
+
+def vovnet27_slim(pretrained: bool = False) -> VoVNet:
+    return VoVNet.from_config(27, slim=True, ese=False, pretrained=pretrained)
+
+
+def vovnet39(pretrained: bool = False) -> VoVNet:
+    return VoVNet.from_config(39, slim=False, ese=False, pretrained=pretrained)
+
+
+def vovnet57(pretrained: bool = False) -> VoVNet:
+    return VoVNet.from_config(57, slim=False, ese=False, pretrained=pretrained)
+
+
+def vovnet19_slim_ese(pretrained: bool = False) -> VoVNet:
+    return VoVNet.from_config(19, slim=True, ese=True, pretrained=pretrained)
+
+
+def vovnet19_ese(pretrained: bool = False) -> VoVNet:
+    return VoVNet.from_config(19, slim=False, ese=True, pretrained=pretrained)
+
+
+def vovnet39_ese(pretrained: bool = False) -> VoVNet:
+    return VoVNet.from_config(39, slim=False, ese=True, pretrained=pretrained)
+
+
+def vovnet57_ese(pretrained: bool = False) -> VoVNet:
+    return VoVNet.from_config(57, slim=False, ese=True, pretrained=pretrained)
+
+
+def vovnet99_ese(pretrained: bool = False) -> VoVNet:
+    return VoVNet.from_config(99, slim=False, ese=True, pretrained=pretrained)

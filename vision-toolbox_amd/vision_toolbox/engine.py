@@ -1,0 +1,774 @@
+"""Static launch-list builder and runner for the backbone hot path.
+
+The reference executes a backbone by walking nn.Sequential in Python and letting
+ATen/autograd dispatch conv2d, batch_norm, relu_, cat, add one by one
+(vision_toolbox/components.py:26-44, backbones/darknet.py:27-28,51-55,
+backbones/vovnet.py:50-63).  Here a backbone is compiled ONCE per
+(input shape, dtype, mode) into two flat lists of libvt_amd launches (forward,
+backward) over one arena; a step is one call into the native executor
+(vt_run_ops) or one hipGraph launch.  Backward is written out explicitly per
+unit (no autograd inside), which is what allows concat elision, residual adds
+folded into epilogues and gradient accumulation folded into the data-gradient
+epilogue.
+
+Only CUDA (HIP) tensors are accepted; there is no CPU path in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Optional
+
+import torch
+from torch import nn
+
+from . import _native as N
+
+ALIGN = 256
+
+# base ids (index into the `bases` array handed to vt_run_ops)
+ARENA, PARAMS, GRADS, STATE, MIRROR, INPUT, COUNTERS, LABELS, MOMENTUM, HYPER, ZERO_F, ZERO_B = range(12)
+NUM_BASES = 12
+
+_TORCH_DTYPE = {N.VT_F32: torch.float32, N.VT_BF16: torch.bfloat16}
+_ESIZE = {N.VT_F32: 4, N.VT_BF16: 2}
+_EPC = {N.VT_F32: 4, N.VT_BF16: 8}
+
+
+def _round_up(v: int, a: int) -> int:
+    return (v + a - 1) // a * a
+
+
+@dataclass(eq=False)
+class Buf:
+    base: int
+    offset: int  # bytes from the base
+    nbytes: int
+    name: str = ""
+
+
+@dataclass(eq=False)
+class TRef:
+    """NHWC activation, possibly a channel slice [coff, coff+C) of a wider buffer."""
+
+    buf: Buf
+    B: int
+    H: int
+    W: int
+    C: int
+    ld: int  # pixel stride, elements
+    coff: int  # channel offset, elements
+    dtype: int
+    needs_grad: bool = True
+
+    @property
+    def M(self) -> int:
+        return self.B * self.H * self.W
+
+    @property
+    def esize(self) -> int:
+        return _ESIZE[self.dtype]
+
+    def addr(self):
+        return (self.buf.base, self.buf.offset + self.coff * self.esize)
+
+    def sl(self, c0: int, c: int) -> "TRef":
+        assert 0 <= c0 and c0 + c <= self.C
+        return TRef(self.buf, self.B, self.H, self.W, c, self.ld, self.coff + c0, self.dtype, self.needs_grad)
+
+    def same_geom(self, o: "TRef") -> bool:
+        return (self.B, self.H, self.W, self.C) == (o.B, o.H, o.W, o.C)
+
+
+class ParamStore:
+    """Flat f32 storage behind every parameter / buffer of a module tree.
+
+    Parameters keep their identity, names and logical shapes (so state_dict keys and
+    OIHW shapes are exactly the reference's, base.py:23-25), but their storage becomes
+    a slice of one flat tensor; 4-D conv weights are held channels_last, i.e.
+    physically [Cout][kh][kw][Cin], which is the filter image the kernels read.
+    """
+
+    def __init__(self, root: nn.Module):
+        self.root = root
+        self.device = None
+        self.pflat = self.sflat = self.nflat = self.mirror = None
+        self.index: dict[int, tuple[int, int, int]] = {}  # id(tensor owner) -> (base, elem offset, numel)
+        self.params: list[nn.Parameter] = []
+        self._ptrs: list[tuple[torch.Tensor, int]] = []
+        self.version = 0
+
+    # -- layout ---------------------------------------------------------------
+    def _collect(self):
+        params, fbufs, ibufs, seen = [], [], [], set()
+        for p in self.root.parameters():
+            if id(p) not in seen:
+                seen.add(id(p))
+                params.append(p)
+        for mod in self.root.modules():
+            for name, b in mod._buffers.items():
+                if b is None or id(b) in seen:
+                    continue
+                seen.add(id(b))
+                (fbufs if b.is_floating_point() else ibufs).append((mod, name, b))
+        return params, fbufs, ibufs
+
+    def stale(self, device) -> bool:
+        if self.device != device or self.pflat is None:
+            return True
+        for t, ptr in self._ptrs:
+            if t.data_ptr() != ptr or t.dtype not in (torch.float32, torch.int64):
+                return True
+        params, fbufs, ibufs = self._collect()
+        return len(params) + len(fbufs) + len(ibufs) != len(self._ptrs)
+
+    def ensure(self, device) -> None:
+        if not self.stale(device):
+            return
+        params, fbufs, ibufs = self._collect()
+        for p in params:
+            if not p.is_floating_point():
+                raise TypeError("non floating point parameter")
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += _round_up(p.numel(), 64)
+        pflat = torch.zeros(max(total, 64), dtype=torch.float32, device=device)
+        soffs, stotal = [], 0
+        for _, _, b in fbufs:
+            soffs.append(stotal)
+            stotal += _round_up(b.numel(), 64)
+        sflat = torch.zeros(max(stotal, 64), dtype=torch.float32, device=device)
+        nflat = torch.zeros(max(len(ibufs), 1) * 2, dtype=torch.int64, device=device)
+        self.index.clear()
+        self._ptrs = []
+        with torch.no_grad():
+            for p, off in zip(params, offs):
+                n = p.numel()
+                seg = pflat[off : off + n]
+                if p.dim() == 4:
+                    o, i, kh, kw = p.shape
+                    view = seg.view(o, kh, kw, i).permute(0, 3, 1, 2)
+                else:
+                    view = seg.view(p.shape)
+                view.copy_(p.data.to(device=device, dtype=torch.float32))
+                p.data = view
+                self.index[id(p)] = (PARAMS, off, n)
+                self._ptrs.append((p, p.data_ptr()))
+            for (mod, name, b), off in zip(fbufs, soffs):
+                n = b.numel()
+                view = sflat[off : off + n].view(b.shape)
+                view.copy_(b.to(device=device, dtype=torch.float32))
+                mod._buffers[name] = view
+                self.index[id(view)] = (STATE, off, n)
+                self._ptrs.append((view, view.data_ptr()))
+            for k, (mod, name, b) in enumerate(ibufs):
+                view = nflat[2 * k : 2 * k + 1].view(b.shape)
+                view.copy_(b.to(device=device, dtype=torch.int64))
+                mod._buffers[name] = view
+                self.index[id(view)] = (COUNTERS, 2 * k, 1)
+                self._ptrs.append((view, view.data_ptr()))
+        self.params, self.offsets = params, offs
+        self.pflat, self.sflat, self.nflat = pflat, sflat, nflat
+        self.mirror = torch.zeros(pflat.numel(), dtype=torch.bfloat16, device=device)
+        self.device = device
+        self.version += 1
+
+    def where(self, t) -> tuple[int, int, int]:
+        return self.index[id(t)]
+
+    def param_signature(self):
+        return tuple(p._version for p in self.params)
+
+
+# ---------------------------------------------------------------------------------------
+# gradient bookkeeping (per forward buffer)
+# ---------------------------------------------------------------------------------------
+@dataclass
+class _GradState:
+    gbuf: Optional[Buf] = None
+    init: list = field(default_factory=list)  # initialised channel intervals [c0, c1) in buffer coords
+    pending: list = field(default_factory=list)  # (c0, c1, TRef addend)
+
+    def covered(self, c0: int, c1: int) -> bool:
+        pos = c0
+        for a, b in sorted(self.init):
+            if a > pos:
+                break
+            pos = max(pos, b)
+        return pos >= c1
+
+    def touches(self, c0: int, c1: int) -> bool:
+        return any(a < c1 and c0 < b for a, b in self.init)
+
+
+class Builder:
+    """Emits the forward / backward launch lists of one model instance."""
+
+    def __init__(self, store: ParamStore, dtype: int, training: bool, need_grad: bool,
+                 grad_base: int = ARENA, master_mirror_fresh: bool = False):
+        self.store = store
+        self.dtype = dtype
+        self.training = training
+        self.need_grad = need_grad
+        self.grad_base = grad_base
+        self.fwd: list[N.Op] = []
+        self.bwd: list[N.Op] = []
+        self._cur = self.fwd
+        self.arena_top = 0
+        # scratch that must be zero before the forward / backward list runs lives in two
+        # contiguous regions (own base ids), so each list needs ONE memset
+        self.zf_top = self.zb_top = 0
+        self.nodes: list[Callable[[], None]] = []  # backward emitters, forward order
+        self.gstate: dict[int, _GradState] = {}
+        self.param_grad_off: dict[int, int] = {}  # id(param) -> byte offset in grad base
+        self.pgrad_bytes = 0
+        self.tag = 0
+        self.n_units = 0
+        self._dgrad_pack_cache: dict = {}
+
+    # -- memory -----------------------------------------------------------------
+    def alloc(self, nbytes: int, name: str = "") -> Buf:
+        off = self.arena_top
+        self.arena_top = _round_up(off + max(nbytes, 1), ALIGN)
+        return Buf(ARENA, off, nbytes, name)
+
+    def act(self, B, H, W, C, name="", needs_grad=True) -> TRef:
+        buf = self.alloc(B * H * W * C * _ESIZE[self.dtype], name)
+        return TRef(buf, B, H, W, C, C, 0, self.dtype, needs_grad)
+
+    def f32(self, n: int, name="") -> Buf:
+        return self.alloc(n * 4, name)
+
+    def zeroed_f32(self, n: int, name="", bwd: Optional[bool] = None) -> Buf:
+        """f32 scratch zeroed once per run of the list being built (stats / reduction sums)."""
+        if bwd is None:
+            bwd = self._cur is self.bwd
+        nbytes = _round_up(n * 4, ALIGN)
+        if bwd:
+            buf = Buf(ZERO_B, self.zb_top, n * 4, name)
+            self.zb_top += nbytes
+        else:
+            buf = Buf(ZERO_F, self.zf_top, n * 4, name)
+            self.zf_top += nbytes
+        return buf
+
+    # -- op emission --------------------------------------------------------------
+    def emit(self, kind: int, ptrs, ints=(), flts=(), desc: Optional[N.ConvDesc] = None, extra_ints=()):
+        op = N.Op()
+        op.kind = kind
+        op.tag = self.tag
+        for k in range(N.VT_OP_MAX_PTR):
+            op.ptr[k].base = -1
+        for k, p in enumerate(ptrs):
+            if p is None:
+                continue
+            base, off = p
+            op.ptr[k].base = base
+            op.ptr[k].offset = off
+        if desc is not None:
+            C.memmove(C.addressof(op.i), C.addressof(desc), C.sizeof(desc))
+            k0 = C.sizeof(desc) // 4
+            for k, v in enumerate(extra_ints):
+                op.i[k0 + k] = int(v)
+        else:
+            for k, v in enumerate(ints):
+                op.i[k] = int(v)
+        for k, v in enumerate(flts):
+            op.f[k] = float(v)
+        self._cur.append(op)
+        return op
+
+    @staticmethod
+    def bp(buf: Buf, byte_off: int = 0):
+        return (buf.base, buf.offset + byte_off)
+
+    # -- parameters ---------------------------------------------------------------
+    def pref(self, t, mirror: bool = False):
+        base, off, n = self.store.where(t)
+        if mirror:
+            assert base == PARAMS
+            return (MIRROR, off * 2)
+        return (base, off * (8 if base == COUNTERS else 4))
+
+    def pgrad(self, p: nn.Parameter):
+        """address of the f32 gradient accumulator of parameter p (None if it needs none)."""
+        if not p.requires_grad:
+            return None
+        if self.grad_base == GRADS:
+            _, off, _ = self.store.where(p)
+            return (GRADS, off * 4)
+        key = id(p)
+        if key not in self.param_grad_off:
+            buf = self.zeroed_f32(p.numel(), "pgrad", bwd=True)
+            self.param_grad_off[key] = buf.offset
+        return (ZERO_B, self.param_grad_off[key])
+
+    # -- gradient bookkeeping -------------------------------------------------------
+    def _gs(self, t: TRef) -> _GradState:
+        return self.gstate.setdefault(id(t.buf), _GradState())
+
+    def _gref(self, t: TRef) -> TRef:
+        gs = self._gs(t)
+        if gs.gbuf is None:
+            gs.gbuf = self.alloc(t.buf.nbytes, "d_" + t.buf.name)
+        return TRef(gs.gbuf, t.B, t.H, t.W, t.C, t.ld, t.coff, t.dtype)
+
+    def _add_into(self, dst: TRef, src: TRef, accumulate: bool):
+        """dst (=|+=) src, elementwise (vt_bn_act_apply with unit scale)."""
+        self.emit(N.OP_BN_ACT_APPLY,
+                  [src.addr(), None, None, dst.addr() if accumulate else None, dst.addr()],
+                  [src.ld, dst.ld, dst.ld, dst.C, 0, self.dtype], [dst.M])
+
+    def _flush_pending(self, t: TRef):
+        gs = self._gs(t)
+        c0, c1 = t.coff, t.coff + t.C
+        keep = []
+        for a, b, add in gs.pending:
+            if a < c1 and c0 < b:
+                if not (c0 <= a and b <= c1):
+                    raise NotImplementedError("pending gradient straddles the requested slice")
+                sub = t.sl(a - c0, b - a)
+                g = self._gref(sub)
+                acc = gs.covered(a, b)
+                if not acc and gs.touches(a, b):
+                    raise NotImplementedError("partially initialised gradient slice")
+                self._add_into(g, add, acc)
+                if not acc:
+                    gs.init.append((a, b))
+            else:
+                keep.append((a, b, add))
+        gs.pending = keep
+
+    def grad_add(self, t: TRef, addend: TRef):
+        """register an identity contribution d(t) += addend (materialised lazily)."""
+        if not t.needs_grad:
+            return
+        assert t.same_geom(addend)
+        self._gs(t).pending.append((t.coff, t.coff + t.C, addend))
+
+    def grad_target(self, t: TRef):
+        """for a kernel that writes d(t) and can fold ONE addend into its epilogue.
+        returns (destination, residual or None)."""
+        gs = self._gs(t)
+        c0, c1 = t.coff, t.coff + t.C
+        g = self._gref(t)
+        if gs.covered(c0, c1):
+            self._flush_pending(t)
+            return g, g
+        if gs.touches(c0, c1):
+            raise NotImplementedError("partially initialised gradient slice")
+        exact = [p for p in gs.pending if p[0] == c0 and p[1] == c1]
+        other = [p for p in gs.pending if p[0] < c1 and c0 < p[1] and not (p[0] == c0 and p[1] == c1)]
+        if len(exact) == 1 and not other:
+            gs.pending.remove(exact[0])
+            gs.init.append((c0, c1))
+            return g, exact[0][2]
+        gs.init.append((c0, c1))
+        if exact or other:
+            # destination is written first (no residual), the addends are added afterwards
+            self._deferred_flush = t
+        return g, None
+
+    def grad_written(self, t: TRef):
+        """call after emitting the writer returned by grad_target when it had leftovers."""
+        d = getattr(self, "_deferred_flush", None)
+        if d is not None:
+            self._deferred_flush = None
+            self._flush_pending(d)
+
+    def grad_read(self, t: TRef) -> Optional[TRef]:
+        """the complete gradient of t, or None if nothing contributed."""
+        gs = self._gs(t)
+        c0, c1 = t.coff, t.coff + t.C
+        over = [p for p in gs.pending if p[0] < c1 and c0 < p[1]]
+        if not gs.touches(c0, c1):
+            if not over:
+                return None
+            if len(over) == 1 and over[0][0] == c0 and over[0][1] == c1:
+                return over[0][2]  # read-only alias of the single contribution
+        self._flush_pending(t)
+        if not gs.covered(c0, c1):
+            # zero-fill the gaps (only dense full-width buffers can be memset)
+            if t.ld == t.C and not gs.touches(c0, c1):
+                g = self._gref(t)
+                self.emit(N.OP_MEMSET, [g.addr()], [0], [t.M * t.C * t.esize])
+                gs.init.append((c0, c1))
+            else:
+                raise NotImplementedError("gradient slice only partially produced")
+        return self._gref(t)
+
+    # -- input / output plumbing -------------------------------------------------------
+    def input_images(self, B, C_, H, W, requires_grad=False) -> TRef:
+        """NCHW f32 images (base INPUT) -> NHWC dtype with channels padded to 16 bytes."""
+        epc = _EPC[self.dtype]
+        cpad = _round_up(C_, epc)
+        x = self.act(B, H, W, cpad, "images", needs_grad=requires_grad)
+        self.emit(N.OP_NCHW_TO_NHWC, [(INPUT, 0), x.addr()], [B, C_, H, W, cpad, self.dtype])
+        x.logical_C = C_
+        if requires_grad and self.need_grad:
+            dx_buf = self.alloc(B * C_ * H * W * 4, "d_images")
+            self.input_grad = dx_buf
+
+            def bwd():
+                g = self.grad_read(x)
+                if g is None:
+                    self.emit(N.OP_MEMSET, [self.bp(dx_buf)], [0], [dx_buf.nbytes])
+                else:
+                    self.emit(N.OP_NHWC_TO_NCHW, [g.addr(), self.bp(dx_buf)], [g.ld, B, C_, H, W, self.dtype])
+
+            self.nodes.append(bwd)
+        return x
+
+    # -- the ConvNormAct unit (reference components.py:13-46) --------------------------
+    def _taps(self, k: int):
+        return [(r, t) for r in range(k) for t in range(k)]
+
+    def _conv_desc(self, x: TRef, Cout, Ho, Wo, s, pad, k, ldy, ldw, flags, ldr=0) -> N.ConvDesc:
+        d = N.ConvDesc()
+        d.dtype = self.dtype
+        d.B, d.Hi, d.Wi, d.Cin, d.ldx = x.B, x.H, x.W, x.C, x.ld
+        d.Ho, d.Wo, d.sh, d.sw, d.h0, d.w0 = Ho, Wo, s, s, -pad, -pad
+        d.Cout, d.ldy, d.oH, d.oW = Cout, ldy, Ho, Wo
+        d.oHs = d.oWs = 1
+        d.oh0 = d.ow0 = 0
+        d.ldw, d.ldr, d.flags = ldw, ldr, flags
+        taps = self._taps(k)
+        d.ntaps = len(taps)
+        for i, (r, t) in enumerate(taps):
+            d.dh[i], d.dw[i] = r, t
+        return d
+
+    def conv_unit(self, x: TRef, conv: nn.Conv2d, norm: Optional[nn.Module], relu: bool,
+                  residual: Optional[TRef] = None, out: Optional[TRef] = None, name: str = "") -> TRef:
+        """y = [relu]([bn](conv(x))) [+ residual], written to `out` when given."""
+        self.tag += 1
+        self.n_units += 1
+        dt, epc = self.dtype, _EPC[self.dtype]
+        k, s = conv.kernel_size[0], conv.stride[0]
+        pad = conv.padding[0]
+        if conv.kernel_size[0] != conv.kernel_size[1] or conv.stride[0] != conv.stride[1] or \
+                conv.dilation != (1, 1) or conv.groups != 1 or conv.padding[0] != conv.padding[1]:
+            raise NotImplementedError("hot path covers square, undilated, ungrouped convolutions")
+        if k * k > N.VT_MAX_TAPS:
+            raise NotImplementedError(f"kernel {k}x{k} exceeds {N.VT_MAX_TAPS} taps")
+        Cout, Cin_w = conv.out_channels, conv.in_channels
+        logical_cin = getattr(x, "logical_C", x.C)
+        if logical_cin != Cin_w:
+            raise ValueError(f"conv expects {Cin_w} input channels, got {logical_cin}")
+        if Cout % epc:
+            raise NotImplementedError(f"out_channels={Cout} must be a multiple of {epc} for dtype {dt}")
+        has_bn = isinstance(norm, nn.BatchNorm2d)
+        if norm is not None and not has_bn and not isinstance(norm, nn.Identity):
+            raise NotImplementedError(f"norm {type(norm).__name__} is outside the hot path")
+        if has_bn and (norm.momentum is None or not norm.affine or not norm.track_running_stats):
+            raise NotImplementedError("BatchNorm2d variants other than the default are outside the hot path")
+        if not has_bn and relu:
+            raise NotImplementedError("conv+relu without BatchNorm is outside the hot path")
+        Ho = (x.H + 2 * pad - k) // s + 1
+        Wo = (x.W + 2 * pad - k) // s + 1
+        ntaps = k * k
+        B = x.B
+        M = B * Ho * Wo
+
+        # ---- filter operand ---------------------------------------------------------
+        w = conv.weight
+        padded = x.C != Cin_w  # stem: 3 channels padded to one 16-byte chunk
+        if padded:
+            wpack = self.alloc(Cout * ntaps * x.C * _ESIZE[dt], "wpad")
+            self.emit(N.OP_MEMSET, [self.bp(wpack)], [0], [wpack.nbytes])
+            self.emit(N.OP_COPY2D, [self.pref(w), self.bp(wpack)], [N.VT_F32, dt, Cin_w, 0],
+                      [Cin_w, x.C, Cout * ntaps])
+            wptr = self.bp(wpack)
+        elif dt == N.VT_F32:
+            wptr = self.pref(w)
+        else:
+            wptr = self.pref(w, mirror=True)
+        ldw = ntaps * x.C
+
+        if out is not None:
+            assert (out.B, out.H, out.W, out.C) == (B, Ho, Wo, Cout), "out geometry mismatch"
+        if residual is not None:
+            assert (residual.B, residual.H, residual.W, residual.C) == (B, Ho, Wo, Cout)
+
+        track = self.need_grad
+        fused = has_bn and not self.training and not track
+        y = out if out is not None else self.act(B, Ho, Wo, Cout, name + ".y")
+        z = None
+        coef = None
+        if has_bn:
+            coef = self.f32(4 * Cout, "bncoef")  # scale, shift, mean, invstd
+            cp = [self.bp(coef, i * Cout * 4) for i in range(4)]
+            g, b_, rm, rv = (self.pref(norm.weight), self.pref(norm.bias), self.pref(norm.running_mean),
+                             self.pref(norm.running_var))
+        if fused:
+            self.emit(N.OP_BN_EVAL_COEFFS, [g, b_, rm, rv, cp[0], cp[1], None, None], [Cout], [norm.eps])
+            flags = N.VT_CONV_AFFINE | (N.VT_CONV_RELU if relu else 0) | (N.VT_CONV_RESIDUAL if residual else 0)
+            d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, y.ld, ldw, flags, residual.ld if residual else 0)
+            self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, y.addr(), cp[0], cp[1],
+                                        residual.addr() if residual else None, None], desc=d)
+        elif has_bn:
+            z = self.act(B, Ho, Wo, Cout, name + ".z")
+            if self.training:
+                stats = self.zeroed_f32(N.VT_STAT_REPLICAS * 2 * Cout, "stats")
+                d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, z.ld, ldw, N.VT_CONV_STATS)
+                self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, z.addr(), None, None, None, self.bp(stats)], desc=d)
+                self.emit(N.OP_BN_FINALIZE,
+                          [self.bp(stats), g, b_, rm, rv, self.pref(norm.num_batches_tracked), *cp],
+                          [Cout], [M, norm.eps, norm.momentum])
+            else:
+                d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, z.ld, ldw, 0)
+                self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, z.addr(), None, None, None, None], desc=d)
+                self.emit(N.OP_BN_EVAL_COEFFS, [g, b_, rm, rv, *cp], [Cout], [norm.eps])
+            self.emit(N.OP_BN_ACT_APPLY,
+                      [z.addr(), cp[0], cp[1], residual.addr() if residual else None, y.addr()],
+                      [z.ld, residual.ld if residual else 0, y.ld, Cout, int(relu), dt], [M])
+        else:
+            # plain conv (+bias): ESE gate conv (vovnet.py:24), classifier head (classifier.py:63)
+            flags = (N.VT_CONV_AFFINE if conv.bias is not None else 0) | (N.VT_CONV_RESIDUAL if residual else 0)
+            d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, y.ld, ldw, flags, residual.ld if residual else 0)
+            self.emit(N.OP_CONV_IGEMM,
+                      [x.addr(), wptr, y.addr(), None, self.pref(conv.bias) if conv.bias is not None else None,
+                       residual.addr() if residual else None, None], desc=d)
+
+        if track:
+            tag = self.tag
+            training = self.training
+
+            def bwd():
+                self.tag = tag
+                dy = self.grad_read(y)
+                if dy is None:
+                    return
+                if residual is not None:
+                    self.grad_add(residual, dy)
+                if has_bn:
+                    sums = self.zeroed_f32(N.VT_STAT_REPLICAS * 2 * Cout, "bwdsums")
+                    self.emit(N.OP_BN_BWD_REDUCE,
+                              [dy.addr(), z.addr(), cp[0], cp[1], cp[2], cp[3], self.bp(sums)],
+                              [dy.ld, z.ld, Cout, int(relu), dt], [M])
+                    bcoef = self.f32(3 * Cout, "bwdcoef")
+                    self.emit(N.OP_BN_BWD_FINALIZE,
+                              [self.bp(sums), cp[0], cp[2], cp[3], self.pgrad(norm.weight), self.pgrad(norm.bias),
+                               self.bp(bcoef)], [Cout, int(training)], [M])
+                    dz = self.act(B, Ho, Wo, Cout, name + ".dz")
+                    self.emit(N.OP_BN_BWD_APPLY,
+                              [dy.addr(), z.addr(), cp[0], cp[1], self.bp(bcoef), dz.addr()],
+                              [dy.ld, z.ld, dz.ld, Cout, int(relu), dt], [M])
+                else:
+                    dz = dy
+                    if conv.bias is not None and conv.bias.requires_grad:
+                        self.emit(N.OP_COLSUM, [dz.addr(), self.pgrad(conv.bias)], [dz.ld, Cout, dt], [M])
+                # filter gradient
+                if w.requires_grad:
+                    dfwd = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, dz.ld, ldw, 0)
+                    if padded:
+                        ws = self.zeroed_f32(Cout * ntaps * x.C, "dwpad", bwd=True)
+                        self.emit(N.OP_CONV_WGRAD, [x.addr(), dz.addr(), self.bp(ws)], desc=dfwd, extra_ints=[ldw])
+                        self.emit(N.OP_COPY2D, [self.bp(ws), self.pgrad(w)], [N.VT_F32, N.VT_F32, Cin_w, 1],
+                                  [x.C, Cin_w, Cout * ntaps])
+                    else:
+                        self.emit(N.OP_CONV_WGRAD, [x.addr(), dz.addr(), self.pgrad(w)], desc=dfwd,
+                                  extra_ints=[ldw])
+                # data gradient
+                if x.needs_grad:
+                    self._dgrad(x, dz, wptr if not padded else self.bp(wpack), dt if (padded or dt != N.VT_F32) else N.VT_F32,
+                                ldw, Cout, k, s, pad, Ho, Wo)
+
+            self.nodes.append(bwd)
+        return y
+
+    def _dgrad(self, x: TRef, dz: TRef, wptr, w_dtype, ldw, Cout, k, s, pad, Ho, Wo):
+        dt = self.dtype
+        # the s*s parity classes tile d(x) disjointly, so they share one destination and
+        # one folded addend: every pixel is produced exactly once
+        gx, res = self.grad_target(x)
+        for ph in range(s):
+            for pw in range(s):
+                r0, t0 = (ph + pad) % s, (pw + pad) % s
+                rows = list(range(r0, k, s))
+                cols = list(range(t0, k, s))
+                Hc = (x.H - ph + s - 1) // s
+                Wc = (x.W - pw + s - 1) // s
+                if Hc <= 0 or Wc <= 0:
+                    continue
+                if not rows or not cols:
+                    raise NotImplementedError("stride larger than kernel: empty data-gradient class")
+                eh, ew = (ph + pad - r0) // s, (pw + pad - t0) // s
+                sel = [r * k + t for r in rows for t in cols]
+                offs = [(eh - u, ew - v) for u in range(len(rows)) for v in range(len(cols))]
+                nsel = len(sel)
+                wd = self.alloc(x.C * nsel * Cout * _ESIZE[dt], "wd")
+                ints = [w_dtype, ldw, dt, nsel, Cout, k * k, x.C, 0] + sel
+                self.emit(N.OP_PACK_DGRAD, [wptr, self.bp(wd)], ints)
+                d = N.ConvDesc()
+                d.dtype = dt
+                d.B, d.Hi, d.Wi, d.Cin, d.ldx = dz.B, Ho, Wo, Cout, dz.ld
+                d.Ho, d.Wo, d.sh, d.sw, d.h0, d.w0 = Hc, Wc, 1, 1, 0, 0
+                d.Cout, d.ldy, d.oH, d.oW = x.C, gx.ld, x.H, x.W
+                d.oHs, d.oWs, d.oh0, d.ow0 = s, s, ph, pw
+                d.ldw, d.ldr = nsel * Cout, (res.ld if res is not None else 0)
+                d.flags = N.VT_CONV_RESIDUAL if res is not None else 0
+                d.ntaps = nsel
+                for i, (a, b) in enumerate(offs):
+                    d.dh[i], d.dw[i] = a, b
+                self.emit(N.OP_CONV_IGEMM, [dz.addr(), self.bp(wd), gx.addr(), None, None,
+                                            res.addr() if res is not None else None, None], desc=d)
+        self.grad_written(x)
+
+    def copy(self, x: TRef, dst: TRef) -> TRef:
+        """dst = x (places a tensor into a channel slice of a wider buffer)."""
+        assert x.same_geom(dst)
+        self.tag += 1
+        self._add_into(dst, x, False)
+        if self.need_grad and x.needs_grad:
+
+            def bwd():
+                g = self.grad_read(dst)
+                if g is not None:
+                    self.grad_add(x, g)
+
+            self.nodes.append(bwd)
+        return dst
+
+    # -- pooling -------------------------------------------------------------------------
+    def maxpool3x3s2(self, x: TRef, out: Optional[TRef] = None, name="maxpool") -> TRef:
+        self.tag += 1
+        Ho, Wo = (x.H + 2 - 3) // 2 + 1, (x.W + 2 - 3) // 2 + 1
+        y = out if out is not None else self.act(x.B, Ho, Wo, x.C, name)
+        assert (y.B, y.H, y.W, y.C) == (x.B, Ho, Wo, x.C)
+        am = self.alloc(x.B * Ho * Wo * x.C, "argmax")
+        self.emit(N.OP_MAXPOOL_FWD, [x.addr(), y.addr(), self.bp(am)],
+                  [x.ld, y.ld, x.B, x.H, x.W, x.C, self.dtype])
+        if self.need_grad and x.needs_grad:
+            tag = self.tag
+
+            def bwd():
+                self.tag = tag
+                dy = self.grad_read(y)
+                if dy is None:
+                    return
+                gx, res = self.grad_target(x)
+                acc = 0
+                if res is not None:
+                    if res is gx or (res.buf is gx.buf and res.coff == gx.coff):
+                        acc = 1
+                    else:  # a foreign addend: materialise it first, then accumulate
+                        self._add_into(gx, res, False)
+                        acc = 1
+                self.emit(N.OP_MAXPOOL_BWD, [dy.addr(), self.bp(am), gx.addr()],
+                          [dy.ld, gx.ld, x.B, x.H, x.W, x.C, acc, self.dtype])
+                self.grad_written(x)
+
+            self.nodes.append(bwd)
+        return y
+
+    def global_avgpool(self, x: TRef, name="avgpool") -> TRef:
+        """[B,H,W,C] -> [B,1,1,C]"""
+        self.tag += 1
+        y = self.act(x.B, 1, 1, x.C, name)
+        self.emit(N.OP_AVGPOOL_FWD, [x.addr(), y.addr()], [x.ld, y.ld, x.B, x.H * x.W, x.C, self.dtype])
+        if self.need_grad and x.needs_grad:
+            tag = self.tag
+
+            def bwd():
+                self.tag = tag
+                dy = self.grad_read(y)
+                if dy is None:
+                    return
+                gx, res = self.grad_target(x)
+                acc = 0
+                if res is not None:
+                    if not (res.buf is gx.buf and res.coff == gx.coff):
+                        self._add_into(gx, res, False)
+                    acc = 1
+                self.emit(N.OP_AVGPOOL_BWD, [dy.addr(), gx.addr()],
+                          [dy.ld, gx.ld, x.B, x.H * x.W, x.C, acc, self.dtype])
+                self.grad_written(x)
+
+            self.nodes.append(bwd)
+        return y
+
+    # -- ESE gate (reference vovnet.py:20-28) ---------------------------------------------
+    def ese(self, x: TRef, linear: nn.Conv2d, residual: Optional[TRef] = None,
+            out: Optional[TRef] = None, name="ese") -> TRef:
+        pooled = self.global_avgpool(x, name + ".pool")
+        s = self.conv_unit(pooled, linear, None, False, name=name + ".linear")
+        self.tag += 1
+        y = out if out is not None else self.act(x.B, x.H, x.W, x.C, name + ".y")
+        self.emit(N.OP_ESE_FWD, [x.addr(), s.addr(), residual.addr() if residual else None, y.addr()],
+                  [x.ld, s.ld, residual.ld if residual else 0, y.ld, x.B, x.H * x.W, x.C, self.dtype])
+        if self.need_grad:
+            tag = self.tag
+
+            def bwd():
+                self.tag = tag
+                dy = self.grad_read(y)
+                if dy is None:
+                    return
+                if residual is not None:
+                    self.grad_add(residual, dy)
+                gx, res = self.grad_target(x)
+                acc = 0
+                if res is not None:
+                    if not (res.buf is gx.buf and res.coff == gx.coff):
+                        self._add_into(gx, res, False)
+                    acc = 1
+                ds32 = self.f32(x.B * x.C, "ds32")
+                self.emit(N.OP_ESE_BWD, [dy.addr(), x.addr(), s.addr(), gx.addr(), self.bp(ds32)],
+                          [dy.ld, x.ld, s.ld, gx.ld, x.B, x.H * x.W, x.C, acc, self.dtype])
+                self.grad_written(x)
+                gs_, _ = self.grad_target(s)
+                self.emit(N.OP_COPY2D, [self.bp(ds32), gs_.addr()], [N.VT_F32, self.dtype, x.C, 0],
+                          [x.C, gs_.ld, x.B])
+
+            self.nodes.append(bwd)
+        return y
+
+    # -- classifier head + loss (reference classifier.py:58-64, 92) -----------------------
+    def xent(self, logits: TRef, label_smoothing: float, grad_scale: float) -> Buf:
+        self.tag += 1
+        loss = self.zeroed_f32(64, "loss")
+        Bn, Ncls = logits.B, logits.C
+        g = None
+        if self.need_grad:
+            gs = self._gs(logits)
+            g = self._gref(logits)
+            gs.init.append((logits.coff, logits.coff + logits.C))
+        self.emit(N.OP_XENT, [logits.addr(), (LABELS, 0), self.bp(loss), g.addr() if g else None],
+                  [logits.ld, g.ld if g else 0, Bn, Ncls, self.dtype], [label_smoothing, grad_scale])
+        return loss
+
+    # -- finish ---------------------------------------------------------------------------
+    def build_backward(self):
+        self._cur = self.bwd
+        for node in reversed(self.nodes):
+            node()
+        self._cur = self.fwd
+
+    def seed_output_grads(self, outs: list[TRef]):
+        """reserve gradient buffers of the returned feature maps; they are filled from the
+        caller's grad tensors before the backward list runs."""
+        seeds = []
+        for t in outs:
+            g = self._gref(t)
+            self._gs(t).init.append((t.coff, t.coff + t.C))
+            seeds.append(g)
+        return seeds
+
+
+def ops_array(ops: list) -> "C.Array":
+    arr = (N.Op * max(len(ops), 1))()
+    for i, op in enumerate(ops):
+        C.memmove(C.addressof(arr[i]), C.addressof(op), C.sizeof(N.Op))
+    return arr
+
+
+def tref_to_tensor(arena: torch.Tensor, t: TRef) -> torch.Tensor:
+    """view of an arena activation as a logical-NCHW (channels_last strided) torch tensor."""
+    td = _TORCH_DTYPE[t.dtype]
+    n = t.M * t.ld
+    flat = arena[t.buf.offset : t.buf.offset + n * t.esize].view(td)
+    v = flat.view(t.B, t.H, t.W, t.ld)[..., t.coff : t.coff + t.C]
+    return v.permute(0, 3, 1, 2)

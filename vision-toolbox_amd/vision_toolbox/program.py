@@ -1,0 +1,207 @@
+"""Compiled programs and the autograd bridge of the module API.
+
+`BackboneRunner` owns, per backbone instance, the flat parameter store and a cache of
+compiled programs keyed by (input shape, dtype, mode).  `forward()` /
+`get_feature_maps()` of a backbone (reference backbones/base.py:16-21) go through
+ONE autograd.Function whose forward runs the forward launch list and whose backward
+runs the explicit backward list; the returned feature maps are ordinary
+autograd-tracked tensors, so user heads / necks (necks.py:83) compose with them.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+from torch import nn
+
+from . import _native as N
+from . import engine as E
+
+
+def current_stream_handle() -> int:
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def resolve_dtype(x: torch.Tensor, override: Optional[torch.dtype]) -> int:
+    """f32 input -> exact-f32 kernels; bf16 input or bf16 autocast -> bf16 kernels."""
+    if override is not None:
+        dt = override
+    elif torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16:
+        dt = torch.bfloat16
+    else:
+        dt = x.dtype
+    if dt == torch.float32:
+        return N.VT_F32
+    if dt == torch.bfloat16:
+        return N.VT_BF16
+    raise TypeError(f"vision_toolbox (MI355X): compute dtype {dt} is not supported (float32 or bfloat16)")
+
+
+class Program:
+    """Forward (+ backward) launch lists over one arena."""
+
+    def __init__(self, b: E.Builder, outs: Sequence[E.TRef], seeds: Sequence[E.TRef]):
+        self.outs = list(outs)
+        self.seeds = list(seeds)
+        self.dtype = b.dtype
+        top = E._round_up(b.arena_top, E.ALIGN)
+        self.zf_off, self.zf_bytes = top, b.zf_top
+        top = E._round_up(top + b.zf_top, E.ALIGN)
+        self.zb_off, self.zb_bytes = top, b.zb_top
+        self.arena_bytes = E._round_up(top + b.zb_top, E.ALIGN) + E.ALIGN
+        fwd, bwd = list(b.fwd), list(b.bwd)
+        if self.zf_bytes:
+            fwd.insert(0, _memset_op(E.ZERO_F, self.zf_bytes))
+        if self.zb_bytes and bwd:
+            bwd.insert(0, _memset_op(E.ZERO_B, self.zb_bytes))
+        self.n_fwd, self.n_bwd = len(fwd), len(bwd)
+        self.fwd_ops = E.ops_array(fwd)
+        self.bwd_ops = E.ops_array(bwd)
+        self.param_grad_off = dict(b.param_grad_off)
+        self.input_grad = getattr(b, "input_grad", None)
+        self.n_units = b.n_units
+        self.kind_histogram = {}
+        for op in fwd + bwd:
+            k = N.OP_NAMES.get(op.kind, str(op.kind))
+            self.kind_histogram[k] = self.kind_histogram.get(k, 0) + 1
+
+    def bases(self, arena_ptr: int, **named) -> list:
+        bs = [None] * E.NUM_BASES
+        bs[E.ARENA] = arena_ptr
+        bs[E.ZERO_F] = arena_ptr + self.zf_off
+        bs[E.ZERO_B] = arena_ptr + self.zb_off
+        for k, v in named.items():
+            bs[getattr(E, k)] = v
+        return bs
+
+
+def _memset_op(base: int, nbytes: int) -> N.Op:
+    op = N.Op()
+    op.kind = N.OP_MEMSET
+    for k in range(N.VT_OP_MAX_PTR):
+        op.ptr[k].base = -1
+    op.ptr[0].base = base
+    op.ptr[0].offset = 0
+    op.i[0] = 0
+    op.f[0] = float(nbytes)
+    return op
+
+
+class _RunState:
+    __slots__ = ("prog", "arena", "bases", "x_shape")
+
+
+class BackboneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, runner: "BackboneRunner", prog: Program, x: torch.Tensor, *params):
+        st, outs = runner._run_forward(prog, x)
+        ctx.runner, ctx.st = runner, st
+        ctx.x_requires_grad = x.requires_grad
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        dx, pgrads = ctx.runner._run_backward(ctx.st, gouts, ctx.x_requires_grad)
+        ctx.st = None
+        return (None, None, dx, *pgrads)
+
+
+class BackboneRunner:
+    def __init__(self, module: nn.Module):
+        self.module = module
+        self.store = E.ParamStore(module)
+        self.cache: dict = {}
+
+    # -- compile ------------------------------------------------------------------
+    def program(self, x: torch.Tensor, dtype: int, all_maps: bool, need_grad: bool) -> Program:
+        key = (tuple(x.shape), dtype, self.module.training, all_maps, need_grad, x.requires_grad and need_grad,
+               self.store.version)
+        prog = self.cache.get(key)
+        if prog is None:
+            B, C_, H, W = x.shape
+            b = E.Builder(self.store, dtype, self.module.training, need_grad)
+            if dtype == N.VT_BF16:
+                # module API: the caller may have changed the f32 masters with any optimiser,
+                # so the bf16 mirror is refreshed at the head of every forward
+                n = self.store.pflat.numel()
+                b.emit(N.OP_COPY2D, [(E.PARAMS, 0), (E.MIRROR, 0)], [N.VT_F32, N.VT_BF16, n, 0], [n, n, 1])
+            xr = b.input_images(B, C_, H, W, requires_grad=x.requires_grad and need_grad)
+            maps = self.module._vt_emit_maps(b, xr)
+            outs = maps if all_maps else maps[-1:]
+            seeds = []
+            if need_grad:
+                seeds = b.seed_output_grads(outs)
+                b.build_backward()
+            prog = Program(b, outs, seeds)
+            self.cache[key] = prog
+        return prog
+
+    # -- run ----------------------------------------------------------------------
+    def __call__(self, x: torch.Tensor, all_maps: bool, compute_dtype: Optional[torch.dtype] = None):
+        if not isinstance(x, torch.Tensor) or x.dim() != 4:
+            raise ValueError("expected a 4-D NCHW image tensor")
+        if not x.is_cuda:
+            raise RuntimeError(
+                "vision_toolbox (MI355X build) runs its backbones only on the GPU through libvt_amd; "
+                f"got a {x.device.type} tensor. There is deliberately no CPU/eager fallback "
+                "(use oracle/ for a CPU reference)."
+            )
+        N.lib()  # raises if the extension is missing
+        dtype = resolve_dtype(x, compute_dtype)
+        self.store.ensure(x.device)
+        params = self.store.params
+        need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        prog = self.program(x, dtype, all_maps, need_grad)
+        if need_grad:
+            outs = BackboneFn.apply(self, prog, x, *params)
+        else:
+            _, outs = self._run_forward(prog, x)
+        return list(outs)
+
+    def _run_forward(self, prog: Program, x: torch.Tensor):
+        dev = x.device
+        x32 = x.detach()
+        if x32.dtype != torch.float32 or not x32.is_contiguous():
+            x32 = x32.to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            arena = torch.empty(prog.arena_bytes, dtype=torch.uint8, device=dev)
+            st = _RunState()
+            st.prog, st.arena, st.x_shape = prog, arena, tuple(x.shape)
+            s = self.store
+            st.bases = prog.bases(arena.data_ptr(), PARAMS=s.pflat.data_ptr(), STATE=s.sflat.data_ptr(),
+                                  MIRROR=s.mirror.data_ptr(), COUNTERS=s.nflat.data_ptr(),
+                                  INPUT=x32.data_ptr())
+            N.run_ops(prog.fwd_ops, prog.n_fwd, st.bases, current_stream_handle())
+        outs = [E.tref_to_tensor(arena, t) for t in prog.outs]
+        return st, outs
+
+    def _run_backward(self, st: _RunState, gouts, x_requires_grad: bool):
+        prog, arena = st.prog, st.arena
+        with torch.cuda.device(arena.device):
+            for seed, g in zip(prog.seeds, gouts):
+                view = E.tref_to_tensor(arena, seed)
+                if g is None:
+                    view.zero_()
+                else:
+                    view.copy_(g)
+            N.run_ops(prog.bwd_ops, prog.n_bwd, st.bases, current_stream_handle())
+        zb = arena[prog.zb_off : prog.zb_off + prog.zb_bytes]
+        pgrads = []
+        for p in self.store.params:
+            off = prog.param_grad_off.get(id(p))
+            if off is None or not p.requires_grad:
+                pgrads.append(None)
+                continue
+            g = zb[off : off + p.numel() * 4].view(torch.float32)
+            if p.dim() == 4:
+                o, i, kh, kw = p.shape
+                g = g.view(o, kh, kw, i).permute(0, 3, 1, 2)
+            else:
+                g = g.view(p.shape)
+            pgrads.append(g)
+        dx = None
+        if x_requires_grad and prog.input_grad is not None:
+            buf = prog.input_grad
+            dx = arena[buf.offset : buf.offset + buf.nbytes].view(torch.float32).view(st.x_shape)
+        return dx, pgrads
