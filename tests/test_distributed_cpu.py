@@ -1,0 +1,91 @@
+"""Data-parallel path on CPU: world_size-2 `gloo` processes exercise the bucket plan, the
+bucketed gradient all-reduce and the parameter broadcast (the N>1 path of bench.py, which
+uses the same code on RCCL)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from vision_toolbox.distributed import GradBucketer, plan_buckets
+
+
+def test_plan_buckets_tiles_the_buffer_last_range_first():
+    for total, bucket in [(27_269_632, 4 << 20), (1000, 64), (64, 4096), (130, 64), (8_388_608, 4 << 20)]:
+        b = plan_buckets(total, bucket)
+        assert b[0][1] == total and sorted(b)[0][0] == 0
+        s = sorted(b)
+        assert all(x[1] == y[0] for x, y in zip(s, s[1:]))
+        assert b == sorted(b, reverse=True)  # issued from the tail (produced first) to the head
+        assert all(e - s_ <= 2 * max(bucket, 64) for s_, e in b)
+    assert plan_buckets(0, 64) == []
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    sys.path[:0] = [str(root / "vision-toolbox_amd"), str(root)]
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)
+        n = 10_000
+        flat = torch.randn(n)
+        mine = flat.clone()
+        gathered = [torch.zeros(n) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        gb = GradBucketer(flat, plan_buckets(n, 2048))
+        assert len(gb.buckets) >= 4
+        gb.reduce_all()
+        gb.finish()
+        ok_sum = torch.allclose(flat, sum(gathered), rtol=1e-6, atol=1e-6)
+
+        # the train step's bucket <-> backward-segment plan and the initial broadcast
+        from vision_toolbox import backbones
+        from vision_toolbox.trainer import TrainStep
+
+        torch.manual_seed(rank)  # different init per rank on purpose
+        ts = TrainStep(backbones.darknet_yolov5n(), 16, 2, 64, torch.bfloat16, device="cpu", plan_only=True,
+                       bucket_mb=0.5)
+        assert ts.world == world and ts.bucketer is not None
+        issued = [bi for group in ts.cut_buckets for bi in group]
+        ok_plan = sorted(issued) == list(range(len(ts.bucketer.buckets))) and ts.bwd_cuts[-1] == ts.prog.n_bwd \
+            and ts.bwd_cuts == sorted(ts.bwd_cuts) and len(ts.bwd_cuts) == len(ts.cut_buckets)
+        # the tail bucket (head / last stage weights) must be ready no later than the stem-side one
+        first_seg_of = {bi: si for si, grp in enumerate(ts.cut_buckets) for bi in grp}
+        ok_order = first_seg_of[0] <= first_seg_of[len(ts.bucketer.buckets) - 1]
+        ts.broadcast_parameters(0)
+        ref = ts.store.pflat.clone()
+        dist.broadcast(ref, 0)
+        ok_bcast = torch.equal(ref, ts.store.pflat)
+        # averaging is folded into SGD: grad_scale = 1 / world
+        ok_scale = abs(ts.opt_ops[0].f[4] - 1.0 / world) < 1e-12
+        q.put((rank, ok_sum, ok_plan, ok_order, ok_bcast, ok_scale))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_bucketed_allreduce_and_train_plan():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in results) == [0, 1]
+    for r in results:
+        assert all(r[1:]), r

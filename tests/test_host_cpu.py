@@ -1,0 +1,226 @@
+"""Host-side logic that needs no GPU: drop-in surface (state_dict keys, attributes, factories),
+the C-ABI export check, the launch-list compiler's structural invariants, and the
+optimiser / schedule restatements."""
+import ctypes
+import json
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+from torch import nn
+
+from vision_toolbox import _native as N
+from vision_toolbox import backbones
+from vision_toolbox import engine as E
+from vision_toolbox.components import ConvNormAct
+from vision_toolbox.trainer import GROUP_BIAS, GROUP_NORM, GROUP_OTHER, TrainStep, param_groups, warmup_cosine_lr
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+@pytest.fixture(scope="module")
+def manifest(golden_dir):
+    return json.loads((golden_dir / "manifest.json").read_text())
+
+
+# ---- drop-in surface -------------------------------------------------------------------------
+def test_every_reference_factory_name_exists(manifest):
+    for name in manifest:
+        assert callable(getattr(backbones, name)), name
+    for cls in ("Darknet", "DarknetYOLOv5", "VoVNet", "BaseBackbone"):
+        assert hasattr(backbones, cls)
+
+
+@pytest.mark.parametrize("name", ["darknet19", "darknet53", "cspdarknet53", "darknet_yolov5n", "darknet_yolov5x",
+                                  "vovnet27_slim", "vovnet39", "vovnet19_slim_ese", "vovnet57_ese", "vovnet99_ese"])
+def test_state_dict_keys_shapes_and_attributes_match_reference(name, manifest):
+    ref = manifest[name]
+    m = getattr(backbones, name)()
+    got = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+    assert got == ref["keys"]
+    assert sum(p.numel() for p in m.parameters()) == ref["num_parameters"]
+    assert isinstance(m.out_channels_list, tuple) and all(isinstance(c, int) for c in m.out_channels_list)
+    assert list(m.out_channels_list) == ref["out_channels_list"]
+    assert isinstance(m.stride, int) and m.stride == ref["stride"]
+    assert callable(m.get_feature_maps) and m.get_last_out_channels() == ref["out_channels_list"][-1]
+
+
+def test_from_config_signatures():
+    assert backbones.Darknet.from_config("cspdarknet53").out_channels_list == (64, 128, 256, 512, 1024)
+    assert backbones.DarknetYOLOv5.from_config("x").out_channels_list == (80, 160, 320, 640, 1280)
+    assert backbones.VoVNet.from_config(39, False, False).out_channels_list == (128, 256, 512, 768, 1024)
+    with pytest.raises(KeyError):
+        backbones.Darknet.from_config("nope")
+
+
+def test_conv_norm_act_constructor_contract():
+    for k, s in [(1, 1), (3, 1), (3, 2), (6, 2), (5, 1), (7, 2)]:
+        u = ConvNormAct(4, 8, k, s)
+        assert u.conv.padding == (-((s - k) // 2),) * 2  # ceil((k - s) / 2), components.py:31
+        assert u.conv.bias is None and isinstance(u.norm, nn.BatchNorm2d) and isinstance(u.act, nn.ReLU)
+    u = ConvNormAct(4, 8, norm="none", act="none")
+    assert u.conv.bias is not None and isinstance(u.norm, nn.Identity)
+    assert list(dict(ConvNormAct(4, 8).named_children())) == ["conv", "norm", "act"]
+    # init: N(0, 2 / ((1 + 0.2^2) * fan_out)) for relu (components.py:45-46)
+    torch.manual_seed(0)
+    w = ConvNormAct(64, 256, 3).conv.weight
+    assert w.std().item() == pytest.approx((2 / (1.04 * 256 * 9)) ** 0.5, rel=0.05)
+
+
+def test_cpu_tensor_is_rejected_loudly():
+    m = backbones.darknet19()
+    with pytest.raises(RuntimeError, match="no CPU/eager fallback"):
+        m(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(RuntimeError, match="no CPU/eager fallback"):
+        m.get_feature_maps(torch.zeros(1, 3, 64, 64))
+
+
+def test_parameter_groups_follow_classifier_py():
+    model = nn.Sequential(backbones.cspdarknet53(), nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(1024, 1000))
+    g = param_groups(model)
+    counts = {k: sum(1 for v in g.values() if v == k) for k in (GROUP_NORM, GROUP_BIAS, GROUP_OTHER)}
+    assert counts == {GROUP_NORM: 2 * 67, GROUP_BIAS: 1, GROUP_OTHER: 67 + 1}
+
+
+# ---- C-ABI ---------------------------------------------------------------------------------------
+def _declared_functions():
+    text = (ROOT / "include" / "vt_amd.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    names = _declared_functions()
+    assert len(names) >= 30
+    lib = N.lib()
+    for n in names:
+        assert n in N.SYMBOLS, f"{n} declared in vt_amd.h but not bound in _native.SYMBOLS"
+        assert getattr(lib, n) is not None
+    assert set(N.SYMBOLS) == set(names)
+    assert lib.vt_version() >= 100
+    out = subprocess.run(["nm", "-D", "--defined-only", str(N.LIB_PATH)], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (vt_[a-z0-9_]+)", out))
+    assert set(names) <= exported
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "vt_amd.h"\nint main(){printf("%zu %zu %zu %zu %zu %d %d",'
+                   "sizeof(vt_conv_desc), sizeof(vt_op), offsetof(vt_op, i), offsetof(vt_op, f),"
+                   "offsetof(vt_conv_desc, dh), VT_OP_KIND_END, VT_STAT_REPLICAS);return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
+    vals = list(map(int, subprocess.run([str(exe)], capture_output=True, text=True).stdout.split()))
+    assert vals[0] == ctypes.sizeof(N.ConvDesc)
+    assert vals[1] == ctypes.sizeof(N.Op)
+    assert vals[2] == N.Op.i.offset and vals[3] == N.Op.f.offset
+    assert vals[4] == N.ConvDesc.dh.offset
+    assert vals[5] == max(N.OP_NAMES) + 1
+    assert vals[6] == N.VT_STAT_REPLICAS
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(N, "_lib", None)
+    monkeypatch.setattr(N, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(ImportError, match="no CPU/eager fallback"):
+        N.lib()
+
+
+# ---- launch-list compiler ----------------------------------------------------------------------------
+def _dry_program(name, dtype, training, need_grad, size=64, batch=2):
+    m = getattr(backbones, name)()
+    m.train(training)
+    r = m._vt_runner()
+    r.store.ensure(torch.device("cpu"))
+    return r.program(torch.zeros(batch, 3, size, size), dtype, True, need_grad)
+
+
+def test_cspdarknet53_program_structure():
+    p = _dry_program("cspdarknet53", N.VT_BF16, True, True)
+    h = p.kind_histogram
+    assert p.n_units == 67
+    assert h["conv_wgrad"] == 67 and h["bn_finalize"] == 67 and h["bn_bwd_apply"] == 67
+    # residual adds are folded into the normalise pass and torch.cat is elided: the ONLY
+    # elementwise launches are one bn_act_apply per unit; the only copies are the bf16 weight
+    # mirror and the 3->8 channel stem filter pad (+ its gradient un-pad)
+    assert h["bn_act_apply"] == 67
+    assert h["copy2d"] == 3
+    # forward convs + one data-gradient launch per conv (4 parity classes for the 5 stride-2 convs)
+    assert h["conv_igemm"] == 67 + (66 - 5) + 5 * 4
+    assert "maxpool_fwd" not in h
+
+
+def test_inference_program_is_fully_fused():
+    p = _dry_program("cspdarknet53", N.VT_BF16, False, False)
+    h = p.kind_histogram
+    assert h["conv_igemm"] == 67 and "bn_act_apply" not in h and p.n_bwd == 0
+    p = _dry_program("vovnet39", N.VT_F32, False, False)
+    assert p.kind_histogram["conv_igemm"] == 39 and p.kind_histogram["maxpool_fwd"] == 4
+    # OSA concat elided, f32 needs no mirror: the one copy is the stem filter's 3 -> 4 channel pad
+    assert p.kind_histogram["copy2d"] == 1 and "bn_act_apply" not in p.kind_histogram
+
+
+def test_vovnet_ese_program_compiles_with_gradients():
+    p = _dry_program("vovnet19_slim_ese", N.VT_F32, True, True)
+    h = p.kind_histogram
+    assert h["ese_fwd"] == 4 and h["ese_bwd"] == 4 and h["maxpool_bwd"] == 4
+    assert h["avgpool_fwd"] == 4 and h["colsum"] == 4
+
+
+def test_unsupported_variants_raise_not_fallback():
+    u = ConvNormAct(8, 8, act="gelu")
+    b = E.Builder(E.ParamStore(u), N.VT_F32, False, False)
+    b.store.ensure(torch.device("cpu"))
+    x = b.act(1, 4, 4, 8)
+    with pytest.raises(NotImplementedError, match="activation"):
+        u._vt_emit(b, x)
+    g = ConvNormAct(8, 8, groups=2)
+    b = E.Builder(E.ParamStore(g), N.VT_F32, False, False)
+    b.store.ensure(torch.device("cpu"))
+    with pytest.raises(NotImplementedError):
+        g._vt_emit(b, b.act(1, 4, 4, 8))
+
+
+def test_param_store_keeps_identity_names_and_values():
+    m = backbones.darknet_yolov5n()
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    ids = {k: id(p) for k, p in m.named_parameters()}
+    st = E.ParamStore(m)
+    st.ensure(torch.device("cpu"))
+    after = m.state_dict()
+    assert list(after) == list(before)
+    for k in before:
+        assert torch.equal(after[k], before[k]), k
+    assert ids == {k: id(p) for k, p in m.named_parameters()}
+    w = m.stem.conv.weight
+    assert w.shape == (16, 3, 6, 6) and w.stride() == (108, 1, 18, 3)  # OIHW view of [O][kh][kw][I]
+    assert not st.stale(torch.device("cpu"))
+    m.stem.conv.weight.data = m.stem.conv.weight.data.clone()
+    assert st.stale(torch.device("cpu"))
+
+
+def test_train_step_plan_covers_all_parameters():
+    ts = TrainStep(backbones.darknet_yolov5n(), 16, 2, 64, torch.bfloat16, device="cpu", plan_only=True)
+    segs = ts.segments
+    assert segs[0][0] == 0 and segs[-1][1] == ts.store.pflat.numel()
+    assert all(a[1] == b[0] for a, b in zip(segs, segs[1:]))
+    assert [s[2] for s in segs] == [0.0, 0.0, 2e-5]  # norm, bias, everything else
+    assert ts.prog.kind_histogram["xent"] == 1 and ts.n_opt == 3
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ts.step()
+
+
+def test_warmup_cosine_matches_torch_schedulers():
+    from torch.optim.lr_scheduler import CosineAnnealingLR, LinearLR, SequentialLR
+
+    p = nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=0.5)
+    cos = CosineAnnealingLR(opt, T_max=95, eta_min=0.0)
+    sched = SequentialLR(opt, [LinearLR(opt, start_factor=0.01, total_iters=5), cos], milestones=[5])
+    for epoch in range(100):
+        assert opt.param_groups[0]["lr"] == pytest.approx(warmup_cosine_lr(epoch, 100, 0.5), rel=1e-6, abs=1e-9)
+        opt.step()
+        sched.step()

@@ -1,0 +1,344 @@
+"""Kernel-level parity: every C-ABI entry point against the CPU oracle's arithmetic
+(torch CPU fp32/fp64, the reference's own third-party arithmetic) on seeded inputs.
+
+Tolerances (relative L2 unless stated): f32 path 2e-5 (exact-f32 MFMA, only the
+summation order differs from ATen); bf16 path 6e-3 against a reference computed from
+the SAME bf16-rounded inputs (remaining error = one bf16 rounding of the output).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import filler
+from vision_toolbox import _native as N
+
+from gpu_util import DNAME, DTYPES, TD, conv_desc, krsc, nhwc, rel_err, rounded, stream, to_nchw, tol, vp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _lib_loaded():
+    N.lib()
+    before = N.launch_count()
+    yield
+    torch.cuda.synchronize()
+    assert N.launch_count() > before, "no libvt_amd launch happened: the HIP path did not run"
+
+
+CONV_CASES = [
+    # B, Cin, Cout, k, s, H, W
+    (2, 16, 32, 1, 1, 8, 8),
+    (2, 16, 16, 3, 1, 9, 9),
+    (2, 8, 24, 3, 2, 10, 10),
+    (2, 8, 16, 6, 2, 12, 12),
+    (3, 40, 72, 3, 1, 7, 5),
+    (1, 64, 136, 3, 1, 14, 14),
+    (2, 160, 160, 3, 1, 7, 7),
+    (4, 32, 32, 3, 1, 33, 17),
+    (2, 128, 64, 1, 1, 12, 12),
+    (2, 256, 128, 3, 2, 14, 14),
+    (1, 8, 8, 3, 1, 3, 3),
+]
+
+
+def _pad(k, s):
+    return -((s - k) // 2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DNAME.get)
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_forward_and_stats(dtype, case):
+    B, Cin, Cout, k, s, H, W = case
+    pad = _pad(k, s)
+    x = filler.tensor(f"x{case}", (B, Cin, H, W))
+    w = filler.tensor(f"w{case}", (Cout, Cin, k, k), scale=(2.0 / (Cin * k * k)) ** 0.5)
+    ref = F.conv2d(rounded(x, dtype).double(), rounded(w, dtype).double(), None, s, pad)
+    xd, wd = nhwc(x, dtype), krsc(w, dtype)
+    Ho, Wo = ref.shape[2:]
+    y = torch.full((B, Ho, Wo, Cout), float("nan"), device="cuda", dtype=TD[dtype])
+    stats = torch.zeros(N.VT_STAT_REPLICAS, 2, Cout, device="cuda")
+    d = conv_desc(dtype, xd, Cin, Cout, k, s, pad, Cout, flags=N.VT_CONV_STATS)
+    N.check(N.lib().vt_conv_igemm(C.byref(d), vp(xd), vp(wd), vp(y), None, None, None, vp(stats), stream()))
+    got = to_nchw(y)
+    assert torch.isfinite(got).all()
+    assert rel_err(got, ref) < tol(dtype)
+    # statistics are those of the values actually stored
+    st = stats.double().sum(0).cpu()
+    yy = y.double().reshape(-1, Cout).cpu()
+    np.testing.assert_allclose(st[0], yy.sum(0), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(st[1], (yy * yy).sum(0), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DNAME.get)
+def test_conv_channel_slices_and_fused_epilogue(dtype):
+    """input and output are channel slices of wider (concat) buffers; eval epilogue
+    y = relu(z*scale + shift) + residual in the same launch."""
+    B, Cin, Cout, k, s, H, W = 2, 24, 40, 3, 1, 11, 6
+    x = filler.tensor("sx", (B, Cin, H, W))
+    w = filler.tensor("sw", (Cout, Cin, k, k), scale=0.1)
+    r = filler.tensor("sr", (B, Cout, H, W))
+    scale, shift = filler.tensor("ssc", (Cout,)) * 0.5 + 1.0, filler.tensor("ssh", (Cout,)) * 0.2
+    z = F.conv2d(rounded(x, dtype).double(), rounded(w, dtype).double(), None, s, 1)
+    ref = torch.relu(z * scale.double()[None, :, None, None] + shift.double()[None, :, None, None])
+    if dtype == N.VT_BF16:
+        ref = ref.to(torch.bfloat16).double()  # the fused path rounds before the residual add
+    ref = ref + rounded(r, dtype).double()
+    xd = nhwc(x, dtype, ld=64, coff=16)
+    rd = nhwc(r, dtype, ld=48, coff=8)
+    wide = torch.full((B, H, W, 96), float("nan"), device="cuda", dtype=TD[dtype])
+    y = wide[..., 32 : 32 + Cout]
+    wd = krsc(w, dtype)
+    scd, shd = scale.cuda(), shift.cuda()  # keep alive: the launch is asynchronous
+    flags = N.VT_CONV_AFFINE | N.VT_CONV_RELU | N.VT_CONV_RESIDUAL
+    d = conv_desc(dtype, xd, Cin, Cout, k, s, 1, 96, flags=flags, ldr=48)
+    N.check(N.lib().vt_conv_igemm(C.byref(d), vp(xd), vp(wd), vp(y), vp(scd), vp(shd), vp(rd), None, stream()))
+    assert rel_err(to_nchw(y), ref) < tol(dtype)
+    # nothing outside the slice was written
+    assert torch.isnan(wide[..., :32]).all() and torch.isnan(wide[..., 32 + Cout :]).all()
+
+
+def test_conv_rejects_bad_arguments():
+    x = torch.zeros(1, 4, 4, 8, device="cuda")
+    d = conv_desc(N.VT_F32, x, 8, 6, 3, 1, 1, 6)  # Cout not a multiple of 4
+    rc = N.lib().vt_conv_igemm(C.byref(d), vp(x), vp(x), vp(x), None, None, None, None, stream())
+    assert rc == N.VT_ERR_UNSUPPORTED and "multiples" in N.last_error()
+    d = conv_desc(N.VT_F32, x, 8, 8, 3, 1, 1, 8)
+    rc = N.lib().vt_conv_igemm(C.byref(d), None, vp(x), vp(x), None, None, None, None, stream())
+    assert rc == N.VT_ERR_INVALID
+    # a successful launch so the autouse launch-count check holds
+    N.check(N.lib().vt_memset(vp(x), 0, 16, stream()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DNAME.get)
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_filter_gradient(dtype, case):
+    B, Cin, Cout, k, s, H, W = case
+    pad = _pad(k, s)
+    x = rounded(filler.tensor(f"gx{case}", (B, Cin, H, W)), dtype).double()
+    w = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+    z = F.conv2d(x, w, None, s, pad)
+    dz = rounded(filler.tensor(f"gdz{case}", z.shape), dtype).double()
+    z.backward(dz)
+    xd, dzd = nhwc(x.float(), dtype), nhwc(dz.float(), dtype)
+    dw = torch.zeros(Cout, k, k, Cin, device="cuda")
+    dw += 1.0  # the kernel accumulates into existing gradient
+    d = conv_desc(dtype, xd, Cin, Cout, k, s, pad, Cout)
+    N.check(N.lib().vt_conv_wgrad(C.byref(d), vp(xd), vp(dzd), vp(dw), k * k * Cin, stream()))
+    got = (dw - 1.0).permute(0, 3, 1, 2).cpu()
+    assert rel_err(got, w.grad) < (2e-5 if dtype == N.VT_F32 else 2e-5)  # inputs pre-rounded, f32 accumulate
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DNAME.get)
+@pytest.mark.parametrize("shape", [(2, 24, 5, 7), (3, 160, 4, 4), (2, 8, 16, 16)], ids=str)
+def test_batchnorm_relu_forward_backward_chain(dtype, shape):
+    """stats -> finalize -> apply -> bwd reduce -> bwd finalize -> bwd apply vs autograd of
+    F.batch_norm + relu (+ residual), incl. running statistics (components.py:36-44)."""
+    B, Cc, H, W = shape
+    M = B * H * W
+    z0 = rounded(filler.tensor(f"z{shape}", shape) * 1.5 + 0.3, dtype)
+    res = rounded(filler.tensor(f"r{shape}", shape), dtype)
+    gamma = (filler.tensor(f"g{shape}", (Cc,)) * 0.2 + 1.0).requires_grad_(True)
+    beta = (filler.tensor(f"b{shape}", (Cc,)) * 0.2).requires_grad_(True)
+    rm, rv = filler.tensor(f"rm{shape}", (Cc,)) * 0.1, filler.tensor(f"rv{shape}", (Cc,)).abs() + 0.5
+    zt = z0.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y_ref = torch.relu(F.batch_norm(zt, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)) + res
+    dy = rounded(filler.tensor(f"dy{shape}", shape), dtype)
+    y_ref.backward(dy)
+
+    zd, rd, dyd = nhwc(z0, dtype), nhwc(res, dtype), nhwc(dy, dtype)
+    stats = torch.zeros(N.VT_STAT_REPLICAS, 2, Cc, device="cuda")
+    zz = zd.float().reshape(-1, Cc)
+    stats[3, 0], stats[3, 1] = zz.sum(0), (zz * zz).sum(0)
+    stats[7, 0] += 0.0
+    g, b_ = gamma.detach().cuda(), beta.detach().cuda()
+    rmd, rvd = rm.cuda(), rv.cuda()
+    nbt = torch.zeros(2, dtype=torch.int64, device="cuda")
+    coef = torch.zeros(4, Cc, device="cuda")
+    L = N.lib()
+    N.check(L.vt_bn_finalize(vp(stats), Cc, float(M), vp(g), vp(b_), 1e-5, 0.1, vp(rmd), vp(rvd), vp(nbt),
+                             vp(coef[0]), vp(coef[1]), vp(coef[2]), vp(coef[3]), stream()))
+    y = torch.empty_like(zd)
+    N.check(L.vt_bn_act_apply(vp(zd), Cc, vp(coef[0]), vp(coef[1]), vp(rd), Cc, vp(y), Cc, M, Cc, 1, dtype, stream()))
+    assert rel_err(to_nchw(y), y_ref.detach()) < tol(dtype, 1e-5)
+    np.testing.assert_allclose(rmd.cpu(), rm_ref, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rvd.cpu(), rv_ref, rtol=1e-4, atol=1e-6)
+    assert nbt[0].item() == 1
+    sums = torch.zeros(N.VT_STAT_REPLICAS, 2, Cc, device="cuda")
+    N.check(L.vt_bn_act_bwd_reduce(vp(dyd), Cc, vp(zd), Cc, vp(coef[0]), vp(coef[1]), vp(coef[2]), vp(coef[3]),
+                                   M, Cc, 1, dtype, vp(sums), stream()))
+    dg, db = torch.ones(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+    bc = torch.zeros(3, Cc, device="cuda")
+    N.check(L.vt_bn_bwd_finalize(vp(sums), Cc, float(M), vp(coef[0]), vp(coef[2]), vp(coef[3]), 1, vp(dg), vp(db),
+                                 vp(bc), stream()))
+    dz = torch.empty_like(zd)
+    N.check(L.vt_bn_act_bwd_apply(vp(dyd), Cc, vp(zd), Cc, vp(coef[0]), vp(coef[1]), vp(bc), vp(dz), Cc, M, Cc, 1,
+                                  dtype, stream()))
+    assert rel_err(to_nchw(dz), zt.grad) < tol(dtype, 1e-4)
+    np.testing.assert_allclose((dg - 1).cpu(), gamma.grad, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose((db - 1).cpu(), beta.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DNAME.get)
+@pytest.mark.parametrize("shape", [(2, 16, 9, 9), (1, 40, 8, 12), (2, 8, 7, 7)], ids=str)
+def test_maxpool_3x3_s2(dtype, shape):
+    """nn.MaxPool2d(3,2,1) (vovnet.py:94), ties included: the input is post-ReLU."""
+    x = rounded(torch.relu(filler.tensor(f"mp{shape}", shape)), dtype).requires_grad_(True)
+    y_ref = F.max_pool2d(x, 3, 2, 1)
+    dy = rounded(filler.tensor(f"mpdy{shape}", y_ref.shape), dtype)
+    y_ref.backward(dy)
+    B, Cc, H, W = shape
+    xd, dyd = nhwc(x.detach(), dtype), nhwc(dy, dtype)
+    Ho, Wo = y_ref.shape[2:]
+    y = torch.empty(B, Ho, Wo, Cc, device="cuda", dtype=TD[dtype])
+    am = torch.zeros(B * Ho * Wo * Cc, dtype=torch.uint8, device="cuda")
+    L = N.lib()
+    N.check(L.vt_maxpool3x3s2_fwd(vp(xd), Cc, vp(y), Cc, vp(am), B, H, W, Cc, dtype, stream()))
+    assert torch.equal(to_nchw(y), y_ref.detach())
+    dx = torch.full((B, H, W, Cc), 1.0, device="cuda", dtype=TD[dtype])
+    N.check(L.vt_maxpool3x3s2_bwd(vp(dyd), Cc, vp(am), vp(dx), Cc, B, H, W, Cc, 1, dtype, stream()))
+    assert rel_err(to_nchw(dx) - 1.0, x.grad) < tol(dtype, 1e-6, 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DNAME.get)
+def test_global_avgpool_and_ese_gate(dtype):
+    B, Cc, H, W = 3, 24, 5, 4
+    x = rounded(filler.tensor("ex", (B, Cc, H, W)), dtype).requires_grad_(True)
+    s = rounded(filler.tensor("es", (B, Cc, 1, 1)) * 3, dtype).requires_grad_(True)
+    r = rounded(filler.tensor("er", (B, Cc, H, W)), dtype)
+    y_ref = x * F.hardsigmoid(s) + r
+    dy = rounded(filler.tensor("edy", y_ref.shape), dtype)
+    y_ref.backward(dy)
+    L = N.lib()
+    xd, sd, rd, dyd = nhwc(x.detach(), dtype), nhwc(s.detach(), dtype), nhwc(r, dtype), nhwc(dy, dtype)
+    pooled = torch.empty(B, Cc, device="cuda", dtype=TD[dtype])
+    N.check(L.vt_global_avgpool_fwd(vp(xd), Cc, vp(pooled), Cc, B, H * W, Cc, dtype, stream()))
+    assert rel_err(pooled.float().cpu(), x.detach().mean((2, 3))) < tol(dtype, 1e-6)
+    y = torch.empty_like(xd)
+    N.check(L.vt_ese_gate_fwd(vp(xd), Cc, vp(sd), Cc, vp(rd), Cc, vp(y), Cc, B, H * W, Cc, dtype, stream()))
+    assert rel_err(to_nchw(y), y_ref.detach()) < tol(dtype, 1e-6)
+    dx = torch.zeros_like(xd)
+    ds = torch.zeros(B, Cc, device="cuda")
+    N.check(L.vt_ese_gate_bwd(vp(dyd), Cc, vp(xd), Cc, vp(sd), Cc, vp(dx), Cc, vp(ds), B, H * W, Cc, 0, dtype, stream()))
+    assert rel_err(to_nchw(dx), x.grad) < tol(dtype, 1e-6)
+    assert rel_err(ds.cpu(), s.grad.reshape(B, Cc)) < 1e-5
+    # avgpool backward with accumulation
+    g = rounded(filler.tensor("apg", (B, Cc)), dtype)
+    gd = g.to("cuda", TD[dtype])
+    acc = torch.ones(B, H, W, Cc, device="cuda", dtype=TD[dtype])
+    N.check(L.vt_global_avgpool_bwd(vp(gd), Cc, vp(acc), Cc, B, H * W, Cc, 1, dtype, stream()))
+    ref = 1.0 + (g / (H * W))[:, :, None, None].expand(B, Cc, H, W)
+    assert rel_err(to_nchw(acc), ref) < tol(dtype, 1e-6)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DNAME.get)
+def test_softmax_cross_entropy_label_smoothing(dtype):
+    """F.cross_entropy(logits, labels, label_smoothing) (classifier.py:92) and its gradient."""
+    B, Ncls = 6, 1000
+    logits = rounded(filler.tensor("xl", (B, Ncls)) * 3, dtype).requires_grad_(True)
+    y = filler.labels(B, Ncls)
+    loss_ref = F.cross_entropy(logits, y, label_smoothing=0.1)
+    loss_ref.backward()
+    ld = logits.detach().to("cuda", TD[dtype])
+    loss = torch.zeros(1, device="cuda")
+    dl = torch.empty_like(ld)
+    yd = y.cuda()
+    N.check(N.lib().vt_softmax_xent(vp(ld), Ncls, vp(yd), 0.1, 1.0 / B, vp(loss), vp(dl), Ncls, B, Ncls,
+                                    dtype, stream()))
+    assert loss.item() == pytest.approx(loss_ref.item(), rel=1e-5)
+    assert rel_err(dl.float().cpu(), logits.grad) < tol(dtype, 1e-5)
+
+
+def test_sgd_momentum_matches_torch_optim():
+    n = 100_003
+    p0, g = filler.tensor("sp", (n,)), filler.tensor("sg", (n,))
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([ref], lr=0.05, momentum=0.9, weight_decay=2e-5)
+    n_pad = (n + 3) // 4 * 4
+    p = torch.zeros(n_pad, device="cuda")
+    p[:n] = p0.cuda()
+    gd = torch.zeros(n_pad, device="cuda")
+    gd[:n] = g.cuda()
+    m = torch.zeros(n_pad, device="cuda")
+    mirror = torch.zeros(n_pad, device="cuda", dtype=torch.bfloat16)
+    lr_dev = torch.tensor([0.05], device="cuda")
+    for step in range(3):
+        ref.grad = g.clone() * (step + 1)
+        opt.step()
+        N.check(N.lib().vt_sgd_momentum(vp(p), vp(gd), vp(m), vp(mirror), N.VT_BF16, n, 123.0, 0.9, 2e-5,
+                                        float(step + 1), vp(lr_dev), stream()))
+    torch.testing.assert_close(p[:n].cpu(), ref.data, rtol=1e-6, atol=1e-6)  # fma vs mul+add
+    assert torch.equal(mirror[:n], p[:n].to(torch.bfloat16))  # the mirror is the RNE cast of the new weights
+
+
+def test_layout_and_pack_kernels():
+    L = N.lib()
+    x = filler.tensor("img", (2, 3, 5, 7))
+    for dtype in DTYPES:
+        cpad = 8 if dtype == N.VT_BF16 else 4
+        y = torch.full((2, 5, 7, cpad), float("nan"), device="cuda", dtype=TD[dtype])
+        xc = x.cuda()
+        N.check(L.vt_nchw_to_nhwc(vp(xc), vp(y), 2, 3, 5, 7, cpad, dtype, stream()))
+        assert torch.equal(y[..., :3].float().cpu(), rounded(x, dtype).permute(0, 2, 3, 1))
+        assert (y[..., 3:] == 0).all()
+        back = torch.zeros(2, 3, 5, 7, device="cuda")
+        N.check(L.vt_nhwc_to_nchw(vp(y), cpad, vp(back), 2, 3, 5, 7, dtype, stream()))
+        assert torch.equal(back.cpu(), rounded(x, dtype))
+    # copy2d with conversion and accumulation
+    a = filler.tensor("c2", (6, 10))
+    dst = torch.ones(6, 16, device="cuda")
+    ac = a.cuda()
+    N.check(L.vt_copy2d(vp(ac), N.VT_F32, 10, vp(dst), N.VT_F32, 16, 6, 10, 1, stream()))
+    torch.testing.assert_close(dst[:, :10].cpu(), a + 1)
+    assert (dst[:, 10:] == 1).all()
+    # dgrad filter pack: out[c][i][n] = w[n][sel[i]][c]
+    Cout, taps, Cin = 8, 9, 4
+    w = filler.tensor("pk", (Cout, taps, Cin))
+    sel = [8, 6, 2, 0]
+    out = torch.zeros(Cin, len(sel), Cout, device="cuda", dtype=torch.bfloat16)
+    arr = (C.c_int32 * len(sel))(*sel)
+    wc = w.cuda()
+    N.check(L.vt_pack_dgrad_filter(vp(wc), N.VT_F32, taps * Cin, vp(out), N.VT_BF16, arr, len(sel), Cout, taps,
+                                   Cin, stream()))
+    ref = w[:, sel, :].permute(2, 1, 0).to(torch.bfloat16)
+    assert torch.equal(out.cpu(), ref)
+    # column sums
+    mat = filler.tensor("cs", (37, 24))
+    acc = torch.ones(24, device="cuda")
+    mc = mat.cuda()
+    N.check(L.vt_colsum(vp(mc), 24, 37, 24, N.VT_F32, vp(acc), stream()))
+    torch.testing.assert_close(acc.cpu(), mat.sum(0) + 1, rtol=1e-5, atol=1e-5)
+
+
+def test_executor_and_graph_replay_agree():
+    """vt_run_ops and a captured hipGraph of the same list give identical results."""
+    from vision_toolbox import engine as E
+
+    n = 4096
+    src = filler.tensor("gsrc", (n,)).cuda()
+    dst1, dst2 = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    op = N.Op()
+    op.kind = N.OP_COPY2D
+    for k in range(N.VT_OP_MAX_PTR):
+        op.ptr[k].base = -1
+    op.ptr[0].base, op.ptr[1].base = 0, 1
+    op.i[0], op.i[1], op.i[2], op.i[3] = N.VT_F32, N.VT_F32, n, 1
+    op.f[0], op.f[1], op.f[2] = n, n, 1
+    ops = E.ops_array([op, op])
+    N.run_ops(ops, 2, [src.data_ptr(), dst1.data_ptr()], stream())
+    g = N.Graph(ops, 2, [src.data_ptr(), dst2.data_ptr()])
+    g.launch(stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dst1, 2 * src) and torch.equal(dst2, 2 * src)
+    g.launch(stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dst2, 4 * src)
+    # error surface: unknown kind is reported, not fatal
+    bad = N.Op()
+    bad.kind = 999
+    with pytest.raises(N.NativeError):
+        N.run_ops(E.ops_array([bad]), 1, [src.data_ptr()], stream())

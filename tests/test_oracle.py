@@ -77,6 +77,20 @@ def test_oracle_train_step_matches_reference(name, gm):
 
 
 @pytest.mark.parametrize("name", MODELS)
+def test_oracle_eval_mode_gradients_match_reference(name, gm):
+    sd = _clf_sd(name, 16)
+    for k, v in sd.items():
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    loss, _ = R.classifier_loss(name, sd, filler.images(4, 64), filler.labels(4, 16), 0.1, training=False)
+    loss.backward()
+    assert loss.item() == pytest.approx(float(gm[f"{name}.evalgrad.loss"]), rel=1e-5)
+    keys = list(gm[f"{name}.train.grad_keys"])
+    got = np.array([sd[k].grad.double().norm().item() for k in keys])
+    np.testing.assert_allclose(got, gm[f"{name}.evalgrad.grad_norms"], rtol=1e-3, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", MODELS)
 def test_oracle_eval_feature_maps_match_reference(name, gm):
     sd = _clf_sd(name, 16)
     x = filler.images(4, 64)

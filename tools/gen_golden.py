@@ -210,6 +210,20 @@ def gen_models():
         sd_grads = dict(model.named_parameters())
         for k in (keys[0], keys[len(keys) // 2], "3.weight", "3.bias"):
             out[f"{name}.train.grad.{k}"] = np_(sd_grads[k].grad)
+        # eval-mode forward WITH gradients (BatchNorm uses its running statistics as constants):
+        # a well-conditioned check of the whole backward wiring, free of the batch-statistics
+        # amplification that 16 samples per channel cause in train mode
+        filler.fill_module(model, name + ".")
+        model.eval()
+        model.zero_grad()
+        logits = model(x)
+        loss = F.cross_entropy(logits, y, label_smoothing=LABEL_SMOOTHING)
+        loss.backward()
+        out[f"{name}.evalgrad.loss"] = np.array(loss.item())
+        out[f"{name}.evalgrad.grad_norms"] = np.array([p.grad.double().norm().item() for _, p in model.named_parameters()])
+        sd_grads = dict(model.named_parameters())
+        for k in (keys[0], keys[1], keys[len(keys) // 2], "3.weight"):
+            out[f"{name}.evalgrad.grad.{k}"] = np_(sd_grads[k].grad)
         # eval forward
         filler.fill_module(model, name + ".")
         model.eval()

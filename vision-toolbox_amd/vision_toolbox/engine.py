@@ -90,8 +90,9 @@ class ParamStore:
     physically [Cout][kh][kw][Cin], which is the filter image the kernels read.
     """
 
-    def __init__(self, root: nn.Module):
+    def __init__(self, root: nn.Module, order_key=None):
         self.root = root
+        self.order_key = order_key  # optional grouping of the flat layout (stable sort key per parameter)
         self.device = None
         self.pflat = self.sflat = self.nflat = self.mirror = None
         self.index: dict[int, tuple[int, int, int]] = {}  # id(tensor owner) -> (base, elem offset, numel)
@@ -112,6 +113,8 @@ class ParamStore:
                     continue
                 seen.add(id(b))
                 (fbufs if b.is_floating_point() else ibufs).append((mod, name, b))
+        if self.order_key is not None:
+            params.sort(key=self.order_key)  # stable: registration order inside each group
         return params, fbufs, ibufs
 
     def stale(self, device) -> bool:

@@ -9,6 +9,7 @@ autograd-tracked tensors, so user heads / necks (necks.py:83) compose with them.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import Optional, Sequence
 
@@ -17,6 +18,21 @@ from torch import nn
 
 from . import _native as N
 from . import engine as E
+
+
+@contextlib.contextmanager
+def tracing_paused():
+    """host-side set-up (flat parameter store, program compilation) must not be recorded by
+    torch.jit.trace; only the BackboneFn call is (as one PythonOp)."""
+    state = torch._C._get_tracing_state()
+    if state is None:
+        yield
+        return
+    torch._C._set_tracing_state(None)
+    try:
+        yield
+    finally:
+        torch._C._set_tracing_state(state)
 
 
 def current_stream_handle() -> int:
@@ -95,7 +111,8 @@ class _RunState:
 class BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, runner: "BackboneRunner", prog: Program, x: torch.Tensor, *params):
-        st, outs = runner._run_forward(prog, x)
+        with tracing_paused():
+            st, outs = runner._run_forward(prog, x)
         ctx.runner, ctx.st = runner, st
         ctx.x_requires_grad = x.requires_grad
         return tuple(outs)
@@ -149,11 +166,13 @@ class BackboneRunner:
             )
         N.lib()  # raises if the extension is missing
         dtype = resolve_dtype(x, compute_dtype)
-        self.store.ensure(x.device)
-        params = self.store.params
-        need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
-        prog = self.program(x, dtype, all_maps, need_grad)
-        if need_grad:
+        tracing = torch._C._get_tracing_state() is not None
+        with tracing_paused():
+            self.store.ensure(x.device)
+            params = self.store.params
+            need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+            prog = self.program(x, dtype, all_maps, need_grad)
+        if need_grad or tracing:  # under jit.trace the call must be recorded as one op
             outs = BackboneFn.apply(self, prog, x, *params)
         else:
             _, outs = self._run_forward(prog, x)

@@ -1,0 +1,276 @@
+"""Fused ImageNet-classifier train step on one MI355X, data-parallel over RCCL.
+
+What the reference does through Lightning (classifier.py:58-64 model assembly, :83-95
+training_step, :111-169 three-group SGD, configs/base.yaml:16-23 DDP) is here ONE static
+program per rank:
+
+    images -> backbone -> global avg-pool -> linear head -> label-smoothing CE
+           -> explicit backward into a persistent flat f32 gradient buffer
+           -> bucketed gradient all-reduce (RCCL over xGMI); each bucket is issued as soon
+              as the backward segment that completes it has been enqueued
+           -> SGD(momentum) over the flat buffers, which also refreshes the bf16 weights
+
+Every segment is a captured hipGraph (vt_graph_*), so a step costs a handful of host calls.
+BatchNorm uses per-rank batch statistics (SyncBN, configs/base.yaml:22, is not enabled: its
+134 latency-bound collectives per step would dominate a ~10 ms step).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import _native as N
+from . import engine as E
+from .distributed import GradBucketer, plan_buckets
+from .program import Program, current_stream_handle
+
+_NORMS = (nn.modules.batchnorm._BatchNorm, nn.modules.instancenorm._InstanceNorm, nn.LayerNorm, nn.GroupNorm)
+GROUP_NORM, GROUP_BIAS, GROUP_OTHER = 0, 1, 2  # flat-buffer order: small, late-produced groups first
+
+
+class _LinearAsConv:
+    """nn.Linear seen as a 1x1 convolution over a [B,1,1,C] map (classifier.py:63)."""
+
+    kernel_size = (1, 1)
+    stride = (1, 1)
+    padding = (0, 0)
+    dilation = (1, 1)
+    groups = 1
+
+    def __init__(self, linear: nn.Linear):
+        self.weight, self.bias = linear.weight, linear.bias
+        self.out_channels, self.in_channels = linear.out_features, linear.in_features
+
+
+def param_groups(model: nn.Module) -> dict:
+    """id(param) -> group, the split of classifier.py:111-155 (norm / bias / everything else)."""
+    out = {}
+    for mod in model.modules():
+        for name, p in mod._parameters.items():
+            if p is None:
+                continue
+            if isinstance(mod, _NORMS):
+                g = GROUP_NORM
+            elif isinstance(mod, (nn.Linear, nn.modules.conv._ConvNd)) and name == "bias":
+                g = GROUP_BIAS
+            else:
+                g = GROUP_OTHER
+            out[id(p)] = g
+    return out
+
+
+def warmup_cosine_lr(epoch: int, max_epochs: int, lr: float, warmup_epochs: int = 5, warmup_factor: float = 0.01,
+                     decay_factor: float = 0.0) -> float:
+    """LinearLR warm-up then CosineAnnealingLR, stepped per epoch (classifier.py:171-190)."""
+    if warmup_epochs > 0 and epoch < warmup_epochs:
+        return lr * (warmup_factor + (1 - warmup_factor) * epoch / warmup_epochs)
+    t, T = epoch - warmup_epochs, max(max_epochs - warmup_epochs, 1)
+    eta_min = lr * decay_factor
+    return eta_min + (lr - eta_min) * (1 + math.cos(math.pi * t / T)) / 2
+
+
+def _grad_write_offsets(op: N.Op) -> list[int]:
+    """element offsets in the flat gradient buffer this backward op writes."""
+    return [op.ptr[k].offset // 4 for k in range(N.VT_OP_MAX_PTR) if op.ptr[k].base == E.GRADS]
+
+
+class TrainStep:
+    def __init__(
+        self,
+        backbone: nn.Module,
+        num_classes: int = 1000,
+        batch_size: int = 256,  # per rank
+        image_size: int = 224,
+        dtype: torch.dtype = torch.bfloat16,
+        lr: float = 0.05,
+        momentum: float = 0.9,
+        weight_decay: float = 2e-5,
+        norm_weight_decay: float = 0.0,
+        bias_weight_decay: float = 0.0,
+        label_smoothing: float = 0.1,
+        device: Optional[torch.device] = None,
+        process_group=None,
+        bucket_mb: float = 16.0,
+        use_graphs: bool = True,
+        plan_only: bool = False,
+    ):
+        N.lib()
+        self.device = torch.device(device if device is not None else "cuda")
+        self.plan_only = plan_only  # build launch lists / bucket plan without a GPU (host-logic tests)
+        if self.device.type != "cuda" and not plan_only:
+            raise RuntimeError("TrainStep runs on the GPU only (no CPU fallback)")
+        self.B, self.S = batch_size, image_size
+        self.dtype = N.VT_BF16 if dtype == torch.bfloat16 else N.VT_F32
+        self.pg = process_group
+        self.world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world = torch.distributed.get_world_size(process_group)
+        head = nn.Linear(backbone.get_last_out_channels(), num_classes)
+        self.model = nn.Sequential(backbone, nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten(), head)
+        self.model.train()
+
+        groups = param_groups(self.model)
+        self.store = st = E.ParamStore(self.model, order_key=lambda p: groups[id(p)])
+        with self._dev_ctx():
+            st.ensure(self.device)
+            self.gflat = torch.zeros_like(st.pflat)
+            self.mflat = torch.zeros_like(st.pflat)
+            self.lr_dev = torch.full((4,), lr, dtype=torch.float32, device=self.device)
+            self.images = torch.zeros(batch_size, 3, image_size, image_size, device=self.device)
+            self.labels = torch.zeros(batch_size, dtype=torch.int64, device=self.device)
+        self.lr = lr
+        total = st.pflat.numel()
+
+        # ---- forward + loss + backward launch lists ---------------------------------------
+        b = E.Builder(st, self.dtype, training=True, need_grad=True, grad_base=E.GRADS)
+        x = b.input_images(batch_size, 3, image_size, image_size)
+        fmap = backbone._vt_emit_maps(b, x)[-1]
+        pooled = b.global_avgpool(fmap, "head.pool")
+        logits = b.conv_unit(pooled, _LinearAsConv(head), None, False, name="head.linear")
+        self._loss_buf = b.xent(logits, label_smoothing, 1.0 / batch_size)
+        self._logits = logits
+        b.build_backward()
+        self.prog = Program(b, [logits], [])
+        self.n_units = b.n_units
+
+        # ---- optimiser launch list: one SGD launch per weight-decay group ---------------------
+        wd_of = {GROUP_OTHER: weight_decay, GROUP_NORM: norm_weight_decay, GROUP_BIAS: bias_weight_decay}
+        self.segments = []  # (elem start, elem end, weight decay)
+        gids = [groups[id(p)] for p in st.params]
+        start = 0
+        for i, p in enumerate(st.params):
+            if i + 1 == len(st.params) or gids[i + 1] != gids[i]:
+                end = st.offsets[i] + E._round_up(p.numel(), 64)
+                self.segments.append((start, end, wd_of[gids[i]]))
+                start = end
+        ob = E.Builder(st, self.dtype, True, True, grad_base=E.GRADS)
+        for s0, s1, wd in self.segments:
+            ob.emit(N.OP_SGD,
+                    [(E.PARAMS, s0 * 4), (E.GRADS, s0 * 4), (E.MOMENTUM, s0 * 4),
+                     (E.MIRROR, s0 * 2) if self.dtype == N.VT_BF16 else None, (E.HYPER, 0)],
+                    [N.VT_BF16], [s1 - s0, lr, momentum, wd, 1.0 / self.world])
+        self.opt_ops, self.n_opt = E.ops_array(ob.fwd), len(ob.fwd)
+        zb = E.Builder(st, self.dtype, True, True)
+        zb.emit(N.OP_MEMSET, [(E.GRADS, 0)], [0], [total * 4])
+        self.zero_ops = E.ops_array(zb.fwd)
+
+        # ---- gradient buckets and the backward segments that complete them --------------------
+        self.bucketer = None
+        self.bwd_cuts = [self.prog.n_bwd]  # op index after which each segment ends
+        self.cut_buckets: list[list[int]] = [[]]
+        if self.world > 1:
+            buckets = plan_buckets(total, int(bucket_mb * (1 << 20)) // 4)
+            self.bucketer = GradBucketer(self.gflat, buckets, self.pg)
+            ready = [0] * len(buckets)  # last bwd op that writes into each bucket
+            for idx in range(self.prog.n_bwd):
+                for off in _grad_write_offsets(self.prog.bwd_ops[idx]):
+                    for bi, (s0, s1) in enumerate(buckets):
+                        if s0 <= off < s1:
+                            ready[bi] = max(ready[bi], idx + 1)
+            cuts = sorted(set(ready) | {self.prog.n_bwd})
+            self.bwd_cuts = [c for c in cuts if c > 0]
+            self.cut_buckets = [[bi for bi, r in enumerate(ready) if r == c or (c == self.bwd_cuts[0] and r == 0)]
+                                for c in self.bwd_cuts]
+
+        with self._dev_ctx():
+            self.arena = torch.empty(1 if plan_only else self.prog.arena_bytes, dtype=torch.uint8, device=self.device)
+            if self.dtype == N.VT_BF16:
+                st.mirror.copy_(st.pflat)  # initial bf16 weights; afterwards SGD keeps them fresh
+        self.bases = self.prog.bases(
+            self.arena.data_ptr(), PARAMS=st.pflat.data_ptr(), GRADS=self.gflat.data_ptr(),
+            STATE=st.sflat.data_ptr(), MIRROR=st.mirror.data_ptr(), COUNTERS=st.nflat.data_ptr(),
+            INPUT=self.images.data_ptr(), LABELS=self.labels.data_ptr(), MOMENTUM=self.mflat.data_ptr(),
+            HYPER=self.lr_dev.data_ptr())
+        self.use_graphs = use_graphs
+        self._graphs = None
+        self.steps_done = 0
+
+    def _dev_ctx(self):
+        import contextlib
+
+        return torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()
+
+    # -- data-parallel plumbing ----------------------------------------------------------------
+    def broadcast_parameters(self, src: int = 0) -> None:
+        """initial weights + buffers from rank `src` (what DDP's constructor does)."""
+        if self.world > 1:
+            torch.distributed.broadcast(self.store.pflat, src, group=self.pg)
+            torch.distributed.broadcast(self.store.sflat, src, group=self.pg)
+            if self.dtype == N.VT_BF16:
+                self.store.mirror.copy_(self.store.pflat)
+
+    def weights_changed(self) -> None:
+        """call after writing parameters from outside (load_state_dict, manual init)."""
+        if self.dtype == N.VT_BF16:
+            self.store.mirror.copy_(self.store.pflat)
+
+    def set_lr(self, lr: float) -> None:
+        self.lr = lr
+        self.lr_dev.fill_(lr)
+
+    # -- one step ----------------------------------------------------------------------------------
+    def _segment_ops(self):
+        """(ops pointer, count) of every backward segment."""
+        p = self.prog
+        segs, lo = [], 0
+        for hi in self.bwd_cuts:
+            sub = (N.Op * (hi - lo)).from_address(ctypes.addressof(p.bwd_ops) + lo * ctypes.sizeof(N.Op))
+            segs.append((sub, hi - lo))
+            lo = hi
+        return segs
+
+    def _build_graphs(self):
+        p = self.prog
+        with self._dev_ctx():
+            self._graphs = {
+                "head": N.Graph(E.ops_array(list(self.zero_ops[:1]) + [p.fwd_ops[i] for i in range(p.n_fwd)]),
+                                1 + p.n_fwd, self.bases),
+                "bwd": [N.Graph(ops, n, self.bases) for ops, n in self._segment_ops()],
+                "opt": N.Graph(self.opt_ops, self.n_opt, self.bases),
+            }
+
+    def step(self, images: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None) -> None:
+        """fwd + loss + bwd + gradient all-reduce + SGD on the resident (or given) batch."""
+        if self.plan_only:
+            raise RuntimeError("plan_only TrainStep cannot execute: there is no CPU path")
+        with self._dev_ctx():
+            if images is not None:
+                self.images.copy_(images, non_blocking=True)
+            if labels is not None:
+                self.labels.copy_(labels, non_blocking=True)
+            s = current_stream_handle()
+            p = self.prog
+            if self.use_graphs:
+                if self._graphs is None:
+                    self._build_graphs()
+                self._graphs["head"].launch(s)
+                for g, bks in zip(self._graphs["bwd"], self.cut_buckets):
+                    g.launch(s)
+                    for bi in bks:
+                        self.bucketer.reduce_bucket(bi)
+            else:
+                N.run_ops(self.zero_ops, 1, self.bases, s)
+                N.run_ops(p.fwd_ops, p.n_fwd, self.bases, s)
+                for (ops, n), bks in zip(self._segment_ops(), self.cut_buckets):
+                    N.run_ops(ops, n, self.bases, s)
+                    for bi in bks:
+                        self.bucketer.reduce_bucket(bi)
+            if self.bucketer is not None:
+                self.bucketer.finish()
+            if self.use_graphs:
+                self._graphs["opt"].launch(s)
+            else:
+                N.run_ops(self.opt_ops, self.n_opt, self.bases, s)
+        self.steps_done += 1
+
+    def loss(self) -> float:
+        """mean loss of the last step (synchronises)."""
+        off = self.prog.zf_off + self._loss_buf.offset
+        return float(self.arena[off : off + 4].view(torch.float32).item())
+
+    def logits(self) -> torch.Tensor:
+        return E.tref_to_tensor(self.arena, self._logits).reshape(self.B, -1)
