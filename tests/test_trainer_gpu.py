@@ -40,7 +40,7 @@ def _oracle_steps(name, ncls, x, y, steps, lr, wd, prefix):
 def test_train_steps_f32_match_oracle(name, graphs):
     # small lr: at 4 images @64px a large step makes the 3-step trajectory chaotic (any two f32
     # implementations diverge), which would test conditioning, not correctness
-    ncls, B, S, steps, lr, wd = 16, 4, 64, 3, 1e-3, 1e-3
+    ncls, B, S, steps, lr, wd = 16, 8, 96, 3, 2e-4, 1e-3
     x, y = filler.images(B, S), filler.labels(B, ncls)
     ref_losses, ref_sd = _oracle_steps(name, ncls, x, y, steps, lr, wd, "tr.")
     ts = TrainStep(getattr(backbones, name)(), ncls, B, S, torch.float32, lr=lr, momentum=0.9, weight_decay=wd,
@@ -54,7 +54,7 @@ def test_train_steps_f32_match_oracle(name, graphs):
         ts.step(x.cuda(), y.cuda())
         got.append(ts.loss())
     assert N.launch_count() > before
-    np.testing.assert_allclose(got, ref_losses, rtol=5e-3)
+    np.testing.assert_allclose(got, ref_losses, rtol=1e-2)
     sd = ts.model.state_dict()
     stem = "0.stem.conv.weight" if name == "cspdarknet53" else "0.stem.0.conv.weight"
     for k, tol in ((stem, 0.1), ("3.weight", 0.03), ("3.bias", 0.03)):

@@ -9,13 +9,28 @@
 //     B[k][n]       = w[n][t][c]                               ("B^T": K contiguous)
 //
 // Tiling: BM x BN output tile per 256-thread workgroup (4 waves, 64-wide), K in
-// steps of 64 bytes per row (32 bf16 / 16 f32).  Both operands are staged
-// global -> VGPR -> LDS in 16-byte chunks (one NHWC pixel contributes 16 B of
-// consecutive channels, so HBM/L2 reads are whole 64-byte row segments), LDS is
-// double buffered with ONE barrier per K-step and the next step's global loads
-// are issued before the current step's MFMAs.  The LDS image is XOR-swizzled so
-// that both the ds_write_b128 of staging and the ds_read_b128 of the MFMA
-// fragments are bank-conflict free (see swz()).
+// steps of 64 bytes per row (32 bf16 / 16 f32).
+//
+// Operand staging is an LDS-DMA ring: every wave-instruction is one
+// global_load_lds_dwordx4 that moves 64 x 16 B (one 16-byte chunk = 8 bf16
+// channels of one NHWC pixel / one filter row per lane) straight from global
+// memory into LDS, no VGPR round trip.  NS = PD+1 stage slots are kept; the loads
+// of K-step ks+PD are issued right after the single barrier of K-step ks, and a
+// COUNTED s_waitcnt vmcnt(IT*(PD-1)) retires exactly the stage about to be read,
+// so PD stages stay in flight across barriers (the loop is latency-bound
+// otherwise: measured 470 TFLOP/s with a one-deep register-staged prefetch).
+// Zero padding, M/N/K tails: the lane's SOURCE address is redirected to a
+// 16-byte zero page, so every lane of every wave issues every load (the LDS
+// destination of an LDS-DMA is lane-linear and cannot be predicated).
+// The LDS image is XOR-swizzled through the source side: LDS slot q of a stage is
+// written linearly, and the lane that owns slot q fetches chunk (q&3)^swz(q>>2)
+// of row q>>2, which makes the ds_read_b128 of the MFMA fragments conflict free.
+//
+// The loads are issued from inline asm on purpose: hipcc would otherwise treat
+// each LDS-DMA as a pending LDS write and drain vmcnt(0) before the first ds_read
+// of every K-step.  Consequently this kernel counts its own VM operations: there
+// is no compiler-visible global load between the first DMA and the final
+// vmcnt(0) (kernel arguments arrive through the scalar cache).
 //
 // MFMA: v_mfma_f32_16x16x32_bf16 (bf16) or 4 x v_mfma_f32_16x16x4_f32 (exact
 // f32 parity mode).  Both use the same fragment addressing: lane l reads chunk
@@ -54,15 +69,30 @@ constexpr int kTapBytes = VT_MAX_TAPS * 16;  // int4 per tap
 constexpr int kStatBytes = 2 * 128 * 4;      // sum, sumsq for BN <= 128
 constexpr int kHdrBytes = kTapBytes + kStatBytes;
 
+__device__ __attribute__((aligned(16))) unsigned int vt_zero16[4];  // source of every padded chunk
+
 // chunk swizzle of a 64-byte LDS row: conflict free for ds_read_b128 issued as
-// (row = l&15, chunk = l>>4) and for ds_write_b128 issued as (row = t>>2, chunk = t&3).
+// (row = l&15, chunk = l>>4).
 __device__ __forceinline__ int swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
 
-template <typename T>
-__device__ __forceinline__ uint4 ldg_pred(const T* ptr, bool valid) {
-    uint4 r = make_uint4(0, 0, 0, 0);
-    if (valid) r = *(const uint4*)ptr;
-    return r;
+// one LDS-DMA wave-instruction: lane l copies 16 B from its own global address to
+// LDS byte address lds_base + 16*l.  M0 carries the LDS base and is restored.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_base)
+        : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 template <typename T>
@@ -81,27 +111,39 @@ __device__ __forceinline__ void mma<float>(const uint4& a, const uint4& b, f32x4
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const IgemmArgs p) {
-    constexpr int NT = WM * WN * 64;
+template <int BM, int BN, int PD>
+struct Geom {
+    static constexpr int NI_A = BM / 16;                // DMA instructions covering the A tile
+    static constexpr int NI = (BM + BN) / 16;           // ... the whole stage
+    static constexpr int IT = (NI + 3) / 4;             // per wave (4 waves), padded with dummies
+    static constexpr int SS = IT * 4 * 64;              // uint4 slots per stage incl. dummy area
+    static constexpr int NS = PD + 1;                   // stage slots
+    static constexpr int STAGE_BYTES = NS * SS * 16;
+};
+
+template <typename T, int BM, int BN, int WM, int WN, int PD>
+__global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs p) {
+    using G = Geom<BM, BN, PD>;
+    constexpr int NT = 256;
     constexpr int EPC = 16 / sizeof(T);
     constexpr int BK = 4 * EPC;
     constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
-    constexpr int A_IT = (BM * 4 + NT - 1) / NT;
-    constexpr int B_IT = (BN * 4 + NT - 1) / NT;
+    constexpr int IT = G::IT, SS = G::SS, NS = G::NS;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be 16-granular");
     static_assert(BN <= 128, "stat scratch sized for BN <= 128");
+    static_assert(BM % 16 == 0 && BN % 16 == 0, "tile rows come in groups of 16 per DMA instruction");
+    static_assert(PD >= 1 && PD <= 3, "prefetch distance");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int4* sTap = (int4*)smem;
     float* sStat = (float*)(smem + kTapBytes);
-    uint4* sA = (uint4*)(smem + kHdrBytes);  // [2][BM*4]
-    uint4* sB = sA + 2 * BM * 4;             // [2][BN*4]
-    T* sOut = (T*)(smem + kHdrBytes);        // [BM][BN], aliases staging after the K loop
+    uint4* sStage = (uint4*)(smem + kHdrBytes);  // [NS][SS]: A rows, then B rows, then dummy slots
+    T* sOut = (T*)(smem + kHdrBytes);            // [BM][BN], aliases the ring after the K loop
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
     // XCD-aware tile map
@@ -126,71 +168,69 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const IgemmArgs p) {
 
     const T* __restrict__ xg = (const T*)p.x;
     const T* __restrict__ wg = (const T*)p.w;
+    const unsigned long zero_src = (unsigned long)(const void*)vt_zero16;
+    const unsigned ring_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)sStage;
 
-    // ---- per-thread staging geometry (fixed for the whole K loop) ----------
-    const int cj = tid & 3;
-    int hb[A_IT], wb[A_IT];
-    long boff[A_IT];
-    bool rvalid[A_IT];
+    // ---- per-lane DMA geometry (fixed for the whole K loop) --------------------
+    // instruction j = wave + 4*i of a stage fills slots [64j, 64j+64); lane l owns slot
+    // q = 64j + l = row (q>>2), position (q&3), and fetches chunk (q&3) ^ swz(row).
+    // (row>>2)&3 == (l>>4)&3 for every j, so the chunk is the same for all of a lane's loads.
+    const int cj = (lane & 3) ^ ((0x1320 >> (((lane >> 4) & 3) * 4)) & 3);
+    int hb[IT], wb[IT];
+    long off0[IT];
+    bool valid[IT];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-        const int row = (tid >> 2) + i * (NT / 4);
-        const int m = tm * BM + row;
-        rvalid[i] = (row < BM) && (m < p.M);
-        const int mm = rvalid[i] ? m : 0;
-        const int b = mm / HoWo;
-        const int rem = mm - b * HoWo;
-        const int oi = rem / p.Wo;
-        const int oj = rem - oi * p.Wo;
-        hb[i] = oi * p.sh + p.h0;
-        wb[i] = oj * p.sw + p.w0;
-        boff[i] = ((long)(b * p.Hi + hb[i]) * p.Wi + wb[i]) * p.ldx;
-    }
-    long woff[B_IT];
-    bool nvalid[B_IT];
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-        const int row = (tid >> 2) + i * (NT / 4);
-        const int n = tn * BN + row;
-        nvalid[i] = (row < BN) && (n < p.Cout);
-        woff[i] = (long)(nvalid[i] ? n : 0) * p.ldw;
+    for (int i = 0; i < IT; ++i) {
+        const int j = wave + 4 * i;
+        hb[i] = wb[i] = 0;
+        off0[i] = 0;
+        valid[i] = false;
+        if (j < G::NI_A) {
+            const int row = j * 16 + (lane >> 2);
+            const int m = tm * BM + row;
+            valid[i] = m < p.M;
+            const int mm = valid[i] ? m : 0;
+            const int b = mm / HoWo;
+            const int rem = mm - b * HoWo;
+            const int oi = rem / p.Wo;
+            const int oj = rem - oi * p.Wo;
+            hb[i] = oi * p.sh + p.h0;
+            wb[i] = oj * p.sw + p.w0;
+            off0[i] = ((long)(b * p.Hi + hb[i]) * p.Wi + wb[i]) * p.ldx;
+        } else if (j < G::NI) {
+            const int n = tn * BN + (j - G::NI_A) * 16 + (lane >> 2);
+            valid[i] = n < p.Cout;
+            off0[i] = (long)(valid[i] ? n : 0) * p.ldw;
+        }
     }
 
-    int kk = cj * EPC;  // flattened K index of this thread's chunk
+    int kk = cj * EPC;  // flattened K index of this lane's chunk
     int tap = kk / p.Cin;
     int c = kk - tap * p.Cin;
 
-    uint4 ra[A_IT], rb[B_IT];
-
-    // (macros, not lambdas: by-reference captures of ra/rb would pin them in scratch)
-#define VT_GLOAD()                                                                              \
+    // issue the IT DMA instructions of one K-step into ring slot `st`, then advance K
+#define VT_ISSUE_STAGE(st)                                                                      \
     do {                                                                                        \
         const bool kval = tap < p.ntaps;                                                        \
         const int4 te = sTap[kval ? tap : 0];                                                   \
-        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                      \
-            const bool v = kval && rvalid[i] && (unsigned)(hb[i] + te.x) < (unsigned)p.Hi &&    \
-                           (unsigned)(wb[i] + te.y) < (unsigned)p.Wi;                           \
-            ra[i] = ldg_pred(xg + (boff[i] + te.z + c), v);                                     \
+        _Pragma("unroll") for (int i = 0; i < IT; ++i) {                                        \
+            const int j = wave + 4 * i;                                                         \
+            /* A / B / dummy is known at compile time unless the boundary cuts a group of 4 */  \
+            const bool isA = (4 * i + 3 < G::NI_A) ? true : (4 * i >= G::NI_A ? false : j < G::NI_A); \
+            const bool isB = !isA && ((4 * i + 3 < G::NI) ? true : (4 * i >= G::NI ? false : j < G::NI)); \
+            const bool va = kval && valid[i] && (unsigned)(hb[i] + te.x) < (unsigned)p.Hi &&    \
+                            (unsigned)(wb[i] + te.y) < (unsigned)p.Wi;                          \
+            const unsigned long pa = (unsigned long)(xg + (off0[i] + te.z + c));                \
+            const unsigned long pb = (unsigned long)(wg + (off0[i] + kk));                      \
+            const unsigned long ps = isA ? (va ? pa : zero_src) : ((isB && kval && valid[i]) ? pb : zero_src); \
+            glds16((const void*)ps, ring_base + (unsigned)(((st)*SS + j * 64) * 16));           \
         }                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < B_IT; ++i)                                        \
-            rb[i] = ldg_pred(wg + (woff[i] + kk), kval && nvalid[i]);                           \
         kk += BK;                                                                               \
         c += BK;                                                                                \
         while (c >= p.Cin) {                                                                    \
             c -= p.Cin;                                                                         \
             ++tap;                                                                              \
-        }                                                                                       \
-    } while (0)
-#define VT_LDS_STORE(buf)                                                                       \
-    do {                                                                                        \
-        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                      \
-            const int row = (tid >> 2) + i * (NT / 4);                                          \
-            if (row < BM) sA[(buf)*BM * 4 + row * 4 + (cj ^ swz(row))] = ra[i];                 \
-        }                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < B_IT; ++i) {                                      \
-            const int row = (tid >> 2) + i * (NT / 4);                                          \
-            if (row < BN) sB[(buf)*BN * 4 + row * 4 + (cj ^ swz(row))] = rb[i];                 \
         }                                                                                       \
     } while (0)
 
@@ -203,16 +243,28 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const IgemmArgs p) {
     const int lane_off = (lane & 15) * 4 + ((lane >> 4) ^ swz(lane & 15));
     const int nk = (p.Ktot + BK - 1) / BK;
 
-    VT_GLOAD();
-    VT_LDS_STORE(0);
-    __syncthreads();
+    // prologue: PD stages in flight
+#pragma unroll
+    for (int s = 0; s < PD; ++s)
+        if (s < nk) VT_ISSUE_STAGE(s);
+
+    int cur = 0;       // ring slot of K-step ks
+    int nxt = PD % NS; // ring slot of K-step ks + PD
     for (int ks = 0; ks < nk; ++ks) {
-        const int cur = ks & 1;
-        const bool more = ks + 1 < nk;
-        if (more) VT_GLOAD();
+        // retire exactly the stage about to be read; younger stages stay in flight
+        const int younger = min(PD - 1, nk - 1 - ks);
+        if (younger >= 2)
+            vm_wait<2 * IT>();
+        else if (younger == 1)
+            vm_wait<IT>();
+        else
+            vm_wait<0>();
+        __builtin_amdgcn_s_barrier();  // every wave's DMA of this stage landed; slot `nxt` is free
+        asm volatile("" ::: "memory");  // the raw barrier does not order memory ops for the compiler
+        if (ks + PD < nk) VT_ISSUE_STAGE(nxt);
         {
-            const uint4* A = sA + cur * BM * 4 + wm * TM * 4 + lane_off;
-            const uint4* Bt = sB + cur * BN * 4 + wn * TN * 4 + lane_off;
+            const uint4* A = sStage + cur * SS + wm * TM * 4 + lane_off;
+            const uint4* Bt = sStage + cur * SS + BM * 4 + wn * TN * 4 + lane_off;
             uint4 af[FM], bf[FN];
 #pragma unroll
             for (int i = 0; i < FM; ++i) af[i] = A[i * 64];
@@ -223,14 +275,13 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const IgemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < FN; ++j) mma<T>(af[i], bf[j], acc[i][j]);
         }
-        if (more) VT_LDS_STORE(cur ^ 1);
-        __syncthreads();
+        cur = (cur + 1 == NS) ? 0 : cur + 1;
+        nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
     }
+#undef VT_ISSUE_STAGE
+    __syncthreads();  // all waves done reading the ring (no DMA is outstanding: last wait was vmcnt(0))
 
-#undef VT_GLOAD
-#undef VT_LDS_STORE
     // ---- epilogue ------------------------------------------------------------
-    // (the trailing barrier of the loop guarantees every wave is done with staging)
     const bool affine = p.flags & VT_CONV_AFFINE;
     const bool relu = p.flags & VT_CONV_RELU;
     const bool stats = p.flags & VT_CONV_STATS;
@@ -315,22 +366,33 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(const IgemmArgs p) {
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int PD>
 int launch(IgemmArgs& a, hipStream_t st) {
+    using G = Geom<BM, BN, PD>;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.Cout + BN - 1) / BN;
     a.chunk = (a.tiles_m + 7) / 8;
-    constexpr int stage = 2 * (BM + BN) * 64;
     constexpr int outb = BM * BN * (int)sizeof(T);
-    constexpr int smem = kHdrBytes + (stage > outb ? stage : outb);
-    static_assert(smem <= 64 * 1024, "tile needs more than the default 64 KiB of LDS");
+    constexpr int smem = kHdrBytes + (G::STAGE_BYTES > outb ? G::STAGE_BYTES : outb);
+    static_assert(smem <= 160 * 1024, "tile exceeds the 160 KiB LDS of a gfx950 CU");
     const long blocks = (long)8 * a.chunk * a.tiles_n;
     if (blocks > 0x7fffffffL) {
         vt_set_error("vt_conv_igemm: grid too large (%ld blocks)", blocks);
         return VT_ERR_UNSUPPORTED;
     }
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN>), dim3((unsigned)blocks), dim3(WM * WN * 64), smem,
-                       st, a);
+    auto kern = igemm_kernel<T, BM, BN, WM, WN, PD>;
+    if (smem > 64 * 1024) {
+        static bool raised = false;  // per instantiation
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) {
+                vt_set_error("vt_conv_igemm: cannot raise dynamic LDS to %d: %s", smem, hipGetErrorString(e));
+                return VT_ERR_HIP;
+            }
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, st, a);
     VT_CHECK_LAUNCH("vt_conv_igemm");
     return VT_OK;
 }
@@ -397,10 +459,10 @@ extern "C" int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w
 
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == VT_BF16) {
-        if (d->Cout > 64) return launch<bf16_t, 128, 128, 2, 2>(a, st);
-        if (d->Cout > 32) return launch<bf16_t, 128, 64, 2, 2>(a, st);
-        return launch<bf16_t, 256, 32, 4, 1>(a, st);
+        if (d->Cout > 64) return launch<bf16_t, 128, 128, 2, 2, 2>(a, st);
+        if (d->Cout > 32) return launch<bf16_t, 128, 64, 2, 2, 2>(a, st);
+        return launch<bf16_t, 256, 32, 4, 1, 2>(a, st);
     }
-    if (d->Cout > 32) return launch<float, 128, 64, 2, 2>(a, st);
-    return launch<float, 128, 32, 4, 1>(a, st);
+    if (d->Cout > 32) return launch<float, 128, 64, 2, 2, 2>(a, st);
+    return launch<float, 128, 32, 4, 1, 2>(a, st);
 }

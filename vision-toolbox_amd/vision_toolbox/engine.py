@@ -229,7 +229,7 @@ class Builder:
         self.pgrad_bytes = 0
         self.tag = 0
         self.n_units = 0
-        self._dgrad_pack_cache: dict = {}
+        self.debug_refs: dict[str, TRef] = {}
 
     # -- memory -----------------------------------------------------------------
     def alloc(self, nbytes: int, name: str = "") -> Buf:
@@ -239,7 +239,18 @@ class Builder:
 
     def act(self, B, H, W, C, name="", needs_grad=True) -> TRef:
         buf = self.alloc(B * H * W * C * _ESIZE[self.dtype], name)
-        return TRef(buf, B, H, W, C, C, 0, self.dtype, needs_grad)
+        t = TRef(buf, B, H, W, C, C, 0, self.dtype, needs_grad)
+        if name:
+            self.debug_refs[name] = t  # name -> activation, for tools/debug_*.py
+        return t
+
+    def debug_grad_ref(self, name: str) -> Optional[TRef]:
+        """the gradient buffer mirroring activation `name` (None if never allocated)."""
+        t = self.debug_refs.get(name)
+        gs = self.gstate.get(id(t.buf)) if t is not None else None
+        if gs is None or gs.gbuf is None:
+            return None
+        return TRef(gs.gbuf, t.B, t.H, t.W, t.C, t.ld, t.coff, t.dtype)
 
     def f32(self, n: int, name="") -> Buf:
         return self.alloc(n * 4, name)
@@ -770,8 +781,13 @@ def ops_array(ops: list) -> "C.Array":
 
 def tref_to_tensor(arena: torch.Tensor, t: TRef) -> torch.Tensor:
     """view of an arena activation as a logical-NCHW (channels_last strided) torch tensor."""
+    # Built with set_() on the arena's storage rather than by slicing/viewing: the result shares
+    # (and keeps alive) the arena memory but is NOT an autograd/tracer "view" of another tensor,
+    # which is what autograd.Function outputs and torch.jit.trace need.
     td = _TORCH_DTYPE[t.dtype]
-    n = t.M * t.ld
-    flat = arena[t.buf.offset : t.buf.offset + n * t.esize].view(td)
-    v = flat.view(t.B, t.H, t.W, t.ld)[..., t.coff : t.coff + t.C]
-    return v.permute(0, 3, 1, 2)
+    byte_off = arena.storage_offset() + t.buf.offset + t.coff * t.esize
+    assert byte_off % t.esize == 0
+    out = torch.empty(0, dtype=td, device=arena.device)
+    out.set_(arena.untyped_storage(), byte_off // t.esize, (t.B, t.C, t.H, t.W),
+             (t.H * t.W * t.ld, 1, t.W * t.ld, t.ld))
+    return out

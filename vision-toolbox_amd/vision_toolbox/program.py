@@ -77,6 +77,7 @@ class Program:
         self.param_grad_off = dict(b.param_grad_off)
         self.input_grad = getattr(b, "input_grad", None)
         self.n_units = b.n_units
+        self.builder = b  # kept for tools/debug_*.py (name -> activation / gradient buffers)
         self.kind_histogram = {}
         for op in fwd + bwd:
             k = N.OP_NAMES.get(op.kind, str(op.kind))
@@ -115,13 +116,16 @@ class BackboneFn(torch.autograd.Function):
             st, outs = runner._run_forward(prog, x)
         ctx.runner, ctx.st = runner, st
         ctx.x_requires_grad = x.requires_grad
+        ctx.n_params = len(params)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gouts):
+        if ctx.st.prog.n_bwd == 0:
+            raise RuntimeError("this forward was compiled without a backward list (traced / no-grad call)")
         dx, pgrads = ctx.runner._run_backward(ctx.st, gouts, ctx.x_requires_grad)
         ctx.st = None
-        return (None, None, dx, *pgrads)
+        return (None, None, dx, *pgrads[: ctx.n_params])
 
 
 class BackboneRunner:
@@ -172,7 +176,11 @@ class BackboneRunner:
             params = self.store.params
             need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
             prog = self.program(x, dtype, all_maps, need_grad)
-        if need_grad or tracing:  # under jit.trace the call must be recorded as one op
+        if tracing:
+            # recorded as ONE opaque op of x; the parameters are read from the module's flat
+            # store at run time, so the tracer never has to resolve them
+            outs = BackboneFn.apply(self, prog, x)
+        elif need_grad:
             outs = BackboneFn.apply(self, prog, x, *params)
         else:
             _, outs = self._run_forward(prog, x)
