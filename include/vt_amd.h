@@ -230,8 +230,15 @@ enum vt_op_kind {
     VT_OP_COPY2D,
     VT_OP_NCHW_TO_NHWC,
     VT_OP_NHWC_TO_NCHW,
+    VT_OP_FORK, /* side stream waits for everything enqueued on the main stream so far */
+    VT_OP_JOIN, /* main stream waits for everything enqueued on the side stream so far */
     VT_OP_KIND_END
 };
+
+/* OR-ed into vt_op.kind: enqueue this op on the side stream.  Filter gradients depend only
+ * on a layer's input and dz, nothing downstream waits for them before the optimiser, so they
+ * run beside the (HBM-bound) rest of backward instead of in line with it. */
+#define VT_OP_SIDE_STREAM 0x10000
 
 typedef struct vt_ptr {
     int32_t base; /* index into the bases[] passed at run time; -1 = NULL */
@@ -250,8 +257,13 @@ typedef struct vt_op {
 /* run ops[0..n) in order on `stream`; argument order per kind is documented in
  * vt_runtime.hip next to each case. */
 int vt_run_ops(const vt_op* ops, int32_t n, void* const* bases, int32_t nbases, void* stream);
+/* same, with a side stream for ops flagged VT_OP_SIDE_STREAM (FORK / JOIN order the two).
+ * side == NULL or side == stream runs everything in line. */
+int vt_run_ops_streams(const vt_op* ops, int32_t n, void* const* bases, int32_t nbases, void* stream,
+                       void* side);
 
-/* hipGraph capture of an op list: capture once, replay with one launch. */
+/* hipGraph capture of an op list (side-stream ops become parallel graph branches): capture
+ * once, replay with one launch. */
 int vt_graph_create(const vt_op* ops, int32_t n, void* const* bases, int32_t nbases,
                     void** graph_out);
 int vt_graph_launch(void* graph, void* stream);

@@ -11,6 +11,7 @@
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kUnroll = 4;  // rows in flight per thread in the streaming kernels
 
 // thread -> (channel chunk column, row lane) for an [M][C] matrix of 16-byte chunks
 struct RowMap {
@@ -105,23 +106,39 @@ bn_act_apply_kernel(const T* __restrict__ z, int ldz, const float* __restrict__ 
             sc[e] = scale ? scale[col * EPC + e] : 1.f;
             sf[e] = shift ? shift[col * EPC + e] : 0.f;
         }
-        for (int it = 0; it < rm.iters; ++it) {
-            const long row = row0 + (long)it * rm.RT;
-            if (row >= M) break;
-            float v[EPC];
-            VecIO<T>::unpack(ld16(z + row * ldz + col * EPC), v);
+        // kUnroll rows per trip: all loads are issued before the first use (bytes in flight)
+        for (int it = 0; it < rm.iters; it += kUnroll) {
+            uint4 vz[kUnroll], vr[kUnroll];
+            bool ok[kUnroll];
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                v[e] = fmaf(v[e], sc[e], sf[e]);
-                if (relu) v[e] = fmaxf(v[e], 0.f);
+            for (int u = 0; u < kUnroll; ++u) {
+                const long row = row0 + (long)(it + u) * rm.RT;
+                ok[u] = (it + u < rm.iters) && row < M;
+                vz[u] = vr[u] = make_uint4(0, 0, 0, 0);
+                if (ok[u]) {
+                    vz[u] = ld16(z + row * ldz + col * EPC);
+                    if (res) vr[u] = ld16(res + row * ldr + col * EPC);
+                }
             }
-            if (res) {
-                float rr[EPC];
-                VecIO<T>::unpack(ld16(res + row * ldr + col * EPC), rr);
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) v[e] += rr[e];
+            for (int u = 0; u < kUnroll; ++u) {
+                if (!ok[u]) continue;
+                const long row = row0 + (long)(it + u) * rm.RT;
+                float v[EPC];
+                VecIO<T>::unpack(vz[u], v);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    v[e] = fmaf(v[e], sc[e], sf[e]);
+                    if (relu) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (res) {
+                    float rr[EPC];
+                    VecIO<T>::unpack(vr[u], rr);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[e] += rr[e];
+                }
+                st16(y + row * ldy + col * EPC, VecIO<T>::pack(v));
             }
-            st16(y + row * ldy + col * EPC, VecIO<T>::pack(v));
         }
     }
 }
@@ -157,17 +174,28 @@ bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z
                 s1[e] = 0.f;
                 s2[e] = 0.f;
             }
-            for (int it = 0; it < rm.iters; ++it) {
-                const long row = row0 + (long)it * rm.RT;
-                if (row >= M) break;
-                float g[EPC], zz[EPC];
-                VecIO<T>::unpack(ld16(dy + row * lddy + col * EPC), g);
-                VecIO<T>::unpack(ld16(z + row * ldz + col * EPC), zz);
+            for (int it = 0; it < rm.iters; it += kUnroll) {
+                uint4 vg[kUnroll], vz[kUnroll];
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) {
-                    const float gg = (!relu || fmaf(zz[e], sc[e], sf[e]) > 0.f) ? g[e] : 0.f;
-                    s1[e] += gg;
-                    s2[e] += gg * ((zz[e] - mu[e]) * is[e]);
+                for (int u = 0; u < kUnroll; ++u) {
+                    const long row = row0 + (long)(it + u) * rm.RT;
+                    vg[u] = vz[u] = make_uint4(0, 0, 0, 0);  // zero dy contributes nothing
+                    if ((it + u < rm.iters) && row < M) {
+                        vg[u] = ld16(dy + row * lddy + col * EPC);
+                        vz[u] = ld16(z + row * ldz + col * EPC);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    float g[EPC], zz[EPC];
+                    VecIO<T>::unpack(vg[u], g);
+                    VecIO<T>::unpack(vz[u], zz);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const float gg = (!relu || fmaf(zz[e], sc[e], sf[e]) > 0.f) ? g[e] : 0.f;
+                        s1[e] += gg;
+                        s2[e] += gg * ((zz[e] - mu[e]) * is[e]);
+                    }
                 }
             }
             const int lc = (t % rm.CT) * EPC;
@@ -236,18 +264,33 @@ bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z,
             cb[e] = coef[C + c];
             cd[e] = coef[2 * C + c];
         }
-        for (int it = 0; it < rm.iters; ++it) {
-            const long row = row0 + (long)it * rm.RT;
-            if (row >= M) break;
-            float g[EPC], zz[EPC];
-            VecIO<T>::unpack(ld16(dy + row * lddy + col * EPC), g);
-            VecIO<T>::unpack(ld16(z + row * ldz + col * EPC), zz);
+        for (int it = 0; it < rm.iters; it += kUnroll) {
+            uint4 vg[kUnroll], vz[kUnroll];
+            bool ok[kUnroll];
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                const float gg = (!relu || fmaf(zz[e], sc[e], sf[e]) > 0.f) ? g[e] : 0.f;
-                g[e] = fmaf(ca[e], gg, fmaf(-cb[e], zz[e], cd[e]));
+            for (int u = 0; u < kUnroll; ++u) {
+                const long row = row0 + (long)(it + u) * rm.RT;
+                ok[u] = (it + u < rm.iters) && row < M;
+                vg[u] = vz[u] = make_uint4(0, 0, 0, 0);
+                if (ok[u]) {
+                    vg[u] = ld16(dy + row * lddy + col * EPC);
+                    vz[u] = ld16(z + row * ldz + col * EPC);
+                }
             }
-            st16(dz + row * lddz + col * EPC, VecIO<T>::pack(g));
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                if (!ok[u]) continue;
+                const long row = row0 + (long)(it + u) * rm.RT;
+                float g[EPC], zz[EPC];
+                VecIO<T>::unpack(vg[u], g);
+                VecIO<T>::unpack(vz[u], zz);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float gg = (!relu || fmaf(zz[e], sc[e], sf[e]) > 0.f) ? g[e] : 0.f;
+                    g[e] = fmaf(ca[e], gg, fmaf(-cb[e], zz[e], cd[e]));
+                }
+                st16(dz + row * lddz + col * EPC, VecIO<T>::pack(g));
+            }
         }
     }
 }

@@ -9,6 +9,7 @@
 #include <stdarg.h>
 
 #include <atomic>
+#include <vector>
 
 #include "vt_common.h"
 
@@ -142,18 +143,63 @@ int vt_memset(void* ptr, int value, uint64_t bytes, void* stream) {
 }
 
 int vt_run_ops(const vt_op* ops, int32_t n, void* const* bases, int32_t nbases, void* stream) {
+    return vt_run_ops_streams(ops, n, bases, nbases, stream, nullptr);
+}
+
+// order stream `waiter` behind everything enqueued on `signaller` so far
+static int stream_wait(hipStream_t waiter, hipStream_t signaller, std::vector<hipEvent_t>& bag) {
+    hipEvent_t ev;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e == hipSuccess) {
+        bag.push_back(ev);  // released by the caller once the whole list is enqueued / captured
+        e = hipEventRecord(ev, signaller);
+    }
+    if (e == hipSuccess) e = hipStreamWaitEvent(waiter, ev, 0);
+    if (e != hipSuccess) {
+        vt_set_error("stream fork/join: %s", hipGetErrorString(e));
+        return VT_ERR_HIP;
+    }
+    return VT_OK;
+}
+
+static int run_ops_impl(const vt_op* ops, int32_t n, void* const* bases, int32_t nbases, void* stream,
+                        void* side, std::vector<hipEvent_t>& bag) {
     VT_REQUIRE(ops && n >= 0 && nbases >= 0 && nbases <= VT_MAX_BASES && (bases || nbases == 0),
                VT_ERR_INVALID, "vt_run_ops: bad argument");
+    const bool two = side != nullptr && side != stream;
+    bool side_dirty = false;  // side stream has work the main stream has not been ordered behind
     for (int i = 0; i < n; ++i) {
-        const int rc = run_one(ops[i], bases, nbases, stream);
+        vt_op op = ops[i];
+        const bool on_side = (op.kind & VT_OP_SIDE_STREAM) != 0;
+        op.kind &= ~VT_OP_SIDE_STREAM;
+        int rc = VT_OK;
+        if (op.kind == VT_OP_FORK) {
+            if (two) rc = stream_wait((hipStream_t)side, (hipStream_t)stream, bag);
+        } else if (op.kind == VT_OP_JOIN) {
+            if (two && side_dirty) rc = stream_wait((hipStream_t)stream, (hipStream_t)side, bag);
+            side_dirty = false;
+        } else {
+            rc = run_one(op, bases, nbases, (two && on_side) ? side : stream);
+            if (two && on_side) side_dirty = true;
+        }
         if (rc != VT_OK) {
             char msg[400];
             snprintf(msg, sizeof(msg), "%s", g_err);
-            vt_set_error("op %d (kind %d, tag %d): %s", i, ops[i].kind, ops[i].tag, msg);
+            vt_set_error("op %d (kind %d, tag %d): %s", i, op.kind, op.tag, msg);
             return rc;
         }
     }
+    // never return with unjoined side work: the caller only knows about `stream`
+    if (two && side_dirty) return stream_wait((hipStream_t)stream, (hipStream_t)side, bag);
     return VT_OK;
+}
+
+int vt_run_ops_streams(const vt_op* ops, int32_t n, void* const* bases, int32_t nbases, void* stream,
+                       void* side) {
+    std::vector<hipEvent_t> bag;
+    const int rc = run_ops_impl(ops, n, bases, nbases, stream, side, bag);
+    for (hipEvent_t ev : bag) (void)hipEventDestroy(ev);  // the runtime defers the release to completion
+    return rc;
 }
 
 int vt_graph_create(const vt_op* ops, int32_t n, void* const* bases, int32_t nbases, void** graph_out) {
@@ -164,16 +210,25 @@ int vt_graph_create(const vt_op* ops, int32_t n, void* const* bases, int32_t nba
         vt_set_error("vt_graph_create: stream: %s", hipGetErrorString(e));
         return VT_ERR_HIP;
     }
+    // a second stream joins the capture at the first FORK; its ops become parallel branches
+    bool wants_side = false;
+    for (int i = 0; i < n; ++i) wants_side |= (ops[i].kind & VT_OP_SIDE_STREAM) != 0;
+    hipStream_t ss = nullptr;
+    if (wants_side && hipStreamCreateWithFlags(&ss, hipStreamNonBlocking) != hipSuccess) ss = nullptr;
     e = hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed);
     if (e != hipSuccess) {
         (void)hipStreamDestroy(cs);
+        if (ss) (void)hipStreamDestroy(ss);
         vt_set_error("vt_graph_create: begin capture: %s", hipGetErrorString(e));
         return VT_ERR_HIP;
     }
-    const int rc = vt_run_ops(ops, n, bases, nbases, cs);
+    std::vector<hipEvent_t> bag;
+    const int rc = run_ops_impl(ops, n, bases, nbases, cs, ss, bag);
     hipGraph_t g = nullptr;
     e = hipStreamEndCapture(cs, &g);
+    for (hipEvent_t ev : bag) (void)hipEventDestroy(ev);  // only after the capture has ended
     (void)hipStreamDestroy(cs);
+    if (ss) (void)hipStreamDestroy(ss);
     if (rc != VT_OK) {
         if (g) (void)hipGraphDestroy(g);
         return rc;

@@ -7,15 +7,24 @@
 // (reference vision_toolbox/components.py:26-35) with respect to its weight.
 //
 // GEMM view: rows = Cout, cols = ntaps*Cin, contraction = pixels.  NHWC keeps
-// channels contiguous, so BOTH operands arrive "K-strided"; they are staged
-// pixel-major in LDS exactly as they sit in HBM (whole 256/512-byte rows,
-// fully coalesced) and the MFMA fragments are formed by the hardware transpose
-// read ds_read_b64_tr_b16 (bf16) or by plain ds_read_b32 (f32).  Rows are
-// padded by 16 elements so both read patterns are bank-conflict free.
+// channels contiguous, so BOTH operands arrive "K-strided" for MFMA; they are
+// staged pixel-major in LDS exactly as they sit in HBM -- whole 256-byte (bf16) /
+// 512-byte (f32) channel rows, i.e. full cache lines -- by an LDS-DMA ring
+// (global_load_lds_dwordx4, no VGPR round trip, PD stages in flight across the
+// single barrier per step, counted s_waitcnt vmcnt; same scheme as vt_igemm.hip),
+// and the MFMA fragments are formed by the hardware transposing read
+// ds_read_b64_tr_b16 (bf16) or by plain ds_read_b32 (f32).
+// An LDS-DMA writes 1 KiB contiguously, so rows cannot be padded; bank conflicts are
+// removed by XOR-swizzling the 16-byte chunk index with the row number through the
+// SOURCE address: chunk ^= 2*(row&7) for bf16 (the 8 rows a half-wave's transposing
+// read touches land on 8 distinct 32-byte bank groups), chunk ^= 4*(row&1) for f32.
+// Out-of-image taps / tails read from a 16-byte zero page.
 //
 // The pixel range is split over blockIdx.y; partial tiles are combined with
 // f32 global atomics straight into the weight's .grad storage (which is
 // [Cout][taps][Cin], the channels_last image of the OIHW gradient).
+#include <stdlib.h>
+
 #include "vt_common.h"
 
 namespace {
@@ -30,24 +39,55 @@ struct WgradArgs {
     int8_t dwv[VT_MAX_TAPS];
 };
 
+__device__ __attribute__((aligned(16))) unsigned int vt_wg_zero16[4];
+
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-template <typename T>
-__global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
+__device__ __forceinline__ void glds16(unsigned long gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_base)
+        : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr int kTapHdr = VT_MAX_TAPS * 8;
+
+// G groups of 4 waves share one output tile: group q consumes pixel steps q, q+G, q+2G, ...
+// through its own LDS-DMA ring, and the G partial tiles are summed in LDS before ONE set of
+// global atomics leaves the workgroup -- the atomic traffic of a launch is
+// (#workgroups x 64 KiB), so more waves per workgroup means fewer atomic bytes per FLOP.
+template <typename T, int G, int kPD>
+__global__ void __launch_bounds__(256 * G) wgrad_kernel(const WgradArgs p) {
+    constexpr int kNS = kPD + 1;      // ring slots per group
     constexpr int EPC = 16 / sizeof(T);
-    constexpr int PK = 4 * EPC;         // pixels per step: 32 bf16 / 16 f32
-    constexpr int LDT = 128 + 16;       // padded LDS row, elements
-    constexpr int CPRW = 128 / EPC;     // 16-byte chunks per row
-    constexpr int RPP = 256 / CPRW;     // rows staged per pass
-    constexpr int NPASS = PK / RPP;     // == 2
-    constexpr int TILE = PK * LDT;      // elements per tile
-    static_assert(NPASS * RPP == PK, "staging shape");
+    constexpr int PK = 4 * EPC;       // pixels per step: 32 bf16 / 16 f32
+    constexpr int ROW = 128;          // channels per tile row (256 B bf16 / 512 B f32)
+    constexpr int CPRW = ROW / EPC;   // 16-byte chunks per row: 16 / 32
+    constexpr int RPI = 64 / CPRW;    // rows per DMA instruction: 4 / 2
+    constexpr int TILE = PK * ROW;    // elements per operand tile (8 KiB)
+    constexpr int STAGE = 2 * TILE;   // dz tile then x tile
+    constexpr int IT = 4;             // DMA instructions per wave per stage (2 dz + 2 x)
+    static_assert(PK / RPI == 8, "8 DMA instructions per operand tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int2* sTap = (int2*)smem;                          // 36 * 8 B
-    T* sT = (T*)(smem + VT_MAX_TAPS * 8);              // [2 buf][2 (dz,x)][TILE]
+    int2* sTap = (int2*)smem;
+    T* sRing = (T*)(smem + kTapHdr);  // [kNS][STAGE]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int gwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = gwave >> 2;       // wave group (pixel-step phase)
+    const int wave = gwave & 3;       // wave inside the group
     const int wm = wave >> 1, wn = wave & 1;
     const int tile_n = blockIdx.x % p.tiles_n, tile_k = blockIdx.x / p.tiles_n;
     const int n0 = tile_n * 128, k0 = tile_k * 128;
@@ -55,27 +95,43 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
     const int m_end = min(p.M, m_begin + p.chunk);
     if (m_begin >= m_end) return;
 
-    if (tid < p.ntaps) sTap[tid] = make_int2(p.dh[tid], p.dwv[tid]);
+#pragma unroll
+    for (int t = 0; t < VT_MAX_TAPS; ++t)
+        if (t < p.ntaps && tid == t) sTap[t] = make_int2(p.dh[t], p.dwv[t]);
     __syncthreads();
 
     const T* __restrict__ xg = (const T*)p.x;
     const T* __restrict__ zg = (const T*)p.dz;
+    const unsigned long zero_src = (unsigned long)(const void*)vt_wg_zero16;
+    const unsigned ring_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)sRing +
+                               (unsigned)(grp * kNS * STAGE * (int)sizeof(T));
 
-    // ---- staging geometry ----------------------------------------------------
-    const int col = tid % CPRW;
-    const int nn = n0 + col * EPC;
+    // ---- per-lane DMA geometry ------------------------------------------------------
+    // operand tile: instruction j' (0..7) fills 16-byte slots [64j', 64j'+64) = rows
+    // RPI*j' .. ; lane l owns row RPI*j' + l/CPRW, position l%CPRW, and fetches the chunk
+    // (l%CPRW) ^ swz(row).  Wave w issues j' = w and w+4 for dz, then the same for x, so the
+    // row parity that enters swz() is the same for all of a lane's loads.
+    const int rloc = lane / CPRW;  // row inside the instruction
+    int swz;
+    if constexpr (sizeof(T) == 2)
+        swz = 2 * ((RPI * wave + rloc) & 7);  // (4*(w+4) + r)&7 == (4w + r)&7
+    else
+        swz = 4 * (rloc & 1);                 // (2*j' + r)&1 == r&1
+    const int col_e = ((lane % CPRW) ^ swz) * EPC;  // element column this lane fetches
+
+    const int nn = n0 + col_e;
     const bool nvalid = nn < p.Cout;
-    const int kc = k0 + col * EPC;
+    const int kc = k0 + col_e;
     const bool kvalid = kc < p.Ktot;
     const int tap = kvalid ? kc / p.Cin : 0;
     const int cc = kc - tap * p.Cin;
     const int2 dd = sTap[tap];
 
-    int mrow[NPASS], pb[NPASS], pi[NPASS], pj[NPASS];
+    int mrow[2], pb[2], pi[2], pj[2];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
-    for (int i = 0; i < NPASS; ++i) {
-        const int m = m_begin + tid / CPRW + i * RPP;
+    for (int i = 0; i < 2; ++i) {
+        const int m = m_begin + grp * PK + RPI * (wave + 4 * i) + rloc;
         mrow[i] = m;
         const int mm = min(m, p.M - 1);
         pb[i] = mm / HoWo;
@@ -84,42 +140,36 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
         pj[i] = rem - pi[i] * p.Wo;
     }
 
-    uint4 rz[NPASS], rx[NPASS];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    auto gload = [&]() {
-#pragma unroll
-        for (int i = 0; i < NPASS; ++i) {
-            const bool mv = mrow[i] < m_end;
-            rz[i] = zero4;
-            rx[i] = zero4;
-            if (mv && nvalid) rz[i] = *(const uint4*)(zg + ((long)mrow[i] * p.ldy + nn));
-            const int hi = pi[i] * p.sh + p.h0 + dd.x;
-            const int wi = pj[i] * p.sw + p.w0 + dd.y;
-            if (mv && kvalid && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi)
-                rx[i] = *(const uint4*)(xg + (((long)(pb[i] * p.Hi + hi) * p.Wi + wi) * p.ldx + cc));
-            // advance this row by PK pixels
-            mrow[i] += PK;
-            pj[i] += PK;
-            while (pj[i] >= p.Wo) {
-                pj[i] -= p.Wo;
-                pi[i] += 1;
-            }
-            while (pi[i] >= p.Ho) {
-                pi[i] -= p.Ho;
-                pb[i] += 1;
-            }
-        }
-    };
-    auto lds_store = [&](int buf) {
-        T* tz = sT + (buf * 2 + 0) * TILE;
-        T* tx = sT + (buf * 2 + 1) * TILE;
-#pragma unroll
-        for (int i = 0; i < NPASS; ++i) {
-            const int r = tid / CPRW + i * RPP;
-            *(uint4*)(tz + r * LDT + col * EPC) = rz[i];
-            *(uint4*)(tx + r * LDT + col * EPC) = rx[i];
-        }
-    };
+#define VT_WG_ISSUE(st)                                                                           \
+    do {                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                           \
+            const int jj = wave + 4 * i;                                                          \
+            const bool mv = mrow[i] < m_end;                                                      \
+            const unsigned long pz = (unsigned long)(zg + ((long)mrow[i] * p.ldy + nn));          \
+            glds16((mv && nvalid) ? pz : zero_src, ring_base + (unsigned)((((st)*STAGE) * (int)sizeof(T)) + jj * 1024)); \
+        }                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                           \
+            const int jj = wave + 4 * i;                                                          \
+            const int hi = pi[i] * p.sh + p.h0 + dd.x;                                            \
+            const int wi = pj[i] * p.sw + p.w0 + dd.y;                                            \
+            const bool xv = mrow[i] < m_end && kvalid && (unsigned)hi < (unsigned)p.Hi &&         \
+                            (unsigned)wi < (unsigned)p.Wi;                                        \
+            const unsigned long px =                                                              \
+                (unsigned long)(xg + (((long)(pb[i] * p.Hi + hi) * p.Wi + wi) * p.ldx + cc));      \
+            glds16(xv ? px : zero_src,                                                            \
+                   ring_base + (unsigned)((((st)*STAGE + TILE) * (int)sizeof(T)) + jj * 1024));    \
+            mrow[i] += PK * G;                                                                    \
+            pj[i] += PK * G;                                                                      \
+            while (pj[i] >= p.Wo) {                                                               \
+                pj[i] -= p.Wo;                                                                    \
+                pi[i] += 1;                                                                       \
+            }                                                                                     \
+            while (pi[i] >= p.Ho) {                                                               \
+                pi[i] -= p.Ho;                                                                    \
+                pb[i] += 1;                                                                       \
+            }                                                                                     \
+        }                                                                                         \
+    } while (0)
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -128,33 +178,50 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int g = lane >> 4, u = lane & 15;
-    const int nsteps = (m_end - m_begin + PK - 1) / PK;
+    // every group runs the same number of iterations (the barrier is workgroup wide); steps
+    // past the end of the range stage zeros
+    const int nsteps = ((m_end - m_begin + PK - 1) / PK + G - 1) / G;
 
-    gload();
-    lds_store(0);
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kPD; ++s)
+        if (s < nsteps) VT_WG_ISSUE(s);
+
+    int cur = 0, nxt = kPD % kNS;
     for (int s = 0; s < nsteps; ++s) {
-        const int cur = s & 1;
-        const bool more = s + 1 < nsteps;
-        if (more) gload();
-        const T* tz = sT + (cur * 2 + 0) * TILE + wm * 64;
-        const T* tx = sT + (cur * 2 + 1) * TILE + wn * 64;
+        const int younger = min(kPD - 1, nsteps - 1 - s);
+        if (younger >= 1)
+            vm_wait<IT>();
+        else
+            vm_wait<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + kPD < nsteps) VT_WG_ISSUE(nxt);
+
+        const T* tz = sRing + (grp * kNS + cur) * STAGE;
+        const T* tx = tz + TILE;
         if constexpr (sizeof(T) == 2) {
-            // lane 4q+pp of a 16-lane group addresses row q, columns 4pp..4pp+3 of a
-            // 4 x 16 block; it receives column u for the block's 4 rows (pixels).
+            // lane 4q+pp of a 16-lane group addresses row q, columns 4pp..4pp+3 of a 4 x 16
+            // block and receives column u for the block's 4 rows (pixels):
+            // fragment element j<4 <-> pixel 4g+j, j>=4 <-> pixel 16+4g+(j-4) for BOTH operands.
             const int q = u >> 2, pp = u & 3;
-            const int ro = (4 * g + q) * LDT + 4 * pp;
+            const int row = 4 * g + q;
+            const int sw2 = 2 * (row & 7);  // == 2*((16+row)&7)
+            const int sub = 4 * (pp & 1);   // element offset inside the 16-byte chunk
             bf16x8 af[4], bf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tz + ro + i * 16));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tz + ro + 16 * LDT + i * 16));
+                const int ch = ((wm * 64 + i * 16) >> 3) + (pp >> 1);
+                const T* a0 = tz + row * ROW + ((ch ^ sw2) << 3) + sub;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 16 * ROW));
                 af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tx + ro + j * 16));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tx + ro + 16 * LDT + j * 16));
+                const int ch = ((wn * 64 + j * 16) >> 3) + (pp >> 1);
+                const T* b0 = tx + row * ROW + ((ch ^ sw2) << 3) + sub;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)b0);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(b0 + 16 * ROW));
                 bf[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
 #pragma unroll
@@ -165,12 +232,19 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
         } else {
 #pragma unroll
             for (int ss = 0; ss < 4; ++ss) {
-                const int ro = (4 * ss + g) * LDT + u;
+                const int row = 4 * ss + g;
+                const int sw4 = 4 * (row & 1);
                 float af[4], bf[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) af[i] = (float)tz[ro + i * 16];
+                for (int i = 0; i < 4; ++i) {
+                    const int ch = ((wm * 64 + i * 16 + u) >> 2) ^ sw4;
+                    af[i] = (float)tz[row * ROW + (ch << 2) + (u & 3)];
+                }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bf[j] = (float)tx[ro + j * 16];
+                for (int j = 0; j < 4; ++j) {
+                    const int ch = ((wn * 64 + j * 16 + u) >> 2) ^ sw4;
+                    bf[j] = (float)tx[row * ROW + (ch << 2) + (u & 3)];
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -178,22 +252,48 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (more) lds_store(cur ^ 1);
-        __syncthreads();
+        cur = (cur + 1 == kNS) ? 0 : cur + 1;
+        nxt = (nxt + 1 == kNS) ? 0 : nxt + 1;
     }
+#undef VT_WG_ISSUE
 
-    // ---- combine: f32 atomics into dw[n][k] -----------------------------------
+    // ---- combine -------------------------------------------------------------------
+    // partial tiles of the G groups are summed into an LDS image [128 n][128 k] (f32, the
+    // ring is dead by now), then every wave issues row-contiguous 256-byte atomics.
+    __syncthreads();
+    float* sAcc = (float*)(smem + kTapHdr);
+    constexpr int HALVES = (G == 1) ? 2 : 1;  // a 4-wave workgroup only owns 48 KiB: two passes of 64 rows
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int h = 0; h < HALVES; ++h) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = k0 + wn * 64 + j * 16 + u;
+        for (int q = 0; q < G; ++q) {
+            if (grp == q && (HALVES == 1 || wm == h)) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wm * 64 + i * 16 + 4 * g + r;
-                if (n < p.Cout && k < p.Ktot) atomicAdd(p.dw + ((long)n * p.ldgw + k), acc[i][j][r]);
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int nrow = (HALVES == 1 ? wm * 64 : 0) + i * 16 + 4 * g + r;
+                            const int kcol = (wn * 64 + j * 16 + u) ^ (g << 4);  // spread the 4 rows of a wave-instr
+                            float* dst = sAcc + nrow * 128 + kcol;
+                            if (q == 0)
+                                *dst = acc[i][j][r];
+                            else
+                                *dst += acc[i][j][r];
+                        }
             }
+            __syncthreads();
         }
+        constexpr int ROWS = 128 / HALVES;
+        for (int idx = tid; idx < ROWS * 128; idx += 256 * G) {
+            const int nrow = idx >> 7, kcol = idx & 127;
+            const int n = n0 + h * ROWS + nrow, k = k0 + kcol;
+            const int gq = ((nrow & 15) >> 2);  // the row's g at write time
+            const float v = sAcc[nrow * 128 + (kcol ^ (gq << 4))];
+            if (n < p.Cout && k < p.Ktot) atomicAdd(p.dw + ((long)n * p.ldgw + k), v);
+        }
+        if (HALVES > 1) __syncthreads();
     }
 }
 
@@ -234,25 +334,61 @@ extern "C" int vt_conv_wgrad(const vt_conv_desc* d, const void* x, const void* d
     memcpy(a.dh, d->dh, VT_MAX_TAPS);
     memcpy(a.dwv, d->dw, VT_MAX_TAPS);
 
+    // Split of the pixel range: aim for `target` workgroups (about 2 per CU), but keep >= 8
+    // steps per wave group; atomic traffic is (#workgroups x 64 KiB) whatever the layer.
+    static const int target = getenv("VT_WGRAD_TARGET") ? atoi(getenv("VT_WGRAD_TARGET")) : 512;
+    static const int max_split_env = getenv("VT_WGRAD_MAXSPLIT") ? atoi(getenv("VT_WGRAD_MAXSPLIT")) : 128;
+    static const int variant = getenv("VT_WGRAD_VARIANT") ? atoi(getenv("VT_WGRAD_VARIANT")) : 0;
+    const int G = variant == 1 ? 1 : (variant == 2 ? 4 : 2);
     const int pk = 4 * epc;
     const long tiles = (long)a.tiles_n * a.tiles_k;
-    long split = (1024 + tiles - 1) / tiles;           // aim for ~4 workgroups per CU
-    const long max_split = (M + 8L * pk - 1) / (8L * pk);  // at least 8 steps per workgroup
+    long split = target / tiles;
+    const long max_split = (M + 8L * pk * G - 1) / (8L * pk * G);
     if (split > max_split) split = max_split;
+    if (split > max_split_env) split = max_split_env;
     if (split < 1) split = 1;
-    if (split > 65535) split = 65535;
     long chunk = (M + split - 1) / split;
-    chunk = (chunk + pk - 1) / pk * pk;
+    chunk = (chunk + (long)pk * G - 1) / ((long)pk * G) * ((long)pk * G);
     split = (M + chunk - 1) / chunk;
     a.chunk = (int)chunk;
 
-    const int smem = VT_MAX_TAPS * 8 + 2 * 2 * pk * (128 + 16) * vt_elem_size(d->dtype);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)tiles, (unsigned)split);
-    if (d->dtype == VT_BF16)
-        hipLaunchKernelGGL(wgrad_kernel<bf16_t>, grid, dim3(256), smem, st, a);
-    else
-        hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), smem, st, a);
+    const int stage = 2 * pk * 128 * vt_elem_size(d->dtype);  // 16 KiB
+#define VT_WG_LAUNCH(TT, GG, PDD)                                                                      \
+    do {                                                                                               \
+        int smem = kTapHdr + GG * (PDD + 1) * stage;                                                   \
+        if (GG > 1 && smem < kTapHdr + 65536) smem = kTapHdr + 65536; /* the f32 reduction image */   \
+        auto kern = wgrad_kernel<TT, GG, PDD>;                                                         \
+        if (smem > 64 * 1024) {                                                                        \
+            static bool raised = false;                                                                \
+            if (!raised) {                                                                             \
+                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+                if (e != hipSuccess) {                                                                 \
+                    vt_set_error("vt_conv_wgrad: cannot raise dynamic LDS to %d: %s", smem, hipGetErrorString(e)); \
+                    return VT_ERR_HIP;                                                                 \
+                }                                                                                      \
+                raised = true;                                                                         \
+            }                                                                                          \
+        }                                                                                              \
+        hipLaunchKernelGGL(kern, grid, dim3(256 * GG), smem, st, a);                                   \
+    } while (0)
+    if (d->dtype == VT_BF16) {
+        if (G == 1)
+            VT_WG_LAUNCH(bf16_t, 1, 2);
+        else if (G == 4)
+            VT_WG_LAUNCH(bf16_t, 4, 1);
+        else
+            VT_WG_LAUNCH(bf16_t, 2, 1);
+    } else {
+        if (G == 1)
+            VT_WG_LAUNCH(float, 1, 2);
+        else if (G == 4)
+            VT_WG_LAUNCH(float, 4, 1);
+        else
+            VT_WG_LAUNCH(float, 2, 1);
+    }
+#undef VT_WG_LAUNCH
     VT_CHECK_LAUNCH("vt_conv_wgrad");
     return VT_OK;
 }

@@ -44,7 +44,10 @@ VT_OP_MAX_PTR, VT_OP_MAX_INT, VT_OP_MAX_FLT, VT_MAX_BASES = 12, 110, 8, 16
     OP_COPY2D,
     OP_NCHW_TO_NHWC,
     OP_NHWC_TO_NCHW,
-) = range(1, 23)
+    OP_FORK,
+    OP_JOIN,
+) = range(1, 25)
+OP_SIDE_STREAM = 0x10000  # OR-ed into Op.kind: enqueue on the side stream
 
 OP_NAMES = {
     OP_MEMSET: "memset",
@@ -69,6 +72,8 @@ OP_NAMES = {
     OP_COPY2D: "copy2d",
     OP_NCHW_TO_NHWC: "nchw_to_nhwc",
     OP_NHWC_TO_NCHW: "nhwc_to_nchw",
+    OP_FORK: "fork",
+    OP_JOIN: "join",
 }
 
 
@@ -139,6 +144,7 @@ SYMBOLS = {
     "vt_nchw_to_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vt_nhwc_to_nchw": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vt_run_ops": (_i32, [C.POINTER(Op), _i32, C.POINTER(_vp), _i32, _vp]),
+    "vt_run_ops_streams": (_i32, [C.POINTER(Op), _i32, C.POINTER(_vp), _i32, _vp, _vp]),
     "vt_graph_create": (_i32, [C.POINTER(Op), _i32, C.POINTER(_vp), _i32, C.POINTER(_vp)]),
     "vt_graph_launch": (_i32, [_vp, _vp]),
     "vt_graph_destroy": (_i32, [_vp]),
@@ -189,10 +195,11 @@ def launch_count() -> int:
     return int(lib().vt_launch_count())
 
 
-def run_ops(ops, n: int, bases, stream: int) -> None:
-    """ops: (Op * n) array; bases: list of device addresses (ints or None)."""
+def run_ops(ops, n: int, bases, stream: int, side: int = 0) -> None:
+    """ops: (Op * n) array; bases: list of device addresses (ints or None); `side` is the
+    stream handle for ops flagged OP_SIDE_STREAM (0: run them in line)."""
     arr = (C.c_void_p * len(bases))(*[C.c_void_p(b) if b else None for b in bases])
-    check(lib().vt_run_ops(ops, n, arr, len(bases), C.c_void_p(stream)))
+    check(lib().vt_run_ops_streams(ops, n, arr, len(bases), C.c_void_p(stream), C.c_void_p(side) if side else None))
 
 
 class Graph:

@@ -269,9 +269,10 @@ class Builder:
         return buf
 
     # -- op emission --------------------------------------------------------------
-    def emit(self, kind: int, ptrs, ints=(), flts=(), desc: Optional[N.ConvDesc] = None, extra_ints=()):
+    def emit(self, kind: int, ptrs=(), ints=(), flts=(), desc: Optional[N.ConvDesc] = None, extra_ints=(),
+             side: bool = False):
         op = N.Op()
-        op.kind = kind
+        op.kind = kind | (N.OP_SIDE_STREAM if side else 0)
         op.tag = self.tag
         for k in range(N.VT_OP_MAX_PTR):
             op.ptr[k].base = -1
@@ -574,17 +575,20 @@ class Builder:
                     dz = dy
                     if conv.bias is not None and conv.bias.requires_grad:
                         self.emit(N.OP_COLSUM, [dz.addr(), self.pgrad(conv.bias)], [dz.ld, Cout, dt], [M])
-                # filter gradient
+                # filter gradient: needs only x and dz and nothing in backward waits for it, so
+                # it goes to the side stream and overlaps the (HBM-bound) chain that follows
                 if w.requires_grad:
                     dfwd = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, dz.ld, ldw, 0)
+                    self.emit(N.OP_FORK)
                     if padded:
                         ws = self.zeroed_f32(Cout * ntaps * x.C, "dwpad", bwd=True)
-                        self.emit(N.OP_CONV_WGRAD, [x.addr(), dz.addr(), self.bp(ws)], desc=dfwd, extra_ints=[ldw])
+                        self.emit(N.OP_CONV_WGRAD, [x.addr(), dz.addr(), self.bp(ws)], desc=dfwd, extra_ints=[ldw],
+                                  side=True)
                         self.emit(N.OP_COPY2D, [self.bp(ws), self.pgrad(w)], [N.VT_F32, N.VT_F32, Cin_w, 1],
-                                  [x.C, Cin_w, Cout * ntaps])
+                                  [x.C, Cin_w, Cout * ntaps], side=True)
                     else:
                         self.emit(N.OP_CONV_WGRAD, [x.addr(), dz.addr(), self.pgrad(w)], desc=dfwd,
-                                  extra_ints=[ldw])
+                                  extra_ints=[ldw], side=True)
                 # data gradient
                 if x.needs_grad:
                     self._dgrad(x, dz, wptr if not padded else self.bp(wpack), dt if (padded or dt != N.VT_F32) else N.VT_F32,
@@ -759,6 +763,7 @@ class Builder:
         self._cur = self.bwd
         for node in reversed(self.nodes):
             node()
+        self.emit(N.OP_JOIN)  # all filter gradients done before anything reads the gradient buffers
         self._cur = self.fwd
 
     def seed_output_grads(self, outs: list[TRef]):

@@ -80,7 +80,7 @@ class Program:
         self.builder = b  # kept for tools/debug_*.py (name -> activation / gradient buffers)
         self.kind_histogram = {}
         for op in fwd + bwd:
-            k = N.OP_NAMES.get(op.kind, str(op.kind))
+            k = N.OP_NAMES.get(op.kind & 0xFFFF, str(op.kind))
             self.kind_histogram[k] = self.kind_histogram.get(k, 0) + 1
 
     def bases(self, arena_ptr: int, **named) -> list:

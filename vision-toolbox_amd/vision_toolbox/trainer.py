@@ -186,6 +186,7 @@ class TrainStep:
             INPUT=self.images.data_ptr(), LABELS=self.labels.data_ptr(), MOMENTUM=self.mflat.data_ptr(),
             HYPER=self.lr_dev.data_ptr())
         self.use_graphs = use_graphs
+        self._side = None  # side stream for the filter gradients (eager mode; graphs fork internally)
         self._graphs = None
         self.steps_done = 0
 
@@ -255,8 +256,10 @@ class TrainStep:
             else:
                 N.run_ops(self.zero_ops, 1, self.bases, s)
                 N.run_ops(p.fwd_ops, p.n_fwd, self.bases, s)
+                if self._side is None:
+                    self._side = torch.cuda.Stream(self.device)
                 for (ops, n), bks in zip(self._segment_ops(), self.cut_buckets):
-                    N.run_ops(ops, n, self.bases, s)
+                    N.run_ops(ops, n, self.bases, s, side=int(self._side.cuda_stream))
                     for bi in bks:
                         self.bucketer.reduce_bucket(bi)
             if self.bucketer is not None:
