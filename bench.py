@@ -71,6 +71,16 @@ def conv_roofline(B, C, HW, dtype_id, iters=30, warmup=10):
             "shape": f"conv3x3 s1 {C}->{C} @{HW}x{HW} B={B} (M={B*HW*HW} N={C} K={9*C})"}
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass
+    (profiles/r01_dominant_kernel_pmc.json: FETCH_SIZE x2 (gfx950) + WRITE_SIZE, separate runs)."""
+    f = ROOT / "profiles" / "r01_dominant_kernel_pmc.json"
+    try:
+        return float(json.loads(f.read_text())["traffic_bytes"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(seconds: float = 12.0):
     """oracle (pure torch CPU fp32 restatement of the reference) CSPDarknet-53 train step."""
     from oracle import filler
@@ -118,7 +128,10 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
     ap.add_argument("--model", default="cspdarknet53")
     ap.add_argument("--image-size", type=int, default=224)
-    ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--graphs", action="store_true",
+                    help="replay captured hipGraphs (default: native executor with the filter gradients on a "
+                         "side stream, which measured faster: hipGraph serialises the forked branches)")
+    ap.add_argument("--no-graphs", action="store_true", help="(default) kept for compatibility")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=16.0)
     args = ap.parse_args()
@@ -137,7 +150,7 @@ def main():
     torch.manual_seed(0)
     bb = getattr(backbones, args.model)()
     ts = TrainStep(bb, 1000, args.batch, args.image_size, torch.bfloat16, lr=0.05, momentum=0.9, weight_decay=2e-5,
-                   label_smoothing=0.1, device=dev, bucket_mb=args.bucket_mb, use_graphs=not args.no_graphs)
+                   label_smoothing=0.1, device=dev, bucket_mb=args.bucket_mb, use_graphs=args.graphs)
     ts.broadcast_parameters(0)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
@@ -191,9 +204,10 @@ def main():
             "config": {"workload": f"{args.model} train step (fwd+CE+bwd+allreduce+SGD), batch {args.batch}/GPU, "
                                    f"3x{args.image_size}x{args.image_size}, 1000 classes, BASELINE configs[1]",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "hip_graphs": not args.no_graphs, "final_loss": round(loss, 4)},
+                       "hip_graphs": bool(args.graphs), "final_loss": round(loss, 4)},
             "roofline": {"bound": "mfma", "achieved": round(dom["tflops"], 1), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4),
+                         "traffic": pmc_traffic(),
                          "kernel": "igemm_kernel<bf16,128,128,2,2>", "launch_ms": round(dom["ms"], 4),
                          "layer": dom["shape"]},
             "roofline_layers": [{"layer": l["shape"], "ms": round(l["ms"], 4), "tflops": round(l["tflops"], 1),

@@ -67,7 +67,7 @@ def test_train_steps_f32_match_oracle(name, graphs):
         d_got, d_ref = sd[k].cpu() - init[k], ref_sd[k].detach() - init[k]
         assert d_ref.norm() > 0 and rel_err(d_got, d_ref) < tol, k  # the UPDATE, not the weight
     k = [k for k in sd if k.endswith("running_var")][-1]
-    assert rel_err(sd[k].cpu(), ref_sd[k]) < 5e-3
+    assert rel_err(sd[k].cpu(), ref_sd[k]) < (5e-2 if deep else 5e-3)
 
 
 def test_bf16_train_step_decreases_loss_and_matches_f32_roughly():

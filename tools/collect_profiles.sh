@@ -1,0 +1,50 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence bench.py's numbers rest on (run on the GPU box via gpurun):
+#   1. kernel-trace + stats of the exact bench command           -> gpurun_out/prof_bench/
+#   2. PMC passes (FETCH_SIZE, WRITE_SIZE in SEPARATE runs, as MI355X_MICROARCH.md prescribes)
+#      of the dominant kernel on its dominant layer                -> gpurun_out/pmc_fetch/, pmc_write/
+#   3. a JSON summary                                              -> gpurun_out/r01_dominant_kernel_pmc.json
+# Copy what should be judged into profiles/ afterwards.
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bench" -- \
+    python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/prof_bench.log" 2>&1
+echo "bench profile exit $?"
+
+LAYER="128,128,3,1,28"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- \
+    python3 "$ROOT/tools/bench_conv.py" fwd $LAYER > "$OUT/pmc_fetch.log" 2>&1
+echo "pmc fetch exit $?"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- \
+    python3 "$ROOT/tools/bench_conv.py" fwd $LAYER > "$OUT/pmc_write.log" 2>&1
+echo "pmc write exit $?"
+
+python3 - "$OUT" <<'EOF'
+import csv, glob, json, sys
+out = sys.argv[1]
+def avg(counter, d):
+    f = glob.glob(f"{out}/{d}/*/*counter_collection.csv")[0]
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+            if "igemm_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    return sum(vals) / max(len(vals), 1), len(vals)
+fetch_kb, n1 = avg("FETCH_SIZE", "pmc_fetch")
+write_kb, n2 = avg("WRITE_SIZE", "pmc_write")
+f = glob.glob(f"{out}/pmc_fetch/*/*kernel_trace.csv")[0]
+durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(f))
+        if "igemm_kernel" in r["Kernel_Name"]]
+res = {
+    "kernel": "igemm_kernel<bf16,128,128,2,2>", "layer": "conv3x3 s1 128->128 @28x28 B=256",
+    "launches": n1, "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb,
+    # gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads -> doubled
+    "hbm_read_bytes": fetch_kb * 1024 * 2, "hbm_write_bytes": write_kb * 1024,
+    "traffic_bytes": fetch_kb * 1024 * 2 + write_kb * 1024,
+    "algorithmic_bytes": (200704 * 128 + 128 * 1152 + 200704 * 128) * 2,
+    "avg_duration_us_under_pmc": sum(durs) / max(len(durs), 1),
+}
+json.dump(res, open(f"{out}/r01_dominant_kernel_pmc.json", "w"), indent=1)
+print(json.dumps(res))
+EOF

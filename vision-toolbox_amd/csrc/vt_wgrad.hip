@@ -337,7 +337,7 @@ extern "C" int vt_conv_wgrad(const vt_conv_desc* d, const void* x, const void* d
     // Split of the pixel range: aim for `target` workgroups (about 2 per CU), but keep >= 8
     // steps per wave group; atomic traffic is (#workgroups x 64 KiB) whatever the layer.
     static const int target = getenv("VT_WGRAD_TARGET") ? atoi(getenv("VT_WGRAD_TARGET")) : 512;
-    static const int max_split_env = getenv("VT_WGRAD_MAXSPLIT") ? atoi(getenv("VT_WGRAD_MAXSPLIT")) : 128;
+    static const int max_split_env = getenv("VT_WGRAD_MAXSPLIT") ? atoi(getenv("VT_WGRAD_MAXSPLIT")) : 4096;
     static const int variant = getenv("VT_WGRAD_VARIANT") ? atoi(getenv("VT_WGRAD_VARIANT")) : 0;
     const int G = variant == 1 ? 1 : (variant == 2 ? 4 : 2);
     const int pk = 4 * epc;
