@@ -6,6 +6,8 @@
 // 16-byte channel chunk column and walks rows (pixels), so per-channel
 // coefficients live in registers and consecutive lanes touch consecutive
 // 16-byte chunks of a pixel row (full-line coalesced NHWC accesses, G13).
+#include <stdlib.h>
+
 #include "vt_common.h"
 
 namespace {
@@ -89,7 +91,7 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 // ---------------------------------------------------------------------------------
 // y = [relu](z*scale + shift) [+ residual]
 // ---------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool kRes>
 __global__ void __launch_bounds__(kThreads)
 bn_act_apply_kernel(const T* __restrict__ z, int ldz, const float* __restrict__ scale,
                     const float* __restrict__ shift, const T* __restrict__ res, int ldr, T* __restrict__ y,
@@ -102,42 +104,48 @@ bn_act_apply_kernel(const T* __restrict__ z, int ldz, const float* __restrict__ 
     for (int col = t % rm.CT; col < rm.CPR; col += rm.CT) {
         float sc[EPC], sf[EPC];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            sc[e] = scale ? scale[col * EPC + e] : 1.f;
-            sf[e] = shift ? shift[col * EPC + e] : 0.f;
+        for (int e = 0; e < EPC; ++e) sc[e] = 1.f, sf[e] = 0.f;
+        if (scale) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) sc[e] = scale[col * EPC + e];
         }
+        if (shift) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) sf[e] = shift[col * EPC + e];
+        }
+        const T* pz = z + row0 * ldz + col * EPC;
+        const T* pr = kRes ? res + row0 * ldr + col * EPC : nullptr;
+        T* py = y + row0 * ldy + col * EPC;
+        const long sz = (long)rm.RT * ldz, sr = (long)rm.RT * ldr, sy = (long)rm.RT * ldy;
         // kUnroll rows per trip: all loads are issued before the first use (bytes in flight)
         for (int it = 0; it < rm.iters; it += kUnroll) {
             uint4 vz[kUnroll], vr[kUnroll];
             bool ok[kUnroll];
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
-                const long row = row0 + (long)(it + u) * rm.RT;
-                ok[u] = (it + u < rm.iters) && row < M;
+                ok[u] = (it + u < rm.iters) && (row0 + (long)(it + u) * rm.RT < M);
                 vz[u] = vr[u] = make_uint4(0, 0, 0, 0);
                 if (ok[u]) {
-                    vz[u] = ld16(z + row * ldz + col * EPC);
-                    if (res) vr[u] = ld16(res + row * ldr + col * EPC);
+                    vz[u] = ld16(pz + (it + u) * sz);
+                    if (kRes) vr[u] = ld16(pr + (it + u) * sr);
                 }
             }
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
-                if (!ok[u]) continue;
-                const long row = row0 + (long)(it + u) * rm.RT;
                 float v[EPC];
                 VecIO<T>::unpack(vz[u], v);
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     v[e] = fmaf(v[e], sc[e], sf[e]);
-                    if (relu) v[e] = fmaxf(v[e], 0.f);
+                    v[e] = relu ? fmaxf(v[e], 0.f) : v[e];
                 }
-                if (res) {
+                if (kRes) {
                     float rr[EPC];
                     VecIO<T>::unpack(vr[u], rr);
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) v[e] += rr[e];
                 }
-                st16(y + row * ldy + col * EPC, VecIO<T>::pack(v));
+                if (ok[u]) st16(py + (it + u) * sy, VecIO<T>::pack(v));
             }
         }
     }
@@ -153,27 +161,33 @@ bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z
                      const float* __restrict__ mean, const float* __restrict__ invstd, long M, int C,
                      RowMap rm, int relu, float* __restrict__ sums) {
     constexpr int EPC = VecIO<T>::EPC;
-    extern __shared__ float sred[];  // [2][CT*EPC]
+    // [RT][2][CT*EPC] partial sums: each thread parks its 2*EPC partials, then the first
+    // 2*CT*EPC threads fold the RT row lanes (no LDS atomics: with RT rows per column they
+    // serialised RT-way and cost as much as the streaming itself on the 28x28..7x7 maps).
+    extern __shared__ __attribute__((aligned(16))) float sred[];
     const int t = threadIdx.x;
     const int r = t / rm.CT;
+    const int tc = t % rm.CT;
+    const int W = rm.CT * EPC;  // channels covered per pass
     const long row0 = (long)blockIdx.x * rm.RT * rm.iters + r;
     const int rep = blockIdx.x % VT_STAT_REPLICAS;
     for (int cbase = 0; cbase < rm.CPR; cbase += rm.CT) {
-        const int col = cbase + t % rm.CT;
+        const int col = cbase + tc;
         const bool active = (r < rm.RT) && (col < rm.CPR);
-        for (int i = t; i < 2 * rm.CT * EPC; i += kThreads) sred[i] = 0.f;
-        __syncthreads();
+        float s1[EPC], s2[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
         if (active) {
-            float sc[EPC], sf[EPC], mu[EPC], is[EPC], s1[EPC], s2[EPC];
+            float sc[EPC], sf[EPC], mu[EPC];
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
                 sc[e] = scale[col * EPC + e];
                 sf[e] = shift[col * EPC + e];
                 mu[e] = mean[col * EPC + e];
-                is[e] = invstd[col * EPC + e];
-                s1[e] = 0.f;
-                s2[e] = 0.f;
             }
+            const T* pg = dy + row0 * lddy + col * EPC;
+            const T* pz = z + row0 * ldz + col * EPC;
+            const long sg = (long)rm.RT * lddy, sz = (long)rm.RT * ldz;
             for (int it = 0; it < rm.iters; it += kUnroll) {
                 uint4 vg[kUnroll], vz[kUnroll];
 #pragma unroll
@@ -181,8 +195,8 @@ bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z
                     const long row = row0 + (long)(it + u) * rm.RT;
                     vg[u] = vz[u] = make_uint4(0, 0, 0, 0);  // zero dy contributes nothing
                     if ((it + u < rm.iters) && row < M) {
-                        vg[u] = ld16(dy + row * lddy + col * EPC);
-                        vz[u] = ld16(z + row * ldz + col * EPC);
+                        vg[u] = ld16(pg + (it + u) * sg);
+                        vz[u] = ld16(pz + (it + u) * sz);
                     }
                 }
 #pragma unroll
@@ -194,22 +208,30 @@ bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z
                     for (int e = 0; e < EPC; ++e) {
                         const float gg = (!relu || fmaf(zz[e], sc[e], sf[e]) > 0.f) ? g[e] : 0.f;
                         s1[e] += gg;
-                        s2[e] += gg * ((zz[e] - mu[e]) * is[e]);
+                        s2[e] = fmaf(gg, zz[e] - mu[e], s2[e]);  // invstd applied once, below
                     }
                 }
             }
-            const int lc = (t % rm.CT) * EPC;
+        }
+        if (r < rm.RT) {
+            float4* d1 = (float4*)(sred + ((long)(r * 2 + 0) * W + tc * EPC));
+            float4* d2 = (float4*)(sred + ((long)(r * 2 + 1) * W + tc * EPC));
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                atomicAdd(&sred[lc + e], s1[e]);
-                atomicAdd(&sred[rm.CT * EPC + lc + e], s2[e]);
+            for (int q = 0; q < EPC / 4; ++q) {
+                d1[q] = make_float4(s1[4 * q], s1[4 * q + 1], s1[4 * q + 2], s1[4 * q + 3]);
+                d2[q] = make_float4(s2[4 * q], s2[4 * q + 1], s2[4 * q + 2], s2[4 * q + 3]);
             }
         }
         __syncthreads();
-        for (int i = t; i < 2 * rm.CT * EPC; i += kThreads) {
-            const int which = i / (rm.CT * EPC), lc = i % (rm.CT * EPC);
+        for (int i = t; i < 2 * W; i += kThreads) {
+            const int which = i / W, lc = i % W;
             const int c = cbase * EPC + lc;
-            if (c < C) atomicAdd(&sums[((long)rep * 2 + which) * C + c], sred[i]);
+            if (c < C) {
+                float acc = 0.f;
+                for (int rr = 0; rr < rm.RT; ++rr) acc += sred[(long)(rr * 2 + which) * W + lc];
+                if (which) acc *= invstd[c];
+                atomicAdd(&sums[((long)rep * 2 + which) * C + c], acc);
+            }
         }
         __syncthreads();
     }
@@ -814,10 +836,17 @@ int vt_bn_act_apply(const void* z, int32_t ldz, const float* scale, const float*
     VT_TRY(check_mat("vt_bn_act_apply(y)", y, ldy, C, dtype));
     if (residual) VT_TRY(check_mat("vt_bn_act_apply(residual)", residual, ldr, C, dtype));
     const RowMap rm = RowMap::make(C, vt_epc(dtype), M);
-    VT_DISPATCH_T(dtype, "vt_bn_act_apply",
-                  hipLaunchKernelGGL(bn_act_apply_kernel<T>, dim3(rm.blocks(M)), dim3(kThreads), 0,
-                                     (hipStream_t)stream, (const T*)z, ldz, scale, shift, (const T*)residual,
-                                     ldr, (T*)y, ldy, (long)M, rm, relu));
+    if (residual) {
+        VT_DISPATCH_T(dtype, "vt_bn_act_apply",
+                      hipLaunchKernelGGL((bn_act_apply_kernel<T, true>), dim3(rm.blocks(M)), dim3(kThreads), 0,
+                                         (hipStream_t)stream, (const T*)z, ldz, scale, shift, (const T*)residual,
+                                         ldr, (T*)y, ldy, (long)M, rm, relu));
+    } else {
+        VT_DISPATCH_T(dtype, "vt_bn_act_apply",
+                      hipLaunchKernelGGL((bn_act_apply_kernel<T, false>), dim3(rm.blocks(M)), dim3(kThreads), 0,
+                                         (hipStream_t)stream, (const T*)z, ldz, scale, shift, (const T*)residual,
+                                         ldr, (T*)y, ldy, (long)M, rm, relu));
+    }
     VT_CHECK_LAUNCH("vt_bn_act_apply");
     return VT_OK;
 }
@@ -830,8 +859,9 @@ int vt_bn_act_bwd_reduce(const void* dy, int32_t lddy, const void* z, int32_t ld
     VT_TRY(check_mat("vt_bn_act_bwd_reduce(dy)", dy, lddy, C, dtype));
     VT_TRY(check_mat("vt_bn_act_bwd_reduce(z)", z, ldz, C, dtype));
     const int epc = vt_epc(dtype);
-    const RowMap rm = RowMap::make(C, epc, M, 2048);
-    const int smem = 2 * rm.CT * epc * (int)sizeof(float);
+    static const int target = getenv("VT_REDUCE_BLOCKS") ? atoi(getenv("VT_REDUCE_BLOCKS")) : 1024;
+    const RowMap rm = RowMap::make(C, epc, M, target);
+    const int smem = rm.RT * 2 * rm.CT * epc * (int)sizeof(float);
     VT_DISPATCH_T(dtype, "vt_bn_act_bwd_reduce",
                   hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(rm.blocks(M)), dim3(kThreads), smem,
                                      (hipStream_t)stream, (const T*)dy, lddy, (const T*)z, ldz, scale, shift,

@@ -46,24 +46,12 @@
 // Workgroup -> tile map is XCD aware: blocks b and b+8 share an XCD (and its
 // L2), so each XCD walks a contiguous range of M tiles, N tiles fastest: the
 // N tiles of one M tile and the 3x3 halos of neighbouring M tiles hit L2.
+#include <stdlib.h>
+
 #include "vt_common.h"
+#include "vt_igemm_args.h"
 
 namespace {
-
-struct IgemmArgs {
-    const void* x;
-    const void* w;
-    void* y;
-    const float* scale;
-    const float* shift;
-    const void* res;
-    float* stats;
-    int B, Hi, Wi, Cin, ldx, Ho, Wo, sh, sw, h0, w0, Cout, ldy, oH, oW, oHs, oWs, oh0, ow0;
-    int ldw, ldr, flags, ntaps;
-    int M, Ktot, tiles_m, tiles_n, chunk, dense_out;
-    int8_t dh[VT_MAX_TAPS];
-    int8_t dw[VT_MAX_TAPS];
-};
 
 constexpr int kTapBytes = VT_MAX_TAPS * 16;  // int4 per tap
 constexpr int kStatBytes = 2 * 128 * 4;      // sum, sumsq for BN <= 128
@@ -514,7 +502,14 @@ extern "C" int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w
     memcpy(a.dw, d->dw, VT_MAX_TAPS);
 
     hipStream_t st = (hipStream_t)stream;
+    {
+        const int rc = vt_span_dispatch(a, d->dtype, stream);  // stride-1-grid convs: input-span kernel
+        if (rc >= 0) return rc;
+    }
     if (d->dtype == VT_BF16) {
+        // 96- and 64-row tiles (to dodge the "2.04 rounds" wave quantisation of 128-row tiles at
+        // batch 256) measured 8-15 % SLOWER on the CSPDarknet-53 layers: the extra filter
+        // staging per FLOP costs more than the idle tail saves.  One tile height.
         if (d->Cout > 64) return launch<bf16_t, 128, 128, 2, 2, 2>(a, st);
         if (d->Cout > 32) return launch<bf16_t, 128, 64, 2, 2, 2>(a, st);
         return launch<bf16_t, 256, 32, 4, 1, 2>(a, st);

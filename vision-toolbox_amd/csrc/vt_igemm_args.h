@@ -1,0 +1,22 @@
+// vt_igemm_args.h -- kernel argument block shared by the implicit-GEMM conv kernels.
+#pragma once
+#include "vt_common.h"
+
+struct IgemmArgs {
+    const void* x;
+    const void* w;
+    void* y;
+    const float* scale;
+    const float* shift;
+    const void* res;
+    float* stats;
+    int B, Hi, Wi, Cin, ldx, Ho, Wo, sh, sw, h0, w0, Cout, ldy, oH, oW, oHs, oWs, oh0, ow0;
+    int ldw, ldr, flags, ntaps;
+    int M, Ktot, tiles_m, tiles_n, chunk, dense_out;
+    int8_t dh[VT_MAX_TAPS];
+    int8_t dw[VT_MAX_TAPS];
+};
+
+// vt_igemm_span.hip: input-span kernel for stride-1-grid convs; returns -1 when it does not
+// apply to `a` (the caller then launches the general kernel), else a VT_* status.
+int vt_span_dispatch(IgemmArgs& a, int dtype, void* stream);
