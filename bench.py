@@ -33,8 +33,8 @@ PEAK_HBM_GBS = 8000.0
 
 
 def conv_roofline(B, C, HW, dtype_id, iters=30, warmup=10):
-    """time the dominant kernel (implicit-GEMM 3x3 conv, 128x128 tile) standalone on the
-    layer shape it spends most time on: CxC 3x3 s1 at HWxHW, batch B, with the training
+    """time the dominant kernel (input-span implicit-GEMM 3x3 conv, 256x128 tile) standalone on
+    the layer shape it spends most time on: CxC 3x3 s1 at HWxHW, batch B, with the training
     epilogue (BN statistics)."""
     from vision_toolbox import _native as N
 
@@ -184,7 +184,8 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = args.batch * world * args.steps / elapsed
-        # dominant kernel: igemm_kernel<bf16,128,128> on the 3x3 convs; roofline on its largest layer
+        # dominant kernel: span_kernel<bf16,256,128> (vt_igemm_span.hip) on the stride-1 3x3 convs and
+        # their data gradients; roofline on the layer shape with the largest share of the step
         layers = [conv_roofline(args.batch, 128, 28, N.VT_BF16), conv_roofline(args.batch, 256, 14, N.VT_BF16),
                   conv_roofline(args.batch, 512, 7, N.VT_BF16)]
         dom = layers[0]
@@ -208,7 +209,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(dom["tflops"], 1), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4),
                          "traffic": pmc_traffic(),
-                         "kernel": "igemm_kernel<bf16,128,128,2,2>", "launch_ms": round(dom["ms"], 4),
+                         "kernel": "span_kernel<bf16,256,128,2,2>", "launch_ms": round(dom["ms"], 4),
                          "layer": dom["shape"]},
             "roofline_layers": [{"layer": l["shape"], "ms": round(l["ms"], 4), "tflops": round(l["tflops"], 1),
                                  "frac": round(l["tflops"] / PEAK_BF16_TFLOPS, 4)} for l in layers],

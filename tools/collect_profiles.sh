@@ -29,15 +29,15 @@ out = sys.argv[1]
 def avg(counter, d):
     f = glob.glob(f"{out}/{d}/*/*counter_collection.csv")[0]
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-            if "igemm_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            if "span_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
     return sum(vals) / max(len(vals), 1), len(vals)
 fetch_kb, n1 = avg("FETCH_SIZE", "pmc_fetch")
 write_kb, n2 = avg("WRITE_SIZE", "pmc_write")
 f = glob.glob(f"{out}/pmc_fetch/*/*kernel_trace.csv")[0]
 durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(f))
-        if "igemm_kernel" in r["Kernel_Name"]]
+        if "span_kernel" in r["Kernel_Name"]]
 res = {
-    "kernel": "igemm_kernel<bf16,128,128,2,2>", "layer": "conv3x3 s1 128->128 @28x28 B=256",
+    "kernel": "span_kernel<bf16,256,128,2,2>", "layer": "conv3x3 s1 128->128 @28x28 B=256",
     "launches": n1, "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb,
     # gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads -> doubled
     "hbm_read_bytes": fetch_kb * 1024 * 2, "hbm_write_bytes": write_kb * 1024,

@@ -1,0 +1,87 @@
+"""Per-op timing of the CSPDarknet-53 bf16 train step (GPU box).
+
+    python tools/profile_ops.py [model] [batch] [top]
+
+Replays every op of the forward / backward launch lists in isolation (each op 5x back to
+back on one stream, HIP events around it) and prints the time, the conv shape and the
+achieved TFLOP/s or GB/s, sorted by time, plus totals per op kind.  In isolation = without
+the filter-gradient side stream competing, so the column sums are a lower bound of a step."""
+import ctypes
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path[:0] = [str(ROOT / "vision-toolbox_amd"), str(ROOT)]
+
+import torch
+
+from vision_toolbox import _native as N
+from vision_toolbox import backbones
+from vision_toolbox.trainer import TrainStep
+
+
+def main():
+    model = sys.argv[1] if len(sys.argv) > 1 else "cspdarknet53"
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    ts = TrainStep(getattr(backbones, model)(), 1000, B, 224, torch.bfloat16, lr=0.05, momentum=0.9,
+                   weight_decay=2e-5, label_smoothing=0.1, device=dev)
+    ts.images.copy_(torch.rand(ts.images.shape, device=dev))
+    ts.labels.copy_(torch.randint(0, 1000, ts.labels.shape, device=dev))
+    for _ in range(3):
+        ts.step()
+    torch.cuda.synchronize()
+    s = int(torch.cuda.current_stream().cuda_stream)
+    p = ts.prog
+    rows = []
+    reps = 5
+    for phase, ops, n in (("fwd", p.fwd_ops, p.n_fwd), ("bwd", p.bwd_ops, p.n_bwd)):
+        for idx in range(n):
+            op = ops[idx]
+            kind = op.kind & 0xFFFF
+            if kind in (N.OP_FORK, N.OP_JOIN):
+                continue
+            one = (N.Op * 1).from_address(ctypes.addressof(ops) + idx * ctypes.sizeof(N.Op))
+            N.run_ops(one, 1, ts.bases, s)
+            e0, e1 = N.Event(), N.Event()
+            e0.record(s)
+            for _ in range(reps):
+                N.run_ops(one, 1, ts.bases, s)
+            e1.record(s)
+            ms = e0.elapsed_ms(e1) / reps
+            name = N.OP_NAMES.get(kind, str(kind))
+            desc, work = "", ""
+            if kind in (N.OP_CONV_IGEMM, N.OP_CONV_WGRAD):
+                d = N.ConvDesc.from_buffer_copy(bytes(op.i)[: ctypes.sizeof(N.ConvDesc)])
+                fl = 2.0 * d.B * d.Ho * d.Wo * d.Cout * d.Cin * d.ntaps
+                desc = f"{d.Cin:4d}->{d.Cout:4d} taps {d.ntaps:2d} s{d.sh} in {d.Hi:3d}x{d.Wi:<3d} grid {d.Ho:3d}x{d.Wo:<3d}"
+                work = f"{fl / ms / 1e9:7.1f} TF/s"
+            elif kind == N.OP_BN_ACT_APPLY:
+                pass
+            rows.append((ms, phase, idx, name, desc, work))
+    tot = defaultdict(float)
+    for ms, phase, idx, name, desc, work in rows:
+        tot[(phase, name)] += ms
+    print(f"{model} B={B}: {len(rows)} ops, sum {sum(r[0] for r in rows):.3f} ms (isolated, serial)")
+    for (phase, name), v in sorted(tot.items(), key=lambda kv: -kv[1]):
+        print(f"  {phase} {name:16s} {v:8.3f} ms")
+    print("-- conv ops by time")
+    conv = [r for r in rows if r[3].startswith("conv")]
+    for ms, phase, idx, name, desc, work in sorted(conv, key=lambda r: -r[0])[:top]:
+        print(f"  {phase}[{idx:4d}] {name:11s} {desc}  {ms:7.4f} ms {work}")
+    # aggregate identical conv shapes
+    agg = defaultdict(lambda: [0, 0.0])
+    for ms, phase, idx, name, desc, work in conv:
+        a = agg[(phase, name, desc)]
+        a[0] += 1
+        a[1] += ms
+    print("-- conv shapes aggregated")
+    for (phase, name, desc), (cnt, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
+        print(f"  {phase} {name:11s} {desc} x{cnt:2d}  {ms:7.3f} ms")
+
+
+if __name__ == "__main__":
+    main()
