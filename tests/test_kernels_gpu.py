@@ -342,3 +342,24 @@ def test_executor_and_graph_replay_agree():
     bad.kind = 999
     with pytest.raises(N.NativeError):
         N.run_ops(E.ops_array([bad]), 1, [src.data_ptr()], stream())
+
+
+@pytest.mark.parametrize("mode", ["0", "2", "3"], ids=["general_only", "span_forced", "span_256row_tiles"])
+def test_conv_kernel_variants_in_subprocess(mode):
+    """vt_conv_igemm picks between the general gather kernel and the input-span kernel (and its
+    tile heights) from the problem size; the sizes above only reach some of them.  The choice
+    is read from VT_IGEMM_SPAN once per process, so the conv tests are re-run in a child
+    process per setting: 0 = general kernel everywhere, 2 = span kernel wherever it applies,
+    3 = span kernel with 256-row tiles."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, VT_IGEMM_SPAN=mode)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, "-k",
+                        "test_conv_forward_and_stats or test_conv_channel_slices_and_fused_epilogue"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    # the autouse fixture wants a launch from THIS process too
+    buf = torch.zeros(16, device="cuda")
+    N.check(N.lib().vt_memset(vp(buf), 0, 64, stream()))

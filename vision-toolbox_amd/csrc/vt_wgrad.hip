@@ -34,7 +34,7 @@ struct WgradArgs {
     const void* dz;
     float* dw;
     int B, Hi, Wi, Cin, ldx, Ho, Wo, sh, sw, h0, w0, Cout, ldy, ntaps;
-    int M, Ktot, ldgw, tiles_n, tiles_k, chunk;
+    int M, Ktot, ldgw, tiles_n, tiles_k, chunk, ablate;
     int8_t dh[VT_MAX_TAPS];
     int8_t dwv[VT_MAX_TAPS];
 };
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(256 * G) wgrad_kernel(const WgradArgs p) {
             const int n = n0 + h * ROWS + nrow, k = k0 + kcol;
             const int gq = ((nrow & 15) >> 2);  // the row's g at write time
             const float v = sAcc[nrow * 128 + (kcol ^ (gq << 4))];
-            if (n < p.Cout && k < p.Ktot) atomicAdd(p.dw + ((long)n * p.ldgw + k), v);
+            if (n < p.Cout && k < p.Ktot && !p.ablate) atomicAdd(p.dw + ((long)n * p.ldgw + k), v);
         }
         if (HALVES > 1) __syncthreads();
     }
@@ -351,6 +351,8 @@ extern "C" int vt_conv_wgrad(const vt_conv_desc* d, const void* x, const void* d
     chunk = (chunk + (long)pk * G - 1) / ((long)pk * G) * ((long)pk * G);
     split = (M + chunk - 1) / chunk;
     a.chunk = (int)chunk;
+    static const int ablate = getenv("VT_WGRAD_ABLATE") ? atoi(getenv("VT_WGRAD_ABLATE")) : 0;  // timing experiments
+    a.ablate = ablate;
 
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)tiles, (unsigned)split);

@@ -230,6 +230,11 @@ class Builder:
         self.tag = 0
         self.n_units = 0
         self.debug_refs: dict[str, TRef] = {}
+        # the fused trainer sets this: the repacked data-gradient filters depend only on the
+        # weights, so their (tiny, launch-bound) pack kernels leave the backward critical path
+        # and run on the side stream while the forward list executes
+        self.hoist_dgrad_packs = False
+        self._hoisted: list[N.Op] = []
 
     # -- memory -----------------------------------------------------------------
     def alloc(self, nbytes: int, name: str = "") -> Buf:
@@ -619,7 +624,12 @@ class Builder:
                 nsel = len(sel)
                 wd = self.alloc(x.C * nsel * Cout * _ESIZE[dt], "wd")
                 ints = [w_dtype, ldw, dt, nsel, Cout, k * k, x.C, 0] + sel
-                self.emit(N.OP_PACK_DGRAD, [wptr, self.bp(wd)], ints)
+                if self.hoist_dgrad_packs:
+                    keep, self._cur = self._cur, self._hoisted
+                    self.emit(N.OP_PACK_DGRAD, [wptr, self.bp(wd)], ints, side=True)
+                    self._cur = keep
+                else:
+                    self.emit(N.OP_PACK_DGRAD, [wptr, self.bp(wd)], ints)
                 d = N.ConvDesc()
                 d.dtype = dt
                 d.B, d.Hi, d.Wi, d.Cin, d.ldx = dz.B, Ho, Wo, Cout, dz.ld
@@ -765,6 +775,15 @@ class Builder:
             node()
         self.emit(N.OP_JOIN)  # all filter gradients done before anything reads the gradient buffers
         self._cur = self.fwd
+        if self._hoisted:
+            # [FORK, packs on the side stream] ahead of the forward ops; the executor joins the
+            # side stream at the end of the list, i.e. before the backward list starts
+            body, self.fwd = self.fwd, []
+            self._cur = self.fwd
+            self.emit(N.OP_FORK)
+            self.fwd.extend(self._hoisted)
+            self.fwd.extend(body)
+            self._hoisted = []
 
     def seed_output_grads(self, outs: list[TRef]):
         """reserve gradient buffers of the returned feature maps; they are filled from the

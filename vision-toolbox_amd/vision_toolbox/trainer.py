@@ -127,6 +127,7 @@ class TrainStep:
 
         # ---- forward + loss + backward launch lists ---------------------------------------
         b = E.Builder(st, self.dtype, training=True, need_grad=True, grad_base=E.GRADS)
+        b.hoist_dgrad_packs = True
         x = b.input_images(batch_size, 3, image_size, image_size)
         fmap = backbone._vt_emit_maps(b, x)[-1]
         pooled = b.global_avgpool(fmap, "head.pool")
@@ -254,10 +255,10 @@ class TrainStep:
                     for bi in bks:
                         self.bucketer.reduce_bucket(bi)
             else:
-                N.run_ops(self.zero_ops, 1, self.bases, s)
-                N.run_ops(p.fwd_ops, p.n_fwd, self.bases, s)
                 if self._side is None:
                     self._side = torch.cuda.Stream(self.device)
+                N.run_ops(self.zero_ops, 1, self.bases, s)
+                N.run_ops(p.fwd_ops, p.n_fwd, self.bases, s, side=int(self._side.cuda_stream))
                 for (ops, n), bks in zip(self._segment_ops(), self.cut_buckets):
                     N.run_ops(ops, n, self.bases, s, side=int(self._side.cuda_stream))
                     for bi in bks:
