@@ -299,6 +299,10 @@ __global__ void __launch_bounds__(256 * G) wgrad_kernel(const WgradArgs p) {
 
 }  // namespace
 
+// vt_wgrad_span.hip: stride-1 3x3 bf16 layers; -1 when it does not apply
+int vt_wgrad_span_dispatch(const vt_conv_desc* d, const void* x, const void* dz, float* dw, int32_t ldgw,
+                           void* stream);
+
 extern "C" int vt_conv_wgrad(const vt_conv_desc* d, const void* x, const void* dz, float* dw,
                              int32_t ldgw, void* stream) {
     VT_REQUIRE(d && x && dz && dw, VT_ERR_INVALID, "vt_conv_wgrad: null argument");
@@ -319,6 +323,10 @@ extern "C" int vt_conv_wgrad(const vt_conv_desc* d, const void* x, const void* d
     const long M = (long)d->B * d->Ho * d->Wo;
     VT_REQUIRE(in_elems < 0x7fffffffL && M * d->ldy < 0x7fffffffL, VT_ERR_UNSUPPORTED,
                "vt_conv_wgrad: tensor exceeds 2^31 elements");
+    {
+        const int rc = vt_wgrad_span_dispatch(d, x, dz, dw, ldgw, stream);
+        if (rc >= 0) return rc;
+    }
 
     WgradArgs a;
     memset(&a, 0, sizeof(a));

@@ -1,0 +1,348 @@
+// vt_wgrad_span.hip -- filter gradient of the stride-1 3x3 convolutions (bf16) with both
+// operands staged ONCE per pixel block for all nine taps.
+//
+//   dw[n][t][c] += sum_pixels dz[pix][n] * x[pix + tap_t][c]      (0 outside the image)
+//
+// (autograd backward of the nn.Conv2d inside ConvNormAct, reference components.py:26-35,
+// w.r.t. its weight.)  vt_wgrad.hip gives every (128 out x 128 (tap,in)) tile its own
+// workgroups, so a 3x3 layer pushes dz AND the tap-shifted x through the global->LDS path
+// nine times (64 FLOP per staged byte: bound by that path at ~460 TFLOP/s), and layers with
+// <= 64 channels fill a quarter of the tile.  Here a workgroup owns (32|64 out) x (32|64 in)
+// x ALL 9 taps (9 accumulator tiles per wave) and walks the pixels once:
+//   * Pixels are enumerated in PADDED coordinates: each image is (H+ph) x (W+pw) positions,
+//     the extra row(s)/column(s) are zero pixels (their LDS rows come from a zero page).  A
+//     tap is then a constant offset d_t = eh*(W+pw) + ew in that flat index -- the zero
+//     column to the right of row i is also the zero column to the left of row i+1, the zero
+//     row below image b also the one above image b+1 -- and no masks are needed anywhere.
+//     Cost: (H+ph)(W+pw)/(HW) more MFMA work (1.07 at 28x28, 1.15 at 14x14).
+//   * Per step of 32 positions one LDS-DMA instruction per wave brings 32 dz rows and one
+//     brings the 32 NEW x rows into a power-of-two ring that always holds positions
+//     [P + dmin, P + 32 + dmax + prefetch): 8 KB staged per 2.4 MFLOP (295 FLOP/B).
+//   * Fragments are formed by ds_read_b64_tr_b16 (both operands are pixel-major = K-strided);
+//     tap t reads the ring at row offset d_t - dmin.  Rows are 128 B (64 channels); the
+//     16-byte chunk index is XOR-ed with 2*((row>>1)&3) through the DMA source address, which
+//     makes any 8 consecutive rows hit 8 distinct 32-byte bank groups, so the shifted reads
+//     are conflict free for every tap.
+// The pixel range is split over blockIdx.y; partial tiles are staged through LDS into whole
+// rows and added with row-contiguous f32 atomics, as in vt_wgrad.hip.
+#include <stdlib.h>
+
+#include "vt_common.h"
+
+namespace {
+
+struct WsArgs {
+    const bf16_t* x;
+    const bf16_t* dz;
+    float* dw;
+    int B, H, W, Cin, ldx, Cout, ldy, ldgw;
+    int PH, PW, S, NP;       // padded rows / pitch / positions per image / total positions
+    int dmin, NH, RX;        // smallest tap offset, halo chunks, ring rows (power of two)
+    int tiles_n, tiles_c, chunk, ablate;
+    short o[9];              // d_t - dmin
+};
+
+__device__ __attribute__((aligned(16))) unsigned int vt_ws_zero16[4];
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ void glds16(unsigned long gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_base)
+        : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+struct Pos {  // a padded position, decomposed; advanced 32 positions per step
+    int b, i, j;
+    __device__ __forceinline__ void init(long P, int S, int PW) {
+        long bb = P / S;
+        long rem = P - bb * S;
+        if (rem < 0) rem += S, --bb;
+        b = (int)bb;
+        i = (int)(rem / PW);
+        j = (int)(rem - (long)i * PW);
+    }
+    __device__ __forceinline__ void advance32(int PH, int PW) {
+        j += 32;
+        while (j >= PW) j -= PW, ++i;
+        while (i >= PH) i -= PH, ++b;
+    }
+};
+
+constexpr int kDzSlot = 32 * 128;  // bytes: 32 positions x 64 channels
+
+// 8 waves: two tap groups (taps 0..4 and 5..8) x a 2 x 2 wave grid; FI x FJ 16x16 accumulator
+// tiles per wave and tap: tile = 32FI out x 32FJ in x 9 taps per workgroup.  ONE workgroup per CU
+// and launch: the atomic bytes of a launch are (#workgroups x tile bytes), and global float
+// atomics run at ~1.3 TB/s chip wide whatever else happens, so the tile is spread over as many
+// waves as the CU holds instead of giving each 4-wave group its own copy.
+// The four waves of tap group 0 bring in dz, those of group 1 the new x rows: one LDS-DMA
+// instruction and one position counter per wave and step.
+template <int FI, int FJ, int PD>
+__global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
+    constexpr int NS = PD + 1;
+    constexpr int NI = 32 * FI, NC = 32 * FJ;
+    constexpr int TG = 5;  // taps per group (the second group owns 4)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sDz = smem;                  // [NS][32 rows][128 B]
+    char* sX = smem + NS * kDzSlot;    // [RX rows][128 B]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tg = wave8 >> 2, wave = wave8 & 3;
+    const int wn = wave >> 1, wc = wave & 1;
+    const int ntl = tg ? 9 - TG : TG;  // taps this wave owns
+    const int tile_n = blockIdx.x % p.tiles_n, tile_c = blockIdx.x / p.tiles_n;
+    const int n0 = tile_n * NI, c0 = tile_c * NC;
+    const long Pbeg = (long)blockIdx.y * p.chunk;
+    const long Pend = min((long)p.NP, Pbeg + p.chunk);
+    if (Pbeg >= Pend) return;
+    const int nsteps = (int)((Pend - Pbeg + 31) / 32);
+
+    const unsigned long zero_src = (unsigned long)(const void*)vt_ws_zero16;
+    const unsigned dz_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)sDz;
+    const unsigned x_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)sX;
+    const unsigned xmask = (unsigned)p.RX * 128u - 1u;
+
+    // ---- DMA geometry: an instruction fills 8 rows x 128 B; lane l -> row l>>3, chunk slot l&7,
+    // and fetches source chunk (l&7) ^ 2*((row>>1)&3).  Wave w of a group owns rows 8w..8w+7 of
+    // each 32-row block (32-row blocks start at multiples of 8 in the ring).
+    const int r8 = lane >> 3;
+    const int srcc = (lane & 7) ^ (2 * ((r8 >> 1) & 3));  // (8w + r8)>>1 & 3 == (r8>>1)&3
+    const bool col_ok = tg ? (srcc * 8 < NC && c0 + srcc * 8 < p.Cin) : (srcc * 8 < NI && n0 + srcc * 8 < p.Cout);
+    const bf16_t* __restrict__ src_base = tg ? p.x + (c0 + srcc * 8) : p.dz + (n0 + srcc * 8);
+    const int src_ld = tg ? p.ldx : p.ldy;
+    Pos ps;
+    long Ps = Pbeg + (tg ? p.dmin : 0) + 8 * wave + r8;  // this lane's stream position
+    ps.init(Ps, p.S, p.PW);
+    int nissued = 0;  // DMA instructions this wave has issued (x: ring chunk index)
+
+    // dz rows beyond the split's end must be zero; x rows may be anything there (times dz = 0)
+#define VT_WS_ISSUE(dst)                                                                          \
+    do {                                                                                          \
+        const bool ok = col_ok && (tg || Ps < Pend) && (unsigned)ps.b < (unsigned)p.B && ps.i < p.H && ps.j < p.W; \
+        const long pix = ((long)ps.b * p.H + ps.i) * p.W + ps.j;                                  \
+        glds16(ok ? (unsigned long)(src_base + pix * src_ld) : zero_src, (dst) + (unsigned)wave * 1024u); \
+        ++nissued;                                                                                \
+        Ps += 32;                                                                                 \
+        ps.advance32(p.PH, p.PW);                                                                 \
+    } while (0)
+#define VT_WS_ISSUE_STEP(slot)                                                                    \
+    do {                                                                                          \
+        if (tg)                                                                                   \
+            VT_WS_ISSUE(x_base + (((unsigned)nissued * 4096u) & xmask));                          \
+        else                                                                                      \
+            VT_WS_ISSUE(dz_base + (unsigned)((slot)*kDzSlot));                                    \
+    } while (0)
+
+    // ---- fragment addressing -----------------------------------------------------------------
+    // ds_read_b64_tr_b16: lane 4q+pp of a 16-lane group addresses row q, columns 4pp..4pp+3 of a
+    // 4 x 16 block and receives column u for the block's 4 rows: fragment element e<4 <-> position
+    // 4g+e, e>=4 <-> 16+4g+(e-4), for BOTH operands.
+    const int g = lane >> 4, u = lane & 15, q = u >> 2, pp = u & 3;
+    const int rowlo = 4 * g + q;
+    unsigned a_off[FI];  // dz slot-relative byte offsets
+#pragma unroll
+    for (int i = 0; i < FI; ++i) {
+        const int ch = ((wn * 16 * FI + 16 * i) >> 3) + (pp >> 1);
+        a_off[i] = (unsigned)(rowlo * 128 + ((ch ^ (2 * ((rowlo >> 1) & 3))) << 4) + 8 * (pp & 1));
+    }
+    unsigned b_off[TG];  // ring-relative byte offsets of the j = 0 fragment at step 0, per owned tap
+#pragma unroll
+    for (int tt = 0; tt < TG; ++tt) {
+        const int t = min(tg * TG + tt, 8);
+        const int row = rowlo + p.o[t];
+        const int ch = ((wc * 16 * FJ) >> 3) + (pp >> 1);
+        b_off[tt] = (unsigned)(row * 128 + ((ch ^ (2 * ((row >> 1) & 3))) << 4) + 8 * (pp & 1));
+    }
+
+    f32x4 acc[TG][FI][FJ];
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int i = 0; i < FI; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: halo chunks (x waves), then PD steps ahead -----------------------------------
+    if (tg)
+        for (int h = 0; h < p.NH; ++h) VT_WS_ISSUE(x_base + (((unsigned)nissued * 4096u) & xmask));
+#pragma unroll
+    for (int s = 0; s < PD; ++s)
+        if (s < nsteps) VT_WS_ISSUE_STEP(s);
+
+    int cur = 0, nxt = PD % NS;
+    for (int s = 0; s < nsteps; ++s) {
+        // dz(s) and x chunk s+NH must have landed; the PD-1 younger steps (1 instruction per wave
+        // each) may stay in flight
+        const int younger = min(PD - 1, nsteps - 1 - s);
+        if (younger >= 2)
+            vm_wait<2>();
+        else if (younger == 1)
+            vm_wait<1>();
+        else
+            vm_wait<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + PD < nsteps) VT_WS_ISSUE_STEP(nxt);
+
+        const char* dzs = sDz + cur * kDzSlot;
+        bf16x8 af[FI];
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(dzs + a_off[i]));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(dzs + a_off[i] + 16 * 128));
+            af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+        const unsigned sb = (unsigned)s * 4096u;
+#pragma unroll
+        for (int tt = 0; tt < TG; ++tt) {
+            if (tt < ntl) {
+                const unsigned lo_o = (sb + b_off[tt]) & xmask;
+                const unsigned hi_o = (lo_o + 16u * 128u) & xmask;
+                bf16x8 bf[FJ];
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) {
+                    // the next 16 input channels sit one 32-byte group over: chunk index ^ 2
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sX + (lo_o ^ (32u * j))));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sX + (hi_o ^ (32u * j))));
+                    bf[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+#pragma unroll
+                for (int i = 0; i < FI; ++i)
+#pragma unroll
+                    for (int j = 0; j < FJ; ++j)
+                        acc[tt][i][j] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[tt][i][j], 0, 0, 0);
+            }
+        }
+        cur = (cur + 1 == NS) ? 0 : cur + 1;
+        nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+    }
+#undef VT_WS_ISSUE
+#undef VT_WS_ISSUE_STEP
+
+    // ---- combine: tap pair (tt, TG+tt) per round; each group stages its NI x NC tile in its own
+    // LDS image, then all 512 threads add whole rows with f32 atomics ------------------------------
+    constexpr int PITCH = NC + 4;
+    constexpr int IMG = NI * PITCH;
+    float* sAcc = (float*)smem;
+#pragma unroll
+    for (int tt = 0; tt < TG; ++tt) {
+        __syncthreads();
+        if (tt < ntl) {
+#pragma unroll
+            for (int i = 0; i < FI; ++i)
+#pragma unroll
+                for (int j = 0; j < FJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        sAcc[tg * IMG + (wn * 16 * FI + 16 * i + 4 * g + r) * PITCH + wc * 16 * FJ + 16 * j + u] =
+                            acc[tt][i][j][r];
+        }
+        __syncthreads();
+        const int nimg = (TG + tt < 9) ? 2 : 1;
+        for (int idx = tid; idx < nimg * NI * NC; idx += 512) {
+            const int img = idx / (NI * NC), e = idx % (NI * NC);
+            const int n = e / NC, c = e % NC;
+            const int t = img * TG + tt;
+            if (n0 + n < p.Cout && c0 + c < p.Cin && !p.ablate)
+                atomicAdd(p.dw + ((long)(n0 + n) * p.ldgw + (long)t * p.Cin + c0 + c), sAcc[img * IMG + n * PITCH + c]);
+        }
+    }
+}
+
+template <int FI, int FJ>
+int launch_ws(const WsArgs& a, long split, hipStream_t st) {
+    constexpr int PD = 2;
+    const int rings = (PD + 1) * kDzSlot + a.RX * 128;
+    const int image = 2 * 32 * FI * (32 * FJ + 4) * 4;
+    const int smem = rings > image ? rings : image;
+    auto kern = wgrad_span_kernel<FI, FJ, PD>;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) {
+            vt_set_error("vt_conv_wgrad(span): cannot raise dynamic LDS: %s", hipGetErrorString(e));
+            return VT_ERR_HIP;
+        }
+        raised = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_n * a.tiles_c), (unsigned)split), dim3(512), smem, st, a);
+    VT_CHECK_LAUNCH("vt_conv_wgrad(span)");
+    return VT_OK;
+}
+
+}  // namespace
+
+// returns -1 when this kernel does not apply (the caller then uses the general kernel)
+int vt_wgrad_span_dispatch(const vt_conv_desc* d, const void* x, const void* dz, float* dw, int32_t ldgw,
+                           void* stream) {
+    static const int enabled = getenv("VT_WGRAD_SPAN") ? atoi(getenv("VT_WGRAD_SPAN")) : 1;
+    if (!enabled) return -1;
+    if (d->dtype != VT_BF16 || d->ntaps != 9 || d->sh != 1 || d->sw != 1 || d->Ho != d->Hi || d->Wo != d->Wi)
+        return -1;
+    int ph = 0, pw = 0;
+    for (int t = 0; t < 9; ++t) {
+        const int eh = d->h0 + d->dh[t], ew = d->w0 + d->dw[t];
+        ph = abs(eh) > ph ? abs(eh) : ph;
+        pw = abs(ew) > pw ? abs(ew) : pw;
+    }
+    WsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = (const bf16_t*)x, a.dz = (const bf16_t*)dz, a.dw = dw;
+    a.B = d->B, a.H = d->Hi, a.W = d->Wi, a.Cin = d->Cin, a.ldx = d->ldx, a.Cout = d->Cout, a.ldy = d->ldy;
+    a.ldgw = ldgw;
+    a.PH = d->Hi + ph, a.PW = d->Wi + pw;
+    a.S = a.PH * a.PW;
+    const long NP = (long)d->B * a.S;
+    if (NP > 0x7ffffff0L) return -1;
+    a.NP = (int)NP;
+    int dmin = 1 << 30, dmax = -(1 << 30), off[9];
+    for (int t = 0; t < 9; ++t) {
+        off[t] = (d->h0 + d->dh[t]) * a.PW + (d->w0 + d->dw[t]);
+        dmin = off[t] < dmin ? off[t] : dmin;
+        dmax = off[t] > dmax ? off[t] : dmax;
+    }
+    a.dmin = dmin;
+    for (int t = 0; t < 9; ++t) a.o[t] = (short)(off[t] - dmin);
+    constexpr int PD = 2;
+    a.NH = (31 + dmax - dmin) / 32;
+    int rx = 64;
+    while (rx < 32 * (a.NH + PD + 1)) rx *= 2;
+    if (rx > 512) return -1;  // wide maps: the ring would not leave room for two workgroups per CU
+    a.RX = rx;
+    const int FI = d->Cout > 32 ? 2 : 1, FJ = d->Cin > 32 ? 2 : 1;
+    a.tiles_n = (d->Cout + 32 * FI - 1) / (32 * FI);
+    a.tiles_c = (d->Cin + 32 * FJ - 1) / (32 * FJ);
+    // pixel split: one 8-wave workgroup per CU, at least 16 steps each (the halo warm-up is NH chunks)
+    static const int target = getenv("VT_WGRAD_SPAN_TARGET") ? atoi(getenv("VT_WGRAD_SPAN_TARGET")) : 256;
+    const long tiles = (long)a.tiles_n * a.tiles_c;
+    long split = target / tiles;
+    const long max_split = (NP + 511) / 512;
+    if (split > max_split) split = max_split;
+    if (split < 1) split = 1;
+    long chunk = (NP + split - 1) / split;
+    chunk = (chunk + 31) / 32 * 32;
+    split = (NP + chunk - 1) / chunk;
+    a.chunk = (int)chunk;
+    static const int ablate = getenv("VT_WGRAD_ABLATE") ? atoi(getenv("VT_WGRAD_ABLATE")) : 0;  // timing experiments
+    a.ablate = ablate;
+    hipStream_t st = (hipStream_t)stream;
+    if (FI == 2 && FJ == 2) return launch_ws<2, 2>(a, split, st);
+    if (FI == 2) return launch_ws<2, 1>(a, split, st);
+    if (FJ == 2) return launch_ws<1, 2>(a, split, st);
+    return launch_ws<1, 1>(a, split, st);
+}
