@@ -64,7 +64,7 @@ def main():
     if len(sys.argv) > 2:  # custom layers: Cin,Cout,k,s,H ...
         layers = [tuple(int(v) for v in a.split(",")) for a in sys.argv[2:]]
     for Cin, Cout, k, s, H in layers:
-        d, Ho = desc_for(B, Cin, Cout, k, s, H, N.VT_CONV_STATS)
+        d, Ho = desc_for(B, Cin, Cout, k, s, H, 0 if os.environ.get("VT_BENCH_NOSTATS") else N.VT_CONV_STATS)
         x = torch.randn(B, H, H, Cin, device="cuda").to(torch.bfloat16)
         w = (torch.randn(Cout, k * k, Cin, device="cuda") * (2.0 / (k * k * Cin)) ** 0.5).to(torch.bfloat16)
         y = torch.empty(B, Ho, Ho, Cout, device="cuda", dtype=torch.bfloat16)

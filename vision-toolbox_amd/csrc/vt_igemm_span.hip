@@ -36,6 +36,20 @@ namespace {
 constexpr int kTapBytes = 32 * 16;  // ntaps <= 32 on this path
 
 __device__ __attribute__((aligned(16))) unsigned int vt_span_zero16[4];
+#ifdef VT_SPAN_STAMPS  // diagnostic build only: per-workgroup phase clocks (never in the shipped library)
+__device__ unsigned long long vt_span_stamps[8192 * 4];
+__device__ unsigned long long vt_span_loop[8192 * 4];
+#define VT_STAMP(k)                                                                  \
+    do {                                                                             \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) vt_span_stamps[blockIdx.x * 4 + (k)] = wall_clock64(); \
+    } while (0)
+#define VT_LOOP_CLK(var) unsigned long long var = clock64()
+#define VT_LOOP_ACC(k, a, b) loop_acc[k] += (b) - (a)
+#else
+#define VT_STAMP(k) do { } while (0)
+#define VT_LOOP_CLK(var) do { } while (0)
+#define VT_LOOP_ACC(k, a, b) do { } while (0)
+#endif
 
 __device__ __forceinline__ int swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
 
@@ -57,6 +71,29 @@ __device__ __forceinline__ void vm_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// counted wait with a run-time count (wave-uniform): vmcnt takes an immediate
+__device__ __forceinline__ void vm_wait_dyn(int n) {
+    switch (n) {
+        case 0: vm_wait<0>(); break;
+        case 1: vm_wait<1>(); break;
+        case 2: vm_wait<2>(); break;
+        case 3: vm_wait<3>(); break;
+        case 4: vm_wait<4>(); break;
+        case 5: vm_wait<5>(); break;
+        case 6: vm_wait<6>(); break;
+        case 7: vm_wait<7>(); break;
+        case 8: vm_wait<8>(); break;
+        case 9: vm_wait<9>(); break;
+        case 10: vm_wait<10>(); break;
+        case 11: vm_wait<11>(); break;
+        case 12: vm_wait<12>(); break;
+        case 13: vm_wait<13>(); break;
+        case 14: vm_wait<14>(); break;
+        case 15: vm_wait<15>(); break;
+        default: vm_wait<16>(); break;
+    }
+}
+
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 template <typename T>
@@ -76,30 +113,32 @@ __device__ __forceinline__ void mma<float>(const uint4& a, const uint4& b, f32x4
 
 // LDS map (bytes): [taps 512][row masks BM*4][row output pixel BM*4][filter ring 3 x BROWS*64]
 //                  [zero 16 .. 64][span slot 0][span slot 1 (only when Cin spans > 1 chunk)]
-template <int BM, int BN>
+template <int BM, int BN, int PD>
 struct SpanLds {
     static constexpr int BROWS = BN < 64 ? 64 : BN;
     static constexpr int kMask = kTapBytes;
     static constexpr int kPo = kMask + BM * 4;
     static constexpr int kB = kPo + BM * 4;
-    static constexpr int kZero = kB + 3 * BROWS * 64;
+    static constexpr int kZero = kB + (PD + 1) * BROWS * 64;
     static constexpr int kA = kZero + 64;
-    __host__ __device__ static constexpr int bytes(int ita, int nslots) { return kA + nslots * ita * 64 * 64; }
+    // ita DMA instructions per wave and chunk: nw waves x 16 rows x 64 B each
+    __host__ __device__ static constexpr int bytes(int ita, int nslots, int nw = 4) { return kA + nslots * ita * nw * 16 * 64; }
 };
 
 // ita: span DMA instructions per wave per chunk (span = 64*ita rows >= BM + dmax - dmin)
-template <typename T, int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(256, 2) span_kernel(const IgemmArgs p, const int dmin, const int ita) {
-    constexpr int NT = 256;
+template <typename T, int BM, int BN, int WM, int WN, int PD>
+__global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel(const IgemmArgs p, const int dmin, const int ita) {
+    constexpr int NW = WM * WN;  // waves: 4, or 8 for the 256 x 128 tile (wave tile 64 x 64, 16 waves per CU)
+    constexpr int NT = 64 * NW;
     constexpr int EPC = 16 / sizeof(T);
     constexpr int CH = 4 * EPC;  // channels per chunk (64-byte rows)
     constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
-    using L = SpanLds<BM, BN>;
+    using L = SpanLds<BM, BN, PD>;
     constexpr int BROWS = L::BROWS;
-    constexpr int ITB = BROWS / 64;  // filter DMA instructions per wave per step
+    constexpr int ITB = BROWS / (16 * NW);  // filter DMA instructions per wave per step
     constexpr int BSLOT = BROWS * 4;
-    constexpr int PD = 2, NSB = PD + 1;
-    static_assert(WM * WN == 4 && TM % 16 == 0 && TN % 16 == 0, "tile shape");
+    constexpr int NSB = PD + 1;
+    static_assert((NW == 4 || NW == 8) && ITB >= 1 && TM % 16 == 0 && TN % 16 == 0, "tile shape");
     static_assert(L::kZero >= FM * 1024, "zero block must sit above the fragment offsets");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -109,7 +148,7 @@ __global__ void __launch_bounds__(256, 2) span_kernel(const IgemmArgs p, const i
     uint4* sB = (uint4*)(smem + L::kB);  // [NSB][BSLOT]
     uint4* sZ = (uint4*)(smem + L::kZero);
     uint4* sA = (uint4*)(smem + L::kA);  // [1 or 2][aslot]
-    const int aslot = ita * 256;         // uint4 per span slot
+    const int aslot = ita * NW * 64;     // uint4 per span slot
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -123,6 +162,7 @@ __global__ void __launch_bounds__(256, 2) span_kernel(const IgemmArgs p, const i
     const int tm = xcd * p.chunk + ml;
     if (ml >= p.chunk || tm >= p.tiles_m) return;
 
+    VT_STAMP(0);
     const int W = p.Wi, H = p.Hi, HW = H * W;
     const long m0 = (long)tm * BM;
     if (tid < p.ntaps) {
@@ -139,16 +179,16 @@ __global__ void __launch_bounds__(256, 2) span_kernel(const IgemmArgs p, const i
     // ---- DMA geometry ---------------------------------------------------------------------
     // an instruction fills 16 rows x 64 B; lane l owns row 16j + (l>>2), chunk (l&3)^swz(row)
     const int cj = (lane & 3) ^ ((0x1320 >> (((lane >> 4) & 3) * 4)) & 3);
-    // span row r = 16*(wave + 4i) + (lane>>2) holds input pixel m0 + dmin + r (zero page outside)
+    // span row r = 16*(wave + NW*i) + (lane>>2) holds input pixel m0 + dmin + r (zero page outside)
     const long pix0 = m0 + dmin + 16 * wave + (lane >> 2);
     const unsigned long a_src0 = (unsigned long)(xg + (pix0 * p.ldx + cj * EPC));
-    const unsigned long a_istep = 64ul * (unsigned long)p.ldx * sizeof(T);
+    const unsigned long a_istep = 16ul * NW * (unsigned long)p.ldx * sizeof(T);
     unsigned long bbase[ITB];
     bool bvalid[ITB];
 #pragma unroll
     for (int i = 0; i < ITB; ++i) {
-        const int n = tn * BN + 16 * (wave + 4 * i) + (lane >> 2);
-        bvalid[i] = n < p.Cout && 16 * (wave + 4 * i) < BN;
+        const int n = tn * BN + 16 * (wave + NW * i) + (lane >> 2);
+        bvalid[i] = n < p.Cout && 16 * (wave + NW * i) < BN;
         bbase[i] = (unsigned long)(wg + ((long)(bvalid[i] ? n : 0) * p.ldw + cj * EPC));
     }
 
@@ -167,9 +207,9 @@ __global__ void __launch_bounds__(256, 2) span_kernel(const IgemmArgs p, const i
     do {                                                                                     \
         const unsigned long cofs = (unsigned long)(ic) * (CH * sizeof(T));                   \
         for (int i = 0; i < ita; ++i) {                                                      \
-            const long pix = pix0 + 64l * i;                                                 \
+            const long pix = pix0 + 16l * NW * i;                                            \
             const unsigned long src = (pix >= 0 && pix < p.M) ? a_src0 + i * a_istep + cofs : zero_src; \
-            glds16(src, a_base + (unsigned)(((sl)*aslot + (wave + 4 * i) * 64) * 16));       \
+            glds16(src, a_base + (unsigned)(((sl)*aslot + (wave + NW * i) * 64) * 16));      \
         }                                                                                    \
     } while (0)
     // filter slice of step (chunk ic, tap it): rows n, K offset it*Cin + ic*CH
@@ -178,7 +218,7 @@ __global__ void __launch_bounds__(256, 2) span_kernel(const IgemmArgs p, const i
         const long koff = ((long)(it)*p.Cin + (long)(ic)*CH) * (long)sizeof(T);            \
         _Pragma("unroll") for (int i = 0; i < ITB; ++i) {                                  \
             const unsigned long ps = bvalid[i] ? bbase[i] + koff : zero_src;               \
-            glds16(ps, b_base + (unsigned)(((bslot)*BSLOT + (wave + 4 * i) * 64) * 16));   \
+            glds16(ps, b_base + (unsigned)(((bslot)*BSLOT + (wave + NW * i) * 64) * 16));  \
         }                                                                                  \
     } while (0)
 
@@ -212,66 +252,80 @@ __global__ void __launch_bounds__(256, 2) span_kernel(const IgemmArgs p, const i
     }
     __syncthreads();  // tap table, row masks, zero block
 
+    VT_STAMP(1);
     unsigned fmask[FM];
 #pragma unroll
     for (int i = 0; i < FM; ++i) fmask[i] = sMask[wm * TM + i * 16 + (lane & 15)];
 
     int ic = 0, it = 0;  // (chunk, tap) of the step being computed
     int bcur = 0, bnxt = PD % NSB;
-    bool a_young = false;  // a span was issued in the previous step
+    int a_age = 0;  // steps since the last span was issued (0: none yet)
+#ifdef VT_SPAN_STAMPS
+    unsigned long long loop_acc[4] = {0, 0, 0, 0};
+#endif
     for (int s = 0; s < nsteps; ++s) {
-        // Retire this step's filter slice.  VM operations retire in issue order, so everything
-        // older -- in particular the span this chunk reads -- is complete as well.  Younger:
-        // the slice of the next step and, if one was issued in the previous step, the next
-        // chunk's span (with ntaps == 1 that span is needed NOW, so only the slice issued after
-        // it may stay in flight).
-        if (s + 1 >= nsteps) {
-            vm_wait<0>();
-        } else if (a_young && p.ntaps > 1) {
-            switch (ita) {
-                case 2: vm_wait<ITB + 2>(); break;
-                case 3: vm_wait<ITB + 3>(); break;
-                case 4: vm_wait<ITB + 4>(); break;
-                case 5: vm_wait<ITB + 5>(); break;
-                case 6: vm_wait<ITB + 6>(); break;
-                case 7: vm_wait<ITB + 7>(); break;
-                default: vm_wait<ITB + 8>(); break;
-            }
-        } else {
-            vm_wait<ITB>();
+        VT_LOOP_CLK(c0);
+        // Retire this step's filter slice B(s).  VM operations retire in issue order, so everything
+        // older is complete as well.  Younger than B(s): the slices of the next nb steps and, if it
+        // was issued fewer than PD steps ago, the next chunk's span A' (issued just before the
+        // slice of its step).  A' is needed at the first tap of its chunk; if that is NOW (few taps),
+        // only the slices issued after A' may stay in flight.
+        const int nb = min(PD - 1, nsteps - 1 - s);
+        int allowed = nb * ITB;
+        if (a_age >= 1 && a_age <= PD - 1) {
+            if (it == 0 && ic > 0 && a_age == p.ntaps)
+                allowed = min(a_age, nb) * ITB;
+            else
+                allowed += ita;
         }
+        vm_wait_dyn(allowed);
+        VT_LOOP_CLK(c1);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        VT_LOOP_CLK(c2);
         // issue: next chunk's span at the first tap of a chunk, then the slice of step s+PD
-        a_young = false;
+        a_age = a_age ? a_age + 1 : 0;
         if (it == 0 && ic + 1 < nchunks) {
             VT_ISSUE_A((ic + 1) & 1, ic + 1);
-            a_young = true;
+            a_age = 1;
         }
         if (s + PD < nsteps) {
             VT_ISSUE_B(bnxt, ic_n, it_n);
             if (++it_n == p.ntaps) it_n = 0, ++ic_n;
         }
 
+        VT_LOOP_CLK(c3);
         {
             const int d = __builtin_amdgcn_readfirstlane(sTap[it].x);
             const int srow0 = wm * TM + (lane & 15) + d;
             const uint4* A = sA + (ic & 1) * aslot + srow0 * 4 + ((lane >> 4) ^ swz(srow0));
             const uint4* Bt = sB + bcur * BSLOT + wn * TN * 4 + b_lane;
             uint4 af[FM], bf[FN];
+            // filter fragments first: every MFMA of the first A row needs them
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bf[j] = Bt[j * 64];
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 // (sZ - i*64)[i*64] == sZ[0]: the constant stays in the instruction's offset field
                 const uint4* src = ((fmask[i] >> it) & 1u) ? A : sZ - i * 64;
                 af[i] = src[i * 64];
             }
-#pragma unroll
-            for (int j = 0; j < FN; ++j) bf[j] = Bt[j * 64];
+            // all fragment reads are issued before the first MFMA (the scheduler otherwise funnels
+            // the A fragments through one register quad: read, wait lgkmcnt(0), 4 MFMAs, read, ...)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) mma<T>(af[i], bf[j], acc[i][j]);
         }
+#ifdef VT_SPAN_STAMPS
+        asm volatile("s_nop 0" ::: "memory");
+        unsigned long long c4 = clock64();
+        VT_LOOP_ACC(0, c0, c1);
+        VT_LOOP_ACC(1, c1, c2);
+        VT_LOOP_ACC(2, c2, c3);
+        VT_LOOP_ACC(3, c3, c4);
+#endif
         if (++it == p.ntaps) it = 0, ++ic;
         bcur = (bcur + 1 == NSB) ? 0 : bcur + 1;
         bnxt = (bnxt + 1 == NSB) ? 0 : bnxt + 1;
@@ -279,6 +333,11 @@ __global__ void __launch_bounds__(256, 2) span_kernel(const IgemmArgs p, const i
 #undef VT_ISSUE_A
 #undef VT_ISSUE_B
     __syncthreads();  // every wave is done with the rings; they become the staging windows
+    VT_STAMP(2);
+#ifdef VT_SPAN_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 8192)
+        for (int k = 0; k < 4; ++k) vt_span_loop[blockIdx.x * 4 + k] = loop_acc[k];
+#endif
 
     // ---- epilogue: per wave, 16-row slabs through a private LDS window --------------------------
     constexpr int PITCH = TN + EPC;          // elements; +16 B keeps the 16-byte reads aligned
@@ -286,7 +345,7 @@ __global__ void __launch_bounds__(256, 2) span_kernel(const IgemmArgs p, const i
     constexpr int RPP = 64 / CPRW;           // slab rows per read pass
     constexpr int NPASS = (16 + RPP - 1) / RPP;
     static_assert(CPRW <= 64, "slab read-out shape");
-    static_assert(4 * 16 * PITCH * (int)sizeof(T) <= 3 * BROWS * 64 + 64 + 2 * 4096,
+    static_assert(NW * 16 * PITCH * (int)sizeof(T) <= (PD + 1) * BROWS * 64 + 64 + 2 * 4096,
                   "staging windows exceed the filter ring + the smallest span slot");
     T* sW = (T*)(smem + L::kB) + wave * 16 * PITCH;
 
@@ -367,41 +426,109 @@ __global__ void __launch_bounds__(256, 2) span_kernel(const IgemmArgs p, const i
             }
         }
     }
+    VT_STAMP(3);
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
-int launch_span(IgemmArgs& a, int dmin, int span, hipStream_t st) {
-    using L = SpanLds<BM, BN>;
-    const int ita = (span + 63) / 64;
-    if (ita < 2 || ita > 8) return -1;
+template <typename L>
+bool smem_ok(int ita, int nw, int nchunks) { return L::bytes(ita, nchunks > 1 ? 2 : 1, nw) <= 160 * 1024; }
+
+template <typename T, int BM, int BN, int WM, int WN, int PD>
+int launch_span_pd(IgemmArgs& a, int dmin, int span, hipStream_t st) {
+    using L = SpanLds<BM, BN, PD>;
+    constexpr int NW = WM * WN;
+    const int ita = (span + 16 * NW - 1) / (16 * NW);
+    if (ita < 1 || ita * NW > 48 || smem_ok<L>(ita, NW, a.Cin / (64 / (int)sizeof(T))) == false) return -1;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.Cout + BN - 1) / BN;
     a.chunk = (a.tiles_m + 7) / 8;
     const int nchunks = a.Cin / (64 / (int)sizeof(T));
-    const int smem = L::bytes(ita, nchunks > 1 ? 2 : 1);
+    const int smem = L::bytes(ita, nchunks > 1 ? 2 : 1, NW);
     const long blocks = (long)8 * a.chunk * a.tiles_n;
-    auto kern = span_kernel<T, BM, BN, WM, WN>;
+    auto kern = span_kernel<T, BM, BN, WM, WN, PD>;
     static bool raised = false;
     if (!raised) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           L::bytes(8, 2));
+                                           160 * 1024);
         if (e != hipSuccess) {
-            vt_set_error("vt_conv_igemm(span): cannot raise dynamic LDS to %d: %s", L::bytes(8, 2),
+            vt_set_error("vt_conv_igemm(span): cannot raise dynamic LDS to %d: %s", 160 * 1024,
                          hipGetErrorString(e));
             return VT_ERR_HIP;
         }
         raised = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, st, a, dmin, ita);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NW), smem, st, a, dmin, ita);
     VT_CHECK_LAUNCH("vt_conv_igemm(span)");
+#ifdef VT_SPAN_STAMPS
+    {
+        static int calls = 0;
+        if (++calls == 20) {  // a warm launch
+            (void)hipStreamSynchronize(st);
+            static unsigned long long h[8192 * 4];
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(vt_span_stamps), sizeof(h));
+            const long nb = blocks < 8192 ? blocks : 8192;
+            unsigned long long t0 = ~0ull, t1 = 0;
+            double ph[3] = {0, 0, 0};
+            for (long b = 0; b < nb; ++b) {
+                if (h[b * 4] < t0) t0 = h[b * 4];
+                if (h[b * 4 + 3] > t1) t1 = h[b * 4 + 3];
+                for (int k = 0; k < 3; ++k) ph[k] += (double)(h[b * 4 + k + 1] - h[b * 4 + k]);
+            }
+            fprintf(stderr, "[span stamps] blocks %ld span %.2f us | avg per WG: prologue %.2f us, loop %.2f us, epilogue %.2f us\n",
+                    nb, (t1 - t0) * 0.01, ph[0] / nb * 0.01, ph[1] / nb * 0.01, ph[2] / nb * 0.01);
+            static unsigned long long hl[8192 * 4];
+            (void)hipMemcpyFromSymbol(hl, HIP_SYMBOL(vt_span_loop), sizeof(hl));
+            double la[4] = {0, 0, 0, 0};
+            for (long b = 0; b < nb; ++b)
+                for (int k = 0; k < 4; ++k) la[k] += (double)hl[b * 4 + k];
+            fprintf(stderr, "[span stamps] loop cycles per WG (wave 0, shader clock): vmwait %.0f barrier %.0f issue %.0f reads+mfma %.0f\n",
+                    la[0] / nb, la[1] / nb, la[2] / nb, la[3] / nb);
+            // start-time histogram: how many rounds
+            int late = 0;
+            for (long b = 0; b < nb; ++b) late += (h[b * 4] - t0) * 0.01 > 5.0;
+            fprintf(stderr, "[span stamps] workgroups starting > 5 us after the first: %d\n", late);
+        }
+    }
+#endif
     return VT_OK;
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_span(IgemmArgs& a, int dmin, int span, hipStream_t st) {
+    // three filter slices in flight when the step count makes it worthwhile and two workgroups
+    // still fit a CU (VT_SPAN_PD=2/3 overrides)
+    static const int pd_env = getenv("VT_SPAN_PD") ? atoi(getenv("VT_SPAN_PD")) : 0;
+    constexpr int NW = WM * WN;
+    const int ita = (span + 16 * NW - 1) / (16 * NW);
+    const int nchunks = a.Cin / (64 / (int)sizeof(T));
+    const bool fits3 = 2 * SpanLds<BM, BN, 3>::bytes(ita, nchunks > 1 ? 2 : 1, NW) <= 160 * 1024;
+    const bool pd3 = pd_env ? pd_env == 3 : (fits3 && nchunks * a.ntaps >= 6);
+    if (pd3) return launch_span_pd<T, BM, BN, WM, WN, 3>(a, dmin, span, st);
+    return launch_span_pd<T, BM, BN, WM, WN, 2>(a, dmin, span, st);
 }
 
 template <typename T, int BM>
 int launch_span_bn(IgemmArgs& a, int dmin, int span, hipStream_t st) {
-    if (a.Cout > 64) return launch_span<T, BM, 128, 2, 2>(a, dmin, span, st);
-    if (a.Cout > 32) return launch_span<T, BM, 64, 4, 1>(a, dmin, span, st);
-    return launch_span<T, BM, 32, 4, 1>(a, dmin, span, st);
+    if constexpr (BM == 512) {
+        // 8 waves of 128 x 64: the filter slices (the larger part of the staged bytes) are fetched
+        // once per 512 pixels instead of once per 256
+        return launch_span<T, BM, 128, 4, 2>(a, dmin, span, st);
+    } else if constexpr (BM == 224) {
+        // 7 x 32 rows: 2 x 2 waves of 112 x BN/2 for every width
+        if (a.Cout > 64) return launch_span<T, BM, 128, 2, 2>(a, dmin, span, st);
+        if (a.Cout > 32) return launch_span<T, BM, 64, 2, 2>(a, dmin, span, st);
+        return launch_span<T, BM, 32, 2, 2>(a, dmin, span, st);
+    } else {
+        if (a.Cout > 64) {
+            // 256 x 128 tile: 4 waves of 128 x 64 (VT_SPAN_WAVES=8: 8 waves of 64 x 64; measured equal)
+            static const int waves = getenv("VT_SPAN_WAVES") ? atoi(getenv("VT_SPAN_WAVES")) : 4;
+            if constexpr (BM == 256 && sizeof(T) == 2) {
+                if (waves == 8) return launch_span<T, BM, 128, 4, 2>(a, dmin, span, st);
+            }
+            return launch_span<T, BM, 128, 2, 2>(a, dmin, span, st);
+        }
+        if (a.Cout > 32) return launch_span<T, BM, 64, 4, 1>(a, dmin, span, st);
+        return launch_span<T, BM, 32, 4, 1>(a, dmin, span, st);
+    }
 }
 
 }  // namespace
@@ -427,9 +554,24 @@ int vt_span_dispatch(IgemmArgs& a, int dtype, void* stream) {
         // 128-row variant for <= 64 output channels and fall back to the general kernel's
         // 128x128 tiles above that (measured faster there: 81 vs 97 us on 512->512 3x3 @7x7).
         // VT_IGEMM_SPAN=2 forces this kernel wherever it applies, =3 also forces 256-row tiles (tests).
-        const long tiles256 = (long)((a.M + 255) / 256) * ((a.Cout + 127) / 128);
+        const long tiles_n = (a.Cout + 127) / 128;
+        const long tiles256 = (long)((a.M + 255) / 256) * tiles_n;
         if (tiles256 >= 384 || enabled >= 3) {
-            const int rc = launch_span_bn<bf16_t, 256>(a, dmin, 256 + dmax - dmin, st);
+            // Two workgroups fit a CU (512 slots).  With batch 256 the pixel counts are 2^k * 49, so
+            // 256-row tiles often end in a thin last round (784 tiles = 1.53 rounds); 224-row
+            // tiles divide those counts exactly (896 tiles = 1.75 rounds of 7/8 the length).
+            // Pick the height with the smaller rounds x height (VT_SPAN_BM=256/224 overrides).
+            static const int bm_env = getenv("VT_SPAN_BM") ? atoi(getenv("VT_SPAN_BM")) : 0;
+            const long t224 = (long)((a.M + 223) / 224) * tiles_n;
+            const long c256 = (tiles256 + 511) / 512 * 256, c224 = (t224 + 511) / 512 * 224;
+            // (only the 128-wide tiles gain: the narrow ones are bound by their epilogue/HBM traffic)
+            const bool use224 = bm_env ? bm_env == 224 : (c224 < c256 && a.Cout > 64);
+            if (bm_env == 512 && a.Cout > 64) {
+                const int rc = launch_span_bn<bf16_t, 512>(a, dmin, 512 + dmax - dmin, st);
+                if (rc != -1) return rc;
+            }
+            const int rc = use224 ? launch_span_bn<bf16_t, 224>(a, dmin, 224 + dmax - dmin, st)
+                                  : launch_span_bn<bf16_t, 256>(a, dmin, 256 + dmax - dmin, st);
             if (rc != -1) return rc;
         }
         if (a.Cout > 64 && enabled < 2) return -1;
