@@ -184,7 +184,7 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = args.batch * world * args.steps / elapsed
-        # dominant kernel: span_kernel<bf16,256,128> (vt_igemm_span.hip) on the stride-1 3x3 convs and
+        # dominant kernel: span_kernel<bf16,224,128> (vt_igemm_span.hip; 224-row tiles at this pixel count) on the stride-1 3x3 convs and
         # their data gradients; roofline on the layer shape with the largest share of the step
         layers = [conv_roofline(args.batch, 128, 28, N.VT_BF16), conv_roofline(args.batch, 256, 14, N.VT_BF16),
                   conv_roofline(args.batch, 512, 7, N.VT_BF16)]
@@ -209,7 +209,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(dom["tflops"], 1), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4),
                          "traffic": pmc_traffic(),
-                         "kernel": "span_kernel<bf16,256,128,2,2>", "launch_ms": round(dom["ms"], 4),
+                         "kernel": "span_kernel<bf16,224,128,2,2>", "launch_ms": round(dom["ms"], 4),
                          "layer": dom["shape"]},
             "roofline_layers": [{"layer": l["shape"], "ms": round(l["ms"], 4), "tflops": round(l["tflops"], 1),
                                  "frac": round(l["tflops"] / PEAK_BF16_TFLOPS, 4)} for l in layers],

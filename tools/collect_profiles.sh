@@ -11,15 +11,15 @@ OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bench" -- \
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bench" -- \
     python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/prof_bench.log" 2>&1
 echo "bench profile exit $?"
 
 LAYER="128,128,3,1,28"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- \
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- \
     python3 "$ROOT/tools/bench_conv.py" fwd $LAYER > "$OUT/pmc_fetch.log" 2>&1
 echo "pmc fetch exit $?"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- \
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- \
     python3 "$ROOT/tools/bench_conv.py" fwd $LAYER > "$OUT/pmc_write.log" 2>&1
 echo "pmc write exit $?"
 
@@ -37,7 +37,7 @@ f = glob.glob(f"{out}/pmc_fetch/*/*kernel_trace.csv")[0]
 durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(f))
         if "span_kernel" in r["Kernel_Name"]]
 res = {
-    "kernel": "span_kernel<bf16,256,128,2,2>", "layer": "conv3x3 s1 128->128 @28x28 B=256",
+    "kernel": "span_kernel<bf16,224,128,2,2>", "layer": "conv3x3 s1 128->128 @28x28 B=256",
     "launches": n1, "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb,
     # gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads -> doubled
     "hbm_read_bytes": fetch_kb * 1024 * 2, "hbm_write_bytes": write_kb * 1024,
