@@ -134,6 +134,9 @@ def main():
     ap.add_argument("--no-graphs", action="store_true", help="(default) kept for compatibility")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=16.0)
+    ap.add_argument("--main-priority", type=int, default=0,
+                    help="run the step on a torch stream of this priority (-1 = high): the filter-gradient side "
+                         "stream then only fills what the critical path leaves")
     args = ap.parse_args()
 
     from vision_toolbox import _native as N
@@ -161,6 +164,8 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if args.main_priority != 0:
+        torch.cuda.set_stream(torch.cuda.Stream(dev, priority=args.main_priority))
     launches0 = N.launch_count()
     for _ in range(args.warmup):
         ts.step()

@@ -126,7 +126,7 @@ struct SpanLds {
 };
 
 // ita: span DMA instructions per wave per chunk (span = 64*ita rows >= BM + dmax - dmin)
-template <typename T, int BM, int BN, int WM, int WN, int PD>
+template <typename T, int BM, int BN, int WM, int WN, int PD, bool PP = false>
 __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel(const IgemmArgs p, const int dmin, const int ita) {
     constexpr int NW = WM * WN;  // waves: 4, or 8 for the 256 x 128 tile (wave tile 64 x 64, 16 waves per CU)
     constexpr int NT = 64 * NW;
@@ -250,6 +250,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
         sMask[r] = bits;
         sPo[r] = po;
     }
+    if constexpr (PP) vm_wait_dyn((min(PD, nsteps) - 1) * ITB);  // span 0 and slice 0 landed before the first LOAD tick
     __syncthreads();  // tap table, row masks, zero block
 
     VT_STAMP(1);
@@ -263,6 +264,72 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
 #ifdef VT_SPAN_STAMPS
     unsigned long long loop_acc[4] = {0, 0, 0, 0};
 #endif
+    if constexpr (PP) {
+        // ---- ping-pong schedule (8 waves, one workgroup per CU) -------------------------------------
+        // The two row halves of the tile (waves 0-3 / 4-7; one wave of each per SIMD) run half a
+        // step apart: in every "tick" (= one workgroup barrier) one half issues its LDS-DMA and reads
+        // its 12 fragments while the other half issues its 32 MFMAs, so the MFMA pipe of a SIMD
+        // always has one wave feeding it and the other wave's staging hides behind it.
+        //   group 0: LOAD(s) at tick 2s,   MFMA(s) at tick 2s+1
+        //   group 1: idle at tick 0, LOAD(s) at tick 2s+1, MFMA(s) at tick 2s+2
+        // B(s+1) is first read at tick 2s+2 (group 0), so every wave retires its part of it before
+        // the barrier that ends tick 2s+1: group 0 after its MFMAs, group 1 after its loads.  Both
+        // groups execute 2*nsteps barriers.  Requires ntaps >= PD (a span is never needed within
+        // PD steps of its issue).
+        static_assert(NW == 8 && WN == 2, "ping-pong needs two 4-wave row halves");
+        const int grp = wm >> 1;
+        if (grp == 1) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        int a_since = 1 << 20;  // LOAD ticks since this wave issued a span
+        for (int s = 0; s < nsteps; ++s) {
+            // ---- LOAD(s)
+            ++a_since;
+            if (it == 0 && ic + 1 < nchunks) {
+                VT_ISSUE_A((ic + 1) & 1, ic + 1);
+                a_since = 0;
+            }
+            if (s + PD < nsteps) {
+                VT_ISSUE_B(bnxt, ic_n, it_n);
+                if (++it_n == p.ntaps) it_n = 0, ++ic_n;
+            }
+            const int d = __builtin_amdgcn_readfirstlane(sTap[it].x);
+            const int srow0 = wm * TM + (lane & 15) + d;
+            const uint4* A = sA + (ic & 1) * aslot + srow0 * 4 + ((lane >> 4) ^ swz(srow0));
+            const uint4* Bt = sB + bcur * BSLOT + wn * TN * 4 + b_lane;
+            uint4 af[FM], bf[FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bf[j] = Bt[j * 64];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const uint4* src = ((fmask[i] >> it) & 1u) ? A : sZ - i * 64;
+                af[i] = src[i * 64];
+            }
+            // younger than B(s+1): the slices issued in the last PD-1 LOAD ticks, plus a span issued
+            // in one of them
+            const int nb = max(0, min(PD - 1, nsteps - 2 - s));
+            const int allowed = nb * ITB + ((a_since <= PD - 2) ? ita : 0);
+            if (grp == 1) vm_wait_dyn(s + 1 < nsteps ? allowed : 0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // ---- MFMA(s)
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) mma<T>(af[i], bf[j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            if (grp == 0) vm_wait_dyn(s + 1 < nsteps ? allowed : 0);
+            if (!(grp == 1 && s + 1 == nsteps)) {
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            if (++it == p.ntaps) it = 0, ++ic;
+            bcur = (bcur + 1 == NSB) ? 0 : bcur + 1;
+            bnxt = (bnxt + 1 == NSB) ? 0 : bnxt + 1;
+        }
+    } else
     for (int s = 0; s < nsteps; ++s) {
         VT_LOOP_CLK(c0);
         // Retire this step's filter slice B(s).  VM operations retire in issue order, so everything
@@ -332,7 +399,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
     }
 #undef VT_ISSUE_A
 #undef VT_ISSUE_B
-    __syncthreads();  // every wave is done with the rings; they become the staging windows
+    // every wave is done with the rings; they become the staging windows (ping-pong: nobody reads
+    // the rings after the last barrier inside the loop)
+    if constexpr (!PP) __syncthreads();
     VT_STAMP(2);
 #ifdef VT_SPAN_STAMPS
     if (threadIdx.x == 0 && blockIdx.x < 8192)
@@ -432,7 +501,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
 template <typename L>
 bool smem_ok(int ita, int nw, int nchunks) { return L::bytes(ita, nchunks > 1 ? 2 : 1, nw) <= 160 * 1024; }
 
-template <typename T, int BM, int BN, int WM, int WN, int PD>
+template <typename T, int BM, int BN, int WM, int WN, int PD, bool PP = false>
 int launch_span_pd(IgemmArgs& a, int dmin, int span, hipStream_t st) {
     using L = SpanLds<BM, BN, PD>;
     constexpr int NW = WM * WN;
@@ -444,7 +513,7 @@ int launch_span_pd(IgemmArgs& a, int dmin, int span, hipStream_t st) {
     const int nchunks = a.Cin / (64 / (int)sizeof(T));
     const int smem = L::bytes(ita, nchunks > 1 ? 2 : 1, NW);
     const long blocks = (long)8 * a.chunk * a.tiles_n;
-    auto kern = span_kernel<T, BM, BN, WM, WN, PD>;
+    auto kern = span_kernel<T, BM, BN, WM, WN, PD, PP>;
     static bool raised = false;
     if (!raised) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -510,8 +579,16 @@ template <typename T, int BM>
 int launch_span_bn(IgemmArgs& a, int dmin, int span, hipStream_t st) {
     if constexpr (BM == 512) {
         // 8 waves of 128 x 64: the filter slices (the larger part of the staged bytes) are fetched
-        // once per 512 pixels instead of once per 256
-        return launch_span<T, BM, 128, 4, 2>(a, dmin, span, st);
+        // once per 512 pixels instead of once per 256.  Narrow layers: 4 waves of 128 x BN -- their
+        // K loop is 1-4 steps long, so a workgroup is mostly prologue + epilogue and what matters
+        // is the bytes it keeps in flight.
+        if (a.Cout > 64) {
+            static const int pp = getenv("VT_SPAN_PP") ? atoi(getenv("VT_SPAN_PP")) : 1;
+            if (pp && a.ntaps >= 3) return launch_span_pd<T, BM, 128, 4, 2, 3, true>(a, dmin, span, st);
+            return launch_span<T, BM, 128, 4, 2>(a, dmin, span, st);
+        }
+        if (a.Cout > 32) return launch_span<T, BM, 64, 4, 1>(a, dmin, span, st);
+        return launch_span<T, BM, 32, 4, 1>(a, dmin, span, st);
     } else if constexpr (BM == 224) {
         // 7 x 32 rows: 2 x 2 waves of 112 x BN/2 for every width
         if (a.Cout > 64) return launch_span<T, BM, 128, 2, 2>(a, dmin, span, st);
@@ -566,7 +643,7 @@ int vt_span_dispatch(IgemmArgs& a, int dtype, void* stream) {
             const long c256 = (tiles256 + 511) / 512 * 256, c224 = (t224 + 511) / 512 * 224;
             // (only the 128-wide tiles gain: the narrow ones are bound by their epilogue/HBM traffic)
             const bool use224 = bm_env ? bm_env == 224 : (c224 < c256 && a.Cout > 64);
-            if (bm_env == 512 && a.Cout > 64) {
+            if (bm_env == 512) {
                 const int rc = launch_span_bn<bf16_t, 512>(a, dmin, 512 + dmax - dmin, st);
                 if (rc != -1) return rc;
             }
