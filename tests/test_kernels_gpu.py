@@ -42,6 +42,9 @@ CONV_CASES = [
     (2, 128, 64, 1, 1, 12, 12),
     (2, 256, 128, 3, 2, 14, 14),
     (1, 8, 8, 3, 1, 3, 3),
+    (2, 8, 32, 3, 1, 20, 13),  # RGB-stem shape class (one 16-byte pixel): vt_stem.hip in bf16
+    (1, 8, 64, 3, 1, 9, 40),
+    (3, 8, 24, 3, 1, 17, 17),
 ]
 
 

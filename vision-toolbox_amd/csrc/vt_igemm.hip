@@ -503,6 +503,10 @@ extern "C" int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w
 
     hipStream_t st = (hipStream_t)stream;
     {
+        const int rc = vt_stem_dispatch(a, d->dtype, stream);  // RGB stem
+        if (rc >= 0) return rc;
+    }
+    {
         const int rc = vt_span_dispatch(a, d->dtype, stream);  // stride-1-grid convs: input-span kernel
         if (rc >= 0) return rc;
     }

@@ -20,3 +20,6 @@ struct IgemmArgs {
 // vt_igemm_span.hip: input-span kernel for stride-1-grid convs; returns -1 when it does not
 // apply to `a` (the caller then launches the general kernel), else a VT_* status.
 int vt_span_dispatch(IgemmArgs& a, int dtype, void* stream);
+
+// vt_stem.hip: 3x3 stride-1 convolution over 8-channel (padded RGB) pixels; -1 when it does not apply.
+int vt_stem_dispatch(IgemmArgs& a, int dtype, void* stream);
