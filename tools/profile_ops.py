@@ -37,6 +37,7 @@ def main():
     s = int(torch.cuda.current_stream().cuda_stream)
     p = ts.prog
     rows = []
+    excess = []
     reps = 5
     for phase, ops, n in (("fwd", p.fwd_ops, p.n_fwd), ("bwd", p.bwd_ops, p.n_bwd)):
         for idx in range(n):
@@ -58,7 +59,13 @@ def main():
                 d = N.ConvDesc.from_buffer_copy(bytes(op.i)[: ctypes.sizeof(N.ConvDesc)])
                 fl = 2.0 * d.B * d.Ho * d.Wo * d.Cout * d.Cin * d.ntaps
                 desc = f"{d.Cin:4d}->{d.Cout:4d} taps {d.ntaps:2d} s{d.sh} in {d.Hi:3d}x{d.Wi:<3d} grid {d.Ho:3d}x{d.Wo:<3d}"
-                work = f"{fl / ms / 1e9:7.1f} TF/s"
+                nb = 2.0 * (d.B * d.Hi * d.Wi * d.Cin / (d.sh * d.sw if kind == N.OP_CONV_WGRAD else 1)
+                            + d.B * d.Ho * d.Wo * d.Cout) + 2.0 * d.Cout * d.Cin * d.ntaps
+                if kind == N.OP_CONV_WGRAD:
+                    nb = 2.0 * (d.B * d.Hi * d.Wi * d.Cin + d.B * d.Ho * d.Wo * d.Cout)
+                ideal = max(fl / 1.0e15, nb / 5.0e12) * 1e3  # ms: 1.0 PF/s practical MFMA, 5 TB/s HBM
+                work = f"{fl / ms / 1e9:7.1f} TF/s {nb / ms / 1e9:6.2f} TB/s ideal {ideal:6.3f} excess {ms - ideal:6.3f}"
+                excess.append((ms - ideal, phase, name, desc, ms, ideal))
             elif kind == N.OP_BN_ACT_APPLY:
                 pass
             rows.append((ms, phase, idx, name, desc, work))
@@ -72,6 +79,16 @@ def main():
     conv = [r for r in rows if r[3].startswith("conv")]
     for ms, phase, idx, name, desc, work in sorted(conv, key=lambda r: -r[0])[:top]:
         print(f"  {phase}[{idx:4d}] {name:11s} {desc}  {ms:7.4f} ms {work}")
+    print("-- conv ops by excess over max(flops / 1.0 PF/s, bytes / 5 TB/s)")
+    agg2 = defaultdict(lambda: [0, 0.0, 0.0])
+    for ex, phase, name, desc, ms, ideal in excess:
+        a = agg2[(phase, name, desc)]
+        a[0] += 1
+        a[1] += ms
+        a[2] += ideal
+    for (phase, name, desc), (cnt, ms, ideal) in sorted(agg2.items(), key=lambda kv: -(kv[1][1] - kv[1][2]))[:top]:
+        print(f"  {phase} {name:11s} {desc} x{cnt:2d}  {ms:7.3f} ms ideal {ideal:7.3f} excess {ms - ideal:7.3f}")
+    print(f"  total conv excess {sum(e[0] for e in excess):.3f} ms of {sum(e[4] for e in excess):.3f} ms")
     # aggregate identical conv shapes
     agg = defaultdict(lambda: [0, 0.0])
     for ms, phase, idx, name, desc, work in conv:
