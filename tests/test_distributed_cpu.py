@@ -64,6 +64,21 @@ def _worker(rank, world, port, q):
         # the tail bucket (head / last stage weights) must be ready no later than the stem-side one
         first_seg_of = {bi: si for si, grp in enumerate(ts.cut_buckets) for bi in grp}
         ok_order = first_seg_of[0] <= first_seg_of[len(ts.bucketer.buckets) - 1]
+        # a bucket may only be reduced after EVERY op that writes any part of it: parameters straddle
+        # bucket boundaries, so the op that names a gradient's start also owns its tail in the next bucket
+        from vision_toolbox import engine as E
+        from vision_toolbox.trainer import _grad_write_offsets
+
+        seg_end_of = {bi: ts.bwd_cuts[si] for si, grp in enumerate(ts.cut_buckets) for bi in grp}
+        extent = {o: o + p.numel() for o, p in zip(ts.store.offsets, ts.store.params)}
+        ok_ready, straddlers = True, 0
+        for idx in range(ts.prog.n_bwd):
+            for off in _grad_write_offsets(ts.prog.bwd_ops[idx]):
+                lo, hi = off, extent.get(off, off + 1)
+                hit = [bi for bi, (s0, s1) in enumerate(ts.bucketer.buckets) if s0 < hi and lo < s1]
+                straddlers += len(hit) > 1
+                ok_ready &= all(seg_end_of[bi] >= idx + 1 for bi in hit)
+        ok_plan = ok_plan and ok_ready and straddlers > 0  # the case must actually occur in this plan
         ts.broadcast_parameters(0)
         ref = ts.store.pflat.clone()
         dist.broadcast(ref, 0)

@@ -1,0 +1,92 @@
+"""Two data-parallel ranks of the fused train step on ONE GPU (gloo moves the gradient buckets):
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+        --master-port 29531 tools/ddp_check.py
+
+A 1-GPU box cannot run RCCL across ranks, but everything around the collective is the code
+bench.py --gpus N runs: parameter broadcast, backward cut into bucket-completing segments,
+asynchronous bucket all-reduce behind the launch stream, 1/world folded into SGD.  Each rank
+trains on its own batch; rank 0 replays the same two steps on the CPU oracle with DDP semantics
+(per-rank BatchNorm statistics, gradients averaged over ranks) and compares the weight updates.
+Prints 'DDP_CHECK_OK' on success."""
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path[:0] = [str(ROOT / "vision-toolbox_amd"), str(ROOT)]
+
+import torch
+import torch.distributed as dist
+
+from oracle import filler
+from oracle import torch_ref as R
+from vision_toolbox import _native as N
+from vision_toolbox import backbones
+from vision_toolbox.trainer import TrainStep
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    name, ncls, B, S, steps, lr, wd = "vovnet19_slim_ese", 16, 4, 64, 2, 2e-3, 1e-3
+    torch.cuda.set_device(0)
+    xs = [filler.images(B, S, seed=1000 + r) for r in range(world)]
+    ys = [filler.labels(B, ncls, seed=2000 + r) for r in range(world)]
+
+    torch.manual_seed(rank)  # ranks start from DIFFERENT weights; the broadcast must fix that
+    ts = TrainStep(getattr(backbones, name)(), ncls, B, S, torch.float32, lr=lr, momentum=0.9, weight_decay=wd,
+                   label_smoothing=0.1, device="cuda:0", bucket_mb=0.25, use_graphs=False)
+    if rank == 0:
+        filler.fill_module(ts.model, "ddp.")
+        ts.weights_changed()
+    ts.broadcast_parameters(0)
+    assert ts.world == world and ts.bucketer is not None and len(ts.bucketer.buckets) >= 3, "want several buckets"
+    assert len(ts.bwd_cuts) >= 2, "backward must be cut into bucket-completing segments"
+    init = {k: v.detach().clone().cpu() for k, v in ts.model.state_dict().items()}
+    before = N.launch_count()
+    for _ in range(steps):
+        ts.step(xs[rank].cuda(), ys[rank].cuda())
+    torch.cuda.synchronize()
+    assert N.launch_count() > before
+    mine = torch.cat([p.detach().reshape(-1).cpu() for p in ts.model.parameters()])
+    both = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    assert torch.equal(both[0], both[1]), "ranks diverged: they must apply identical averaged gradients"
+
+    if rank == 0:
+        sd = {}
+        for k, shape in R.classifier_spec(name, ncls).items():
+            dt = torch.int64 if k.endswith("num_batches_tracked") else torch.float32
+            sd[k] = filler.fill_tensor("ddp." + k, torch.zeros(shape, dtype=dt))
+        params = {k: v for k, v in sd.items()
+                  if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))}
+        for v in params.values():
+            v.requires_grad_(True)
+        mom = {}
+        for _ in range(steps):
+            grads = {k: torch.zeros_like(v) for k, v in params.items()}
+            for r in range(world):  # each replica: own batch, own BN batch statistics, same weights
+                for v in params.values():
+                    v.grad = None
+                rsd = {k: (v if k in params else v.clone()) for k, v in sd.items()}  # running stats: rank-local
+                loss, _ = R.classifier_loss(name, rsd, xs[r], ys[r], 0.1, training=True)
+                loss.backward()
+                for k, v in params.items():
+                    grads[k] += v.grad / world
+            R.sgd_step(params, grads, mom, lr, 0.9, lambda k: R.weight_decay_group(k, wd, 0.0, 0.0))
+        got = ts.model.state_dict()
+        worst = 0.0
+        for k in ("0.stem.0.conv.weight", "0.stages.3.module_0.out_conv.conv.weight", "3.weight", "3.bias"):
+            d_got, d_ref = got[k].cpu() - init[k], sd[k].detach() - init[k]
+            err = ((d_got - d_ref).norm() / d_ref.norm()).item()
+            worst = max(worst, err)
+            assert d_ref.norm() > 0 and err < 0.1, (k, err)
+        print(f"DDP_CHECK_OK world={world} buckets={len(ts.bucketer.buckets)} segments={len(ts.bwd_cuts)} "
+              f"worst update rel err {worst:.3e}", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

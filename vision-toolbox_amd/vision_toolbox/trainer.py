@@ -167,10 +167,20 @@ class TrainStep:
             buckets = plan_buckets(total, int(bucket_mb * (1 << 20)) // 4)
             self.bucketer = GradBucketer(self.gflat, buckets, self.pg)
             ready = [0] * len(buckets)  # last bwd op that writes into each bucket
+            # an op names the START of the gradient it writes; the gradient extends over the whole
+            # parameter, which may straddle a bucket boundary -- every bucket the parameter
+            # overlaps must wait for that op (missing this lets a tail bucket be reduced before
+            # the op adds to it: ranks then apply different gradients and drift apart)
+            import bisect
+
+            starts = list(st.offsets)
+            ends = [o + E._round_up(p.numel(), 64) for o, p in zip(st.offsets, st.params)]
             for idx in range(self.prog.n_bwd):
                 for off in _grad_write_offsets(self.prog.bwd_ops[idx]):
+                    k = bisect.bisect_right(starts, off) - 1
+                    lo, hi = (starts[k], ends[k]) if k >= 0 and off < ends[k] else (off, off + 1)
                     for bi, (s0, s1) in enumerate(buckets):
-                        if s0 <= off < s1:
+                        if s0 < hi and lo < s1:
                             ready[bi] = max(ready[bi], idx + 1)
             cuts = sorted(set(ready) | {self.prog.n_bwd})
             self.bwd_cuts = [c for c in cuts if c > 0]
