@@ -28,6 +28,7 @@ for p in (str(ROOT / "vision-toolbox_amd"), str(ROOT)):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+LABELS = {"cspdarknet53": "CSPDarknet-53", "darknet53": "Darknet-53", "darknet19": "Darknet-19", "vovnet39": "VoVNet-39"}
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
 
@@ -144,7 +145,12 @@ def main():
     from vision_toolbox.distributed import init_from_env
     from vision_toolbox.trainer import TrainStep
 
-    rank, local, world = init_from_env("nccl")
+    # test hooks (1-GPU boxes): VT_DIST_BACKEND=gloo VT_FORCE_DEVICE=0 let two ranks share one GPU so the
+    # N>1 control flow of this script can be exercised without RCCL; never set them for a measurement
+    backend = os.environ.get("VT_DIST_BACKEND", "nccl")
+    if "VT_FORCE_DEVICE" in os.environ:
+        os.environ["LOCAL_RANK"] = os.environ["VT_FORCE_DEVICE"]
+    rank, local, world = init_from_env(backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local)
@@ -195,7 +201,7 @@ def main():
                   conv_roofline(args.batch, 512, 7, N.VT_BF16)]
         dom = layers[0]
         out = {
-            "metric": "images/sec (node) CSPDarknet-53 bf16 train step @224px",
+            "metric": f"images/sec (node) {LABELS.get(args.model, args.model)} bf16 train step @{args.image_size}px",
             "value": round(value, 2),
             "unit": "images/sec",
             "n_gpus": world,
