@@ -156,6 +156,23 @@ int vt_global_avgpool_bwd(const void* dy, int32_t lddy, void* dx, int32_t lddx, 
                           int32_t HW, int32_t C, int32_t accumulate, int32_t dtype,
                           void* stream);
 
+/* ---- nearest-neighbour resampling of the necks (necks.py:66, 70-81) -------- */
+/* The `nn.Upsample(scale_factor=2.0 | 0.5, mode="nearest")` of FPN / PAN fused with the `sum`
+ * that follows it (`aggregate_sum`, necks.py:19-23):
+ *   mode 0 (top-down):  dst[b][i][j] = src[b][i/2][j/2] (+ other[b][i][j]);  src is [B][Hd/2][Wd/2][C]
+ *   mode 1 (bottom-up): dst[b][i][j] = src[b][2i][2j]   (+ other[b][i][j]);  src is [B][2Hd][2Wd][C]
+ * dst / other are [B][Hd][Wd][C]; `other` may be NULL. */
+int vt_resample2x_add_fwd(const void* src, int32_t lds, const void* other, int32_t ldo, void* dst,
+                          int32_t ldd, int32_t B, int32_t Hd, int32_t Wd, int32_t C, int32_t mode,
+                          int32_t dtype, void* stream);
+/* gradient w.r.t. src of the above (the `other` branch is the identity):
+ *   mode 0: dsrc[b][i][j] (+)= sum of the 2x2 block dy[b][2i..2i+1][2j..2j+1]
+ *   mode 1: dsrc[b][i][j] (+)= (i, j both even) ? dy[b][i/2][j/2] : 0
+ * dy is [B][Hd][Wd][C]. */
+int vt_resample2x_bwd(const void* dy, int32_t lddy, void* dsrc, int32_t lds, int32_t B, int32_t Hd,
+                      int32_t Wd, int32_t C, int32_t mode, int32_t accumulate, int32_t dtype,
+                      void* stream);
+
 /* ---- ESEBlock gate (vovnet.py:20-28) ------------------------------------ */
 /* y = x * hardsigmoid(s[b][c]) [+ residual]; s is [B][C] (the biased 1x1 conv
  * of the pooled map, computed with vt_conv_igemm). */
@@ -232,6 +249,8 @@ enum vt_op_kind {
     VT_OP_NHWC_TO_NCHW,
     VT_OP_FORK, /* side stream waits for everything enqueued on the main stream so far */
     VT_OP_JOIN, /* main stream waits for everything enqueued on the side stream so far */
+    VT_OP_RESAMPLE_FWD,
+    VT_OP_RESAMPLE_BWD,
     VT_OP_KIND_END
 };
 

@@ -295,3 +295,52 @@ def weight_decay_group(key: str, wd: float, norm_wd: float, bias_wd: float) -> f
     if key.endswith(".bias"):
         return bias_wd
     return wd
+
+
+# ---- necks: FPN / PAN, necks.py:45-120 ---------------------------------
+def neck_spec(kind: str, in_channels, out_channels: int) -> "OrderedDict[str, tuple]":
+    """state_dict key -> shape of FPN(in_channels, out_channels) / PAN(...) with the defaults
+    (fuse 'sum', ConvNormAct blocks); a lateral conv exists only where in != out (necks.py:60-65)."""
+
+    def fpn_spec(out, p, ins):
+        for i, c in enumerate(ins):
+            if c != out_channels:
+                out[f"{p}lateral_convs.{i}.weight"] = (out_channels, c, 1, 1)
+                out[f"{p}lateral_convs.{i}.bias"] = (out_channels,)
+        for i in range(len(ins) - 1):
+            _cna_spec(out, f"{p}output_convs.{i}.", out_channels, out_channels, 3)
+
+    out = OrderedDict()
+    if kind == "fpn":
+        fpn_spec(out, "", list(in_channels))
+    elif kind == "pan":
+        fpn_spec(out, "top_down.", list(in_channels))
+        fpn_spec(out, "bottom_up.", [out_channels] * len(in_channels))
+    else:
+        raise KeyError(kind)
+    return out
+
+
+def fpn(sd, p, xs, top_down: bool, training: bool):
+    """FPN.forward (necks.py:83-88): lateral 1x1 convs (biased, no norm), then level by level
+    `fuse([x_dst, upsample(x_src)])` = x_dst + nearest-resampled x_src, then the output ConvNormAct."""
+    outs = []
+    for i, x in enumerate(xs):
+        k = f"{p}lateral_convs.{i}.weight"
+        outs.append(F.conv2d(x, sd[k], sd[f"{p}lateral_convs.{i}.bias"]) if k in sd else x)
+    n = len(outs)
+    for i in range(n - 1):
+        if top_down:  # necks.py:70-73
+            d, s = n - 2 - i, n - 1 - i
+            fused = outs[d] + F.interpolate(outs[s], scale_factor=2.0, mode="nearest")
+        else:  # necks.py:76-79
+            d, s = i + 1, i
+            fused = outs[d] + F.interpolate(outs[s], scale_factor=0.5, mode="nearest")
+        outs[d] = cna(sd, f"{p}output_convs.{i}.", fused, 1, training)
+    return outs
+
+
+def pan(sd, p, xs, training: bool):
+    """PAN.forward (necks.py:117-120).  NOTE the reference builds `bottom_up` with FPN's default
+    top_down=True (necks.py:109-115), so both passes run top-down; restated as written."""
+    return fpn(sd, p + "bottom_up.", fpn(sd, p + "top_down.", xs, True, training), True, training)

@@ -1,0 +1,135 @@
+"""FPN / PAN necks.
+
+CPU: the oracle's restatement (oracle/torch_ref.py fpn / pan) against fixtures produced by the
+unmodified reference (tools/gen_golden_necks.py -> tests/golden/necks.npz), and the state_dict
+contract of the shipped modules.  GPU: the shipped modules against the same fixtures (f32 kernels:
+5e-5 / 2e-4; bf16 kernels: 3e-2 relative L2 against the f32 reference values)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import filler
+from oracle import torch_ref as R
+
+GOLDEN = Path(__file__).parent / "golden" / "necks.npz"
+CASES = {  # must match tools/gen_golden_necks.py
+    "fpn_td": ("fpn", (16, 32, 64), 32, True, (16, 8, 4), 2),
+    "fpn_bu": ("fpn", (16, 32, 64), 32, False, (16, 8, 4), 2),
+    "pan": ("pan", (16, 24, 40), 16, True, (16, 8, 4), 2),
+}
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLDEN)
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a, dtype=torch.float64), torch.as_tensor(b, dtype=torch.float64)
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _inputs(name, ins, sizes, B, device="cpu", dtype=torch.float32):
+    return [filler.tensor(f"{name}.x{i}", (B, c, s, s)).to(device=device, dtype=dtype).requires_grad_(True)
+            for i, (c, s) in enumerate(zip(ins, sizes))]
+
+
+def _loss(name, ys):
+    return sum((y.float() * filler.tensor(f"{name}.r{i}", tuple(y.shape)).to(y.device)).sum() for i, y in enumerate(ys))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_oracle_necks_match_reference_fixtures(gold, name, mode):
+    kind, ins, outc, td, sizes, B = CASES[name]
+    spec = R.neck_spec(kind, ins, outc)
+    assert list(spec.keys()) == list(gold[f"{name}/keys"])
+    assert [str(tuple(s)) for s in spec.values()] == list(gold[f"{name}/shapes"])
+    sd = {k: filler.fill_tensor(f"{name}.{k}", torch.zeros(s, dtype=torch.int64 if k.endswith("tracked") else torch.float32))
+          for k, s in spec.items()}
+    params = {k: v.requires_grad_(True) for k, v in sd.items()
+              if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))}
+    xs = _inputs(name, ins, sizes, B)
+    ys = R.fpn(sd, "", xs, td, mode == "train") if kind == "fpn" else R.pan(sd, "", xs, mode == "train")
+    _loss(name, ys).backward()
+    for i, y in enumerate(ys):
+        assert rel(y.detach(), gold[f"{name}/{mode}/y{i}"]) < 1e-6
+    for i, x in enumerate(xs):
+        assert rel(x.grad, gold[f"{name}/{mode}/dx{i}"]) < 1e-5
+    for k, p in params.items():
+        assert rel(p.grad, gold[f"{name}/{mode}/grad/{k}"]) < 1e-5, k
+    if mode == "train":
+        for k, v in sd.items():
+            if k.endswith(("running_mean", "running_var")):
+                assert rel(v.detach(), gold[f"{name}/train/state/{k}"]) < 1e-6
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_neck_modules_keep_the_reference_state_dict(gold, name):
+    from vision_toolbox import necks
+
+    kind, ins, outc, td, sizes, B = CASES[name]
+    m = necks.FPN(list(ins), outc, top_down=td) if kind == "fpn" else necks.PAN(list(ins), outc)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(gold[f"{name}/keys"])
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(gold[f"{name}/shapes"])
+    with pytest.raises(RuntimeError, match="no CPU/eager fallback"):
+        m([torch.zeros(1, c, s, s) for c, s in zip(ins, sizes)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("mode", ["train", "eval"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_neck_modules_match_reference_fixtures_on_gpu(gold, name, mode, dtype):
+    from vision_toolbox import _native as N
+    from vision_toolbox import necks
+
+    kind, ins, outc, td, sizes, B = CASES[name]
+    m = necks.FPN(list(ins), outc, top_down=td) if kind == "fpn" else necks.PAN(list(ins), outc)
+    filler.fill_module(m, f"{name}.")
+    m = m.cuda().train(mode == "train")
+    xs = _inputs(name, ins, sizes, B, "cuda", dtype)
+    before = N.launch_count()
+    ys = m(xs)
+    assert len(ys) == len(ins) and all(y.is_cuda for y in ys)
+    _loss(name, ys).backward()
+    torch.cuda.synchronize()
+    assert N.launch_count() > before, "HIP path did not run"
+    f32 = dtype == torch.float32
+    ty, tg = (5e-5, 2e-4) if f32 else (3e-2, 0.12)  # bf16: train-mode BN at 2x16x16 amplifies the rounding
+    for i, y in enumerate(ys):
+        assert tuple(y.shape) == gold[f"{name}/{mode}/y{i}"].shape
+        assert rel(y.detach().float().cpu(), gold[f"{name}/{mode}/y{i}"]) < ty, i
+    for i, x in enumerate(xs):
+        assert x.grad is not None and rel(x.grad.float().cpu(), gold[f"{name}/{mode}/dx{i}"]) < tg, i
+    worst = 0.0
+    for k, p in m.named_parameters():
+        worst = max(worst, rel(p.grad.cpu(), gold[f"{name}/{mode}/grad/{k}"]))
+    assert worst < (tg if f32 else 0.15), worst
+    if mode == "train" and f32:
+        for k, v in m.state_dict().items():
+            if k.endswith(("running_mean", "running_var")):
+                assert rel(v.cpu(), gold[f"{name}/train/state/{k}"]) < 1e-4, k
+
+
+@pytest.mark.gpu
+def test_backbone_and_neck_compose_through_autograd():
+    """get_feature_maps() -> PAN -> loss.backward(): gradients reach the backbone's parameters through the
+    neck's autograd.Function (necks.py:83 consumes the list output)."""
+    from vision_toolbox import backbones, necks
+
+    bb = backbones.darknet_yolov5n().cuda().train()
+    filler.fill_module(bb, "cmp.bb.")
+    maps_c = bb.out_channels_list[-3:]
+    neck = necks.PAN(list(maps_c), 32).cuda().train()
+    filler.fill_module(neck, "cmp.neck.")
+    x = filler.images(2, 64).cuda()
+    fmaps = bb.get_feature_maps(x)[-3:]
+    outs = neck(fmaps)
+    sum(o.float().square().mean() for o in outs).backward()
+    g = bb.stem.conv.weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0
+    assert all(p.grad is not None for p in neck.parameters())

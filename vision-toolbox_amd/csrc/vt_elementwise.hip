@@ -483,6 +483,86 @@ avgpool_bwd_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dx, int l
 }
 
 // ---------------------------------------------------------------------------------
+// nearest x2 / x0.5 resampling fused with the sum that follows it (necks)
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+resample_fwd_kernel(const T* __restrict__ src, int lds, const T* __restrict__ other, int ldo, T* __restrict__ dst,
+                    int ldd, int Hd, int Wd, long M, RowMap rm, int mode) {
+    constexpr int EPC = VecIO<T>::EPC;
+    const int t = threadIdx.x;
+    const int r = t / rm.CT;
+    if (r >= rm.RT) return;
+    const long row0 = (long)blockIdx.x * rm.RT * rm.iters + r;
+    const int Hs = mode ? 2 * Hd : Hd / 2, Ws = mode ? 2 * Wd : Wd / 2;
+    for (int col = t % rm.CT; col < rm.CPR; col += rm.CT) {
+        for (int it = 0; it < rm.iters; ++it) {
+            const long row = row0 + (long)it * rm.RT;
+            if (row >= M) break;
+            const long b = row / ((long)Hd * Wd);
+            const int rem = (int)(row - b * Hd * Wd);
+            const int i = rem / Wd, j = rem - i * Wd;
+            const int si = mode ? 2 * i : i >> 1, sj = mode ? 2 * j : j >> 1;
+            const long srow = (b * Hs + si) * Ws + sj;
+            float v[EPC];
+            VecIO<T>::unpack(ld16(src + srow * lds + col * EPC), v);
+            if (other) {
+                float o[EPC];
+                VecIO<T>::unpack(ld16(other + row * ldo + col * EPC), o);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) v[e] += o[e];
+            }
+            st16(dst + row * ldd + col * EPC, VecIO<T>::pack(v));
+        }
+    }
+}
+
+// one thread row = one pixel of dsrc
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+resample_bwd_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dsrc, int lds, int Hd, int Wd, long Ms,
+                    RowMap rm, int mode, int accumulate) {
+    constexpr int EPC = VecIO<T>::EPC;
+    const int t = threadIdx.x;
+    const int r = t / rm.CT;
+    if (r >= rm.RT) return;
+    const long row0 = (long)blockIdx.x * rm.RT * rm.iters + r;
+    const int Hs = mode ? 2 * Hd : Hd / 2, Ws = mode ? 2 * Wd : Wd / 2;
+    for (int col = t % rm.CT; col < rm.CPR; col += rm.CT) {
+        for (int it = 0; it < rm.iters; ++it) {
+            const long row = row0 + (long)it * rm.RT;
+            if (row >= Ms) break;
+            const long b = row / ((long)Hs * Ws);
+            const int rem = (int)(row - b * Hs * Ws);
+            const int i = rem / Ws, j = rem - i * Ws;
+            float a[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) a[e] = 0.f;
+            if (accumulate) VecIO<T>::unpack(ld16(dsrc + row * lds + col * EPC), a);
+            if (mode == 0) {
+#pragma unroll
+                for (int di = 0; di < 2; ++di)
+#pragma unroll
+                    for (int dj = 0; dj < 2; ++dj) {
+                        float g[EPC];
+                        const long drow = (b * Hd + 2 * i + di) * Wd + 2 * j + dj;
+                        VecIO<T>::unpack(ld16(dy + drow * lddy + col * EPC), g);
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) a[e] += g[e];
+                    }
+            } else if (!(i & 1) && !(j & 1)) {
+                float g[EPC];
+                const long drow = (b * Hd + (i >> 1)) * Wd + (j >> 1);
+                VecIO<T>::unpack(ld16(dy + drow * lddy + col * EPC), g);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) a[e] += g[e];
+            }
+            st16(dsrc + row * lds + col * EPC, VecIO<T>::pack(a));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // ESE gate: y = x * hardsigmoid(s[b][c]) [+ residual]
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ float hsig(float v) { return fminf(fmaxf(v * (1.f / 6.f) + 0.5f, 0.f), 1.f); }
@@ -966,6 +1046,44 @@ int vt_global_avgpool_bwd(const void* dy, int32_t lddy, void* dx, int32_t lddx, 
                                      (hipStream_t)stream, (const T*)dy, lddy, (T*)dx, lddx, HW, M, rm,
                                      accumulate));
     VT_CHECK_LAUNCH("vt_global_avgpool_bwd");
+    return VT_OK;
+}
+
+int vt_resample2x_add_fwd(const void* src, int32_t lds, const void* other, int32_t ldo, void* dst, int32_t ldd,
+                          int32_t B, int32_t Hd, int32_t Wd, int32_t C, int32_t mode, int32_t dtype, void* stream) {
+    VT_REQUIRE(B > 0 && Hd > 0 && Wd > 0 && (mode == 0 || mode == 1), VT_ERR_INVALID,
+               "vt_resample2x_add_fwd: bad argument");
+    VT_REQUIRE(mode == 1 || (Hd % 2 == 0 && Wd % 2 == 0), VT_ERR_UNSUPPORTED,
+               "vt_resample2x_add_fwd: x2 upsampling needs an even destination (%dx%d)", Hd, Wd);
+    VT_TRY(check_mat("vt_resample2x_add_fwd(src)", src, lds, C, dtype));
+    VT_TRY(check_mat("vt_resample2x_add_fwd(dst)", dst, ldd, C, dtype));
+    if (other) VT_TRY(check_mat("vt_resample2x_add_fwd(other)", other, ldo, C, dtype));
+    const long M = (long)B * Hd * Wd;
+    const RowMap rm = RowMap::make(C, vt_epc(dtype), M);
+    VT_DISPATCH_T(dtype, "vt_resample2x_add_fwd",
+                  hipLaunchKernelGGL(resample_fwd_kernel<T>, dim3(rm.blocks(M)), dim3(kThreads), 0,
+                                     (hipStream_t)stream, (const T*)src, lds, (const T*)other, ldo, (T*)dst, ldd, Hd,
+                                     Wd, M, rm, mode));
+    VT_CHECK_LAUNCH("vt_resample2x_add_fwd");
+    return VT_OK;
+}
+
+int vt_resample2x_bwd(const void* dy, int32_t lddy, void* dsrc, int32_t lds, int32_t B, int32_t Hd, int32_t Wd,
+                      int32_t C, int32_t mode, int32_t accumulate, int32_t dtype, void* stream) {
+    VT_REQUIRE(B > 0 && Hd > 0 && Wd > 0 && (mode == 0 || mode == 1), VT_ERR_INVALID,
+               "vt_resample2x_bwd: bad argument");
+    VT_REQUIRE(mode == 1 || (Hd % 2 == 0 && Wd % 2 == 0), VT_ERR_UNSUPPORTED,
+               "vt_resample2x_bwd: x2 upsampling needs an even destination (%dx%d)", Hd, Wd);
+    VT_TRY(check_mat("vt_resample2x_bwd(dy)", dy, lddy, C, dtype));
+    VT_TRY(check_mat("vt_resample2x_bwd(dsrc)", dsrc, lds, C, dtype));
+    const int Hs = mode ? 2 * Hd : Hd / 2, Ws = mode ? 2 * Wd : Wd / 2;
+    const long Ms = (long)B * Hs * Ws;
+    const RowMap rm = RowMap::make(C, vt_epc(dtype), Ms);
+    VT_DISPATCH_T(dtype, "vt_resample2x_bwd",
+                  hipLaunchKernelGGL(resample_bwd_kernel<T>, dim3(rm.blocks(Ms)), dim3(kThreads), 0,
+                                     (hipStream_t)stream, (const T*)dy, lddy, (T*)dsrc, lds, Hd, Wd, Ms, rm, mode,
+                                     accumulate));
+    VT_CHECK_LAUNCH("vt_resample2x_bwd");
     return VT_OK;
 }
 

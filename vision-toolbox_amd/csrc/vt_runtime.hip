@@ -88,6 +88,10 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
         case VT_OP_MAXPOOL_BWD:  // ptr: dy argmax dx | i: lddy lddx B H W C accumulate dtype
             return vt_maxpool3x3s2_bwd(P[0], I[0], (const uint8_t*)P[1], P[2], I[1], I[2], I[3], I[4], I[5],
                                        I[6], I[7], st);
+        case VT_OP_RESAMPLE_FWD:  // ptr: src other dst | i: lds ldo ldd B Hd Wd C mode dtype
+            return vt_resample2x_add_fwd(P[0], I[0], P[1], I[1], P[2], I[2], I[3], I[4], I[5], I[6], I[7], I[8], st);
+        case VT_OP_RESAMPLE_BWD:  // ptr: dy dsrc | i: lddy lds B Hd Wd C mode accumulate dtype
+            return vt_resample2x_bwd(P[0], I[0], P[1], I[1], I[2], I[3], I[4], I[5], I[6], I[7], I[8], st);
         case VT_OP_AVGPOOL_FWD:  // ptr: x y | i: ldx ldy B HW C dtype
             return vt_global_avgpool_fwd(P[0], I[0], P[1], I[1], I[2], I[3], I[4], I[5], st);
         case VT_OP_AVGPOOL_BWD:  // ptr: dy dx | i: lddy lddx B HW C accumulate dtype

@@ -46,7 +46,9 @@ VT_OP_MAX_PTR, VT_OP_MAX_INT, VT_OP_MAX_FLT, VT_MAX_BASES = 12, 110, 8, 16
     OP_NHWC_TO_NCHW,
     OP_FORK,
     OP_JOIN,
-) = range(1, 25)
+    OP_RESAMPLE_FWD,
+    OP_RESAMPLE_BWD,
+) = range(1, 27)
 OP_SIDE_STREAM = 0x10000  # OR-ed into Op.kind: enqueue on the side stream
 
 OP_NAMES = {
@@ -74,6 +76,8 @@ OP_NAMES = {
     OP_NHWC_TO_NCHW: "nhwc_to_nchw",
     OP_FORK: "fork",
     OP_JOIN: "join",
+    OP_RESAMPLE_FWD: "resample_fwd",
+    OP_RESAMPLE_BWD: "resample_bwd",
 }
 
 
@@ -135,6 +139,8 @@ SYMBOLS = {
     "vt_maxpool3x3s2_bwd": (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vt_global_avgpool_fwd": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vt_global_avgpool_bwd": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vt_resample2x_add_fwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vt_resample2x_bwd": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vt_ese_gate_fwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vt_ese_gate_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vt_colsum": (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp]),

@@ -235,6 +235,11 @@ class Builder:
         # and run on the side stream while the forward list executes
         self.hoist_dgrad_packs = False
         self._hoisted: list[N.Op] = []
+        # feature-map inputs of programs that do not start from an image (necks): the runner copies
+        # the caller's tensors into these buffers before the forward list and reads their gradients
+        # (ext_grads, filled by build_backward) after the backward list
+        self.ext_inputs: list[TRef] = []
+        self.ext_grads: list[Optional[TRef]] = []
 
     # -- memory -----------------------------------------------------------------
     def alloc(self, nbytes: int, name: str = "") -> Buf:
@@ -661,6 +666,61 @@ class Builder:
         return dst
 
     # -- pooling -------------------------------------------------------------------------
+    def input_map(self, B, C_, H, W, name="in", requires_grad=True) -> TRef:
+        """an NHWC feature map supplied by the caller (necks.py:83: the backbone's outputs)."""
+        t = self.act(B, H, W, C_, name, needs_grad=requires_grad)
+        idx = len(self.ext_inputs)
+        self.ext_inputs.append(t)
+        self.ext_grads.append(None)
+        if requires_grad and self.need_grad:
+
+            def bwd():  # first node appended => last to run: every contribution has been registered
+                self.ext_grads[idx] = self.grad_read(t)
+
+            self.nodes.append(bwd)
+        return t
+
+    def resample_add(self, src: TRef, other: Optional[TRef], mode: int, name="resample") -> TRef:
+        """nearest x2 (mode 0) / x0.5 (mode 1) resampling of `src` plus `other` (necks.py:66-81)."""
+        self.tag += 1
+        if mode == 0:
+            Hd, Wd = src.H * 2, src.W * 2
+        else:
+            if src.H % 2 or src.W % 2:
+                raise NotImplementedError("x0.5 nearest resampling of an odd-sized map")
+            Hd, Wd = src.H // 2, src.W // 2
+        if other is not None:
+            assert (other.B, other.H, other.W, other.C) == (src.B, Hd, Wd, src.C), "fuse operands differ in shape"
+        y = self.act(src.B, Hd, Wd, src.C, name)
+        self.emit(N.OP_RESAMPLE_FWD, [src.addr(), other.addr() if other is not None else None, y.addr()],
+                  [src.ld, other.ld if other is not None else 0, y.ld, src.B, Hd, Wd, src.C, mode, self.dtype])
+        if self.need_grad and (src.needs_grad or (other is not None and other.needs_grad)):
+            tag = self.tag
+
+            def bwd():
+                self.tag = tag
+                dy = self.grad_read(y)
+                if dy is None:
+                    return
+                if other is not None:
+                    self.grad_add(other, dy)
+                if not src.needs_grad:
+                    return
+                gx, res = self.grad_target(src)
+                acc = 0
+                if res is not None:
+                    if res is gx or (res.buf is gx.buf and res.coff == gx.coff):
+                        acc = 1
+                    else:  # a foreign addend: materialise it first, then accumulate
+                        self._add_into(gx, res, False)
+                        acc = 1
+                self.emit(N.OP_RESAMPLE_BWD, [dy.addr(), gx.addr()],
+                          [dy.ld, gx.ld, src.B, Hd, Wd, src.C, mode, acc, self.dtype])
+                self.grad_written(src)
+
+            self.nodes.append(bwd)
+        return y
+
     def maxpool3x3s2(self, x: TRef, out: Optional[TRef] = None, name="maxpool") -> TRef:
         self.tag += 1
         Ho, Wo = (x.H + 2 - 3) // 2 + 1, (x.W + 2 - 3) // 2 + 1
