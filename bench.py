@@ -135,6 +135,9 @@ def main():
     ap.add_argument("--no-graphs", action="store_true", help="(default) kept for compatibility")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=16.0)
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="SyncBatchNorm as in the reference recipe (configs/base.yaml:22); off for the headline "
+                         "metric: 2 small sequential collectives per unit")
     ap.add_argument("--main-priority", type=int, default=0,
                     help="run the step on a torch stream of this priority (-1 = high): the filter-gradient side "
                          "stream then only fills what the critical path leaves")
@@ -159,7 +162,8 @@ def main():
     torch.manual_seed(0)
     bb = getattr(backbones, args.model)()
     ts = TrainStep(bb, 1000, args.batch, args.image_size, torch.bfloat16, lr=0.05, momentum=0.9, weight_decay=2e-5,
-                   label_smoothing=0.1, device=dev, bucket_mb=args.bucket_mb, use_graphs=args.graphs)
+                   label_smoothing=0.1, device=dev, bucket_mb=args.bucket_mb, use_graphs=args.graphs,
+                   sync_bn=args.sync_bn)
     ts.broadcast_parameters(0)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
@@ -216,7 +220,7 @@ def main():
             "config": {"workload": f"{args.model} train step (fwd+CE+bwd+allreduce+SGD), batch {args.batch}/GPU, "
                                    f"3x{args.image_size}x{args.image_size}, 1000 classes, BASELINE configs[1]",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "hip_graphs": bool(args.graphs), "final_loss": round(loss, 4)},
+                       "hip_graphs": bool(args.graphs), "sync_bn": bool(args.sync_bn), "final_loss": round(loss, 4)},
             "roofline": {"bound": "mfma", "achieved": round(dom["tflops"], 1), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4),
                          "traffic": pmc_traffic(),

@@ -129,10 +129,13 @@ int vt_bn_act_bwd_reduce(const void* dy, int32_t lddy, const void* z, int32_t ld
                          const float* scale, const float* shift, const float* mean,
                          const float* invstd, int64_t M, int32_t C, int32_t relu,
                          int32_t dtype, float* sums, void* stream);
-/* dgamma += sum g*xhat; dbeta += sum g; coef[3][C] for vt_bn_act_bwd_apply.
- * train!=0: full batch-norm gradient; train==0: statistics are constants. */
-int vt_bn_bwd_finalize(const float* sums, int32_t C, double count, const float* scale,
-                       const float* mean, const float* invstd, int32_t train,
+/* dgamma += pscale * sum g*xhat; dbeta += pscale * sum g; coef[3][C] for vt_bn_act_bwd_apply.
+ * train!=0: full batch-norm gradient; train==0: statistics are constants.
+ * SyncBatchNorm (configs/base.yaml:22): `sums` then hold the all-reduced sums and `count` the
+ * global sample count; pscale = 1/world keeps the parameter gradients rank-local in size, so
+ * the gradient all-reduce(mean) that follows yields the same values as torch's SyncBatchNorm. */
+int vt_bn_bwd_finalize(const float* sums, int32_t C, double count, double pscale,
+                       const float* scale, const float* mean, const float* invstd, int32_t train,
                        float* dgamma, float* dbeta, float* coef, void* stream);
 /* dz = coef0[c]*g - coef1[c]*z + coef2[c] */
 int vt_bn_act_bwd_apply(const void* dy, int32_t lddy, const void* z, int32_t ldz,

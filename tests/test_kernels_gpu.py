@@ -176,7 +176,7 @@ def test_batchnorm_relu_forward_backward_chain(dtype, shape):
                                    M, Cc, 1, dtype, vp(sums), stream()))
     dg, db = torch.ones(Cc, device="cuda"), torch.ones(Cc, device="cuda")
     bc = torch.zeros(3, Cc, device="cuda")
-    N.check(L.vt_bn_bwd_finalize(vp(sums), Cc, float(M), vp(coef[0]), vp(coef[2]), vp(coef[3]), 1, vp(dg), vp(db),
+    N.check(L.vt_bn_bwd_finalize(vp(sums), Cc, float(M), 1.0, vp(coef[0]), vp(coef[2]), vp(coef[3]), 1, vp(dg), vp(db),
                                  vp(bc), stream()))
     dz = torch.empty_like(zd)
     N.check(L.vt_bn_act_bwd_apply(vp(dyd), Cc, vp(zd), Cc, vp(coef[0]), vp(coef[1]), vp(bc), vp(dz), Cc, M, Cc, 1,

@@ -97,10 +97,11 @@ def test_lr_schedule_follows_device_scalar():
     assert not torch.equal(w0, ts.store.pflat)
 
 
-def test_two_ranks_on_one_gpu_match_ddp_semantics():
+@pytest.mark.parametrize("sync_bn", ["0", "1"], ids=["ddp", "ddp_syncbn"])
+def test_two_ranks_on_one_gpu_match_ddp_semantics(sync_bn):
     """bench.py --gpus N path minus RCCL itself: two ranks share this GPU and exchange the gradient
     buckets over gloo (tools/ddp_check.py); updates must equal the oracle's DDP replay and the ranks
-    must stay bit-identical."""
+    must stay bit-identical.  sync_bn=1: SyncBatchNorm mode against one process on the joint batch."""
     import os
     import socket
     import subprocess
@@ -113,7 +114,7 @@ def test_two_ranks_on_one_gpu_match_ddp_semantics():
         port = sk.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), str(root / "tools" / "ddp_check.py")],
-                       capture_output=True, text=True, timeout=900, env=dict(os.environ))
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, DDP_CHECK_SYNCBN=sync_bn))
     assert r.returncode == 0 and "DDP_CHECK_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     buf = torch.zeros(16, device="cuda")  # the launch-count guard of this module wants a launch here too
     N.check(N.lib().vt_memset(buf.data_ptr(), 0, 64, int(torch.cuda.current_stream().cuda_stream)))

@@ -8,6 +8,8 @@ bench.py --gpus N runs: parameter broadcast, backward cut into bucket-completing
 asynchronous bucket all-reduce behind the launch stream, 1/world folded into SGD.  Each rank
 trains on its own batch; rank 0 replays the same two steps on the CPU oracle with DDP semantics
 (per-rank BatchNorm statistics, gradients averaged over ranks) and compares the weight updates.
+With DDP_CHECK_SYNCBN=1 the step runs in SyncBatchNorm mode (configs/base.yaml:22) and the oracle is
+ONE process on the concatenated batch (batch statistics over all ranks' images).
 Prints 'DDP_CHECK_OK' on success."""
 import os
 import sys
@@ -30,13 +32,14 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     name, ncls, B, S, steps, lr, wd = "vovnet19_slim_ese", 16, 4, 64, 2, 2e-3, 1e-3
+    sync_bn = os.environ.get("DDP_CHECK_SYNCBN", "0") == "1"
     torch.cuda.set_device(0)
     xs = [filler.images(B, S, seed=1000 + r) for r in range(world)]
     ys = [filler.labels(B, ncls, seed=2000 + r) for r in range(world)]
 
     torch.manual_seed(rank)  # ranks start from DIFFERENT weights; the broadcast must fix that
     ts = TrainStep(getattr(backbones, name)(), ncls, B, S, torch.float32, lr=lr, momentum=0.9, weight_decay=wd,
-                   label_smoothing=0.1, device="cuda:0", bucket_mb=0.25, use_graphs=False)
+                   label_smoothing=0.1, device="cuda:0", bucket_mb=0.25, use_graphs=False, sync_bn=sync_bn)
     if rank == 0:
         filler.fill_module(ts.model, "ddp.")
         ts.weights_changed()
@@ -64,7 +67,7 @@ def main():
         for v in params.values():
             v.requires_grad_(True)
         mom = {}
-        for _ in range(steps):
+        for _ in range(steps if not sync_bn else 0):
             grads = {k: torch.zeros_like(v) for k, v in params.items()}
             for r in range(world):  # each replica: own batch, own BN batch statistics, same weights
                 for v in params.values():
@@ -75,6 +78,13 @@ def main():
                 for k, v in params.items():
                     grads[k] += v.grad / world
             R.sgd_step(params, grads, mom, lr, 0.9, lambda k: R.weight_decay_group(k, wd, 0.0, 0.0))
+        for _ in range(steps if sync_bn else 0):  # SyncBN == one process on the concatenated batch
+            for v in params.values():
+                v.grad = None
+            loss, _ = R.classifier_loss(name, sd, torch.cat(xs), torch.cat(ys), 0.1, training=True)
+            loss.backward()
+            R.sgd_step(params, {k: v.grad for k, v in params.items()}, mom, lr, 0.9,
+                       lambda k: R.weight_decay_group(k, wd, 0.0, 0.0))
         got = ts.model.state_dict()
         worst = 0.0
         for k in ("0.stem.0.conv.weight", "0.stages.3.module_0.out_conv.conv.weight", "3.weight", "3.bias"):
@@ -82,7 +92,12 @@ def main():
             err = ((d_got - d_ref).norm() / d_ref.norm()).item()
             worst = max(worst, err)
             assert d_ref.norm() > 0 and err < 0.1, (k, err)
-        print(f"DDP_CHECK_OK world={world} buckets={len(ts.bucketer.buckets)} segments={len(ts.bwd_cuts)} "
+        if sync_bn:
+            rv = [k for k in got if k.endswith("running_var")]
+            for k in (rv[0], rv[-1]):
+                err = ((got[k].cpu() - sd[k]).norm() / sd[k].norm()).item()
+                assert err < 5e-3, (k, err)
+        print(f"DDP_CHECK_OK sync_bn={sync_bn} world={world} buckets={len(ts.bucketer.buckets)} segments={len(ts.bwd_cuts)} "
               f"worst update rel err {worst:.3e}", flush=True)
     dist.barrier()
     dist.destroy_process_group()

@@ -237,7 +237,7 @@ bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, double count,
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, double count, double pscale,
                                        const float* __restrict__ scale, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, int train, float* dgamma,
                                        float* dbeta, float* coef) {
@@ -248,8 +248,8 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, do
         s1 += (double)sums[((long)r * 2 + 0) * C + c];
         s2 += (double)sums[((long)r * 2 + 1) * C + c];
     }
-    if (dgamma) dgamma[c] += (float)s2;
-    if (dbeta) dbeta[c] += (float)s1;
+    if (dgamma) dgamma[c] += (float)(s2 * pscale);
+    if (dbeta) dbeta[c] += (float)(s1 * pscale);
     const float a = scale[c];
     float b = 0.f, d = 0.f;
     if (train) {
@@ -950,13 +950,13 @@ int vt_bn_act_bwd_reduce(const void* dy, int32_t lddy, const void* z, int32_t ld
     return VT_OK;
 }
 
-int vt_bn_bwd_finalize(const float* sums, int32_t C, double count, const float* scale, const float* mean,
+int vt_bn_bwd_finalize(const float* sums, int32_t C, double count, double pscale, const float* scale, const float* mean,
                        const float* invstd, int32_t train, float* dgamma, float* dbeta, float* coef,
                        void* stream) {
     VT_REQUIRE(sums && scale && mean && invstd && coef && C > 0 && count > 0, VT_ERR_INVALID,
                "vt_bn_bwd_finalize: bad argument");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums,
-                       C, count, scale, mean, invstd, train, dgamma, dbeta, coef);
+                       C, count, pscale, scale, mean, invstd, train, dgamma, dbeta, coef);
     VT_CHECK_LAUNCH("vt_bn_bwd_finalize");
     return VT_OK;
 }

@@ -77,8 +77,8 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
             return vt_bn_act_bwd_reduce(P[0], I[0], P[1], I[1], (const float*)P[2], (const float*)P[3],
                                         (const float*)P[4], (const float*)P[5], (int64_t)F[0], I[2], I[3],
                                         I[4], (float*)P[6], st);
-        case VT_OP_BN_BWD_FINALIZE:  // ptr: sums scale mean invstd dgamma dbeta coef | i: C train | f: count
-            return vt_bn_bwd_finalize((const float*)P[0], I[0], F[0], (const float*)P[1], (const float*)P[2],
+        case VT_OP_BN_BWD_FINALIZE:  // ptr: sums scale mean invstd dgamma dbeta coef | i: C train | f: count pscale(0 = 1)
+            return vt_bn_bwd_finalize((const float*)P[0], I[0], F[0], F[1] == 0.0 ? 1.0 : F[1], (const float*)P[1], (const float*)P[2],
                                       (const float*)P[3], I[1], (float*)P[4], (float*)P[5], (float*)P[6], st);
         case VT_OP_BN_BWD_APPLY:  // ptr: dy z scale shift coef dz | i: lddy ldz lddz C relu dtype | f: M
             return vt_bn_act_bwd_apply(P[0], I[0], P[1], I[1], (const float*)P[2], (const float*)P[3],

@@ -133,7 +133,7 @@ SYMBOLS = {
     "vt_bn_eval_coeffs": (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "vt_bn_act_apply": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "vt_bn_act_bwd_reduce": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
-    "vt_bn_bwd_finalize": (_i32, [_vp, _i32, _f64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "vt_bn_bwd_finalize": (_i32, [_vp, _i32, _f64, _f64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "vt_bn_act_bwd_apply": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "vt_maxpool3x3s2_fwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vt_maxpool3x3s2_bwd": (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

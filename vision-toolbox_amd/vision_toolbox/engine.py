@@ -235,6 +235,10 @@ class Builder:
         # and run on the side stream while the forward list executes
         self.hoist_dgrad_packs = False
         self._hoisted: list[N.Op] = []
+        # SyncBatchNorm (configs/base.yaml:22): the trainer all-reduces every layer's statistics
+        # between the kernel that accumulates them and the finalize kernel; the finalize kernels
+        # are then told the GLOBAL sample count (and scale the affine gradients by 1/world)
+        self.bn_world = 1
         # feature-map inputs of programs that do not start from an image (necks): the runner copies
         # the caller's tensors into these buffers before the forward list and reads their gradients
         # (ext_grads, filled by build_backward) after the backward list
@@ -541,7 +545,7 @@ class Builder:
                 self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, z.addr(), None, None, None, self.bp(stats)], desc=d)
                 self.emit(N.OP_BN_FINALIZE,
                           [self.bp(stats), g, b_, rm, rv, self.pref(norm.num_batches_tracked), *cp],
-                          [Cout], [M, norm.eps, norm.momentum])
+                          [Cout], [M * self.bn_world, norm.eps, norm.momentum])
             else:
                 d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, z.ld, ldw, 0)
                 self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, z.addr(), None, None, None, None], desc=d)
@@ -576,7 +580,7 @@ class Builder:
                     bcoef = self.f32(3 * Cout, "bwdcoef")
                     self.emit(N.OP_BN_BWD_FINALIZE,
                               [self.bp(sums), cp[0], cp[2], cp[3], self.pgrad(norm.weight), self.pgrad(norm.bias),
-                               self.bp(bcoef)], [Cout, int(training)], [M])
+                               self.bp(bcoef)], [Cout, int(training)], [M * self.bn_world, 1.0 / self.bn_world])
                     dz = self.act(B, Ho, Wo, Cout, name + ".dz")
                     self.emit(N.OP_BN_BWD_APPLY,
                               [dy.addr(), z.addr(), cp[0], cp[1], self.bp(bcoef), dz.addr()],

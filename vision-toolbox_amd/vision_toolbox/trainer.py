@@ -97,6 +97,7 @@ class TrainStep:
         bucket_mb: float = 16.0,
         use_graphs: bool = True,
         plan_only: bool = False,
+        sync_bn: bool = False,
     ):
         N.lib()
         self.device = torch.device(device if device is not None else "cuda")
@@ -128,6 +129,11 @@ class TrainStep:
         # ---- forward + loss + backward launch lists ---------------------------------------
         b = E.Builder(st, self.dtype, training=True, need_grad=True, grad_base=E.GRADS)
         b.hoist_dgrad_packs = True
+        # SyncBatchNorm, the reference recipe's setting (configs/base.yaml:22): batch statistics over
+        # ALL ranks.  Off by default for the throughput metric: it adds two small,
+        # strictly sequential collectives per unit (67 + 67 for CSPDarknet-53).
+        self.sync_bn = bool(sync_bn) and self.world > 1
+        b.bn_world = self.world if self.sync_bn else 1
         x = b.input_images(batch_size, 3, image_size, image_size)
         fmap = backbone._vt_emit_maps(b, x)[-1]
         pooled = b.global_avgpool(fmap, "head.pool")
@@ -137,6 +143,9 @@ class TrainStep:
         b.build_backward()
         self.prog = Program(b, [logits], [])
         self.n_units = b.n_units
+        # sync points: the statistics a finalize kernel reads must be all-reduced right before it
+        self._fwd_sync = self._sync_points(self.prog.fwd_ops, self.prog.n_fwd, N.OP_BN_FINALIZE) if self.sync_bn else []
+        self._bwd_sync = self._sync_points(self.prog.bwd_ops, self.prog.n_bwd, N.OP_BN_BWD_FINALIZE) if self.sync_bn else []
 
         # ---- optimiser launch list: one SGD launch per weight-decay group ---------------------
         wd_of = {GROUP_OTHER: weight_decay, GROUP_NORM: norm_weight_decay, GROUP_BIAS: bias_weight_decay}
@@ -201,6 +210,37 @@ class TrainStep:
         self._graphs = None
         self.steps_done = 0
 
+    @staticmethod
+    def _sync_points(ops, n, kind):
+        """[(op index of the finalize kernel, base id, byte offset, bytes of its [replicas][2][C] sums)]"""
+        pts = []
+        for idx in range(n):
+            op = ops[idx]
+            if (op.kind & 0xFFFF) == kind:
+                pts.append((idx, op.ptr[0].base, op.ptr[0].offset, N.VT_STAT_REPLICAS * 2 * op.i[0] * 4))
+        return pts
+
+    def _sync_view(self, base, off, nbytes):
+        start = {E.ZERO_F: self.prog.zf_off, E.ZERO_B: self.prog.zb_off}[base] + off
+        return self.arena[start : start + nbytes].view(torch.float32)
+
+    def _run_list(self, ops, n, sync, cuts, cut_buckets, s, side):
+        """run a launch list in segments: a segment ends before every finalize kernel whose statistics
+        must be all-reduced first (SyncBatchNorm) and after every op that completes a gradient bucket."""
+        marks = {idx: ("sync", (base, off, nb)) for idx, base, off, nb in sync}
+        ends = sorted(set(marks) | set(cuts) | {n})
+        lo = 0
+        for hi in ends:
+            if hi > lo:
+                sub = (N.Op * (hi - lo)).from_address(ctypes.addressof(ops) + lo * ctypes.sizeof(N.Op))
+                N.run_ops(sub, hi - lo, self.bases, s, side=side)
+            if hi in marks:  # stream-ordered: NCCL makes the launch stream wait, no host sync
+                torch.distributed.all_reduce(self._sync_view(*marks[hi][1]), group=self.pg)
+            if hi in cut_buckets:
+                for bi in cut_buckets[hi]:
+                    self.bucketer.reduce_bucket(bi)
+            lo = hi
+
     def _dev_ctx(self):
         import contextlib
 
@@ -256,7 +296,7 @@ class TrainStep:
                 self.labels.copy_(labels, non_blocking=True)
             s = current_stream_handle()
             p = self.prog
-            if self.use_graphs:
+            if self.use_graphs and not self.sync_bn:
                 if self._graphs is None:
                     self._build_graphs()
                 self._graphs["head"].launch(s)
@@ -267,15 +307,14 @@ class TrainStep:
             else:
                 if self._side is None:
                     self._side = torch.cuda.Stream(self.device)
+                side = int(self._side.cuda_stream)
                 N.run_ops(self.zero_ops, 1, self.bases, s)
-                N.run_ops(p.fwd_ops, p.n_fwd, self.bases, s, side=int(self._side.cuda_stream))
-                for (ops, n), bks in zip(self._segment_ops(), self.cut_buckets):
-                    N.run_ops(ops, n, self.bases, s, side=int(self._side.cuda_stream))
-                    for bi in bks:
-                        self.bucketer.reduce_bucket(bi)
+                self._run_list(p.fwd_ops, p.n_fwd, self._fwd_sync, [], {}, s, side)
+                self._run_list(p.bwd_ops, p.n_bwd, self._bwd_sync, self.bwd_cuts,
+                               dict(zip(self.bwd_cuts, self.cut_buckets)), s, side)
             if self.bucketer is not None:
                 self.bucketer.finish()
-            if self.use_graphs:
+            if self.use_graphs and not self.sync_bn:
                 self._graphs["opt"].launch(s)
             else:
                 N.run_ops(self.opt_ops, self.n_opt, self.bases, s)
