@@ -197,6 +197,23 @@ int vt_softmax_xent(const void* logits, int32_t ldl, const int64_t* labels,
                     float label_smoothing, float grad_scale, float* loss, void* dlogits,
                     int32_t lddl, int32_t B, int32_t N, int32_t dtype, void* stream);
 
+/* MixUp / CutMix of the training step (classifier.py:86-87, extras.py:14-109), on device.
+ * `mix` is a device float[8] the host refreshes per step (so captured graphs stay valid):
+ *   mix[0] mode: 0 none, 1 mixup, 2 cutmix;  mix[1] lambda (for cutmix: 1 - box area / image area,
+ *   extras.py:88);  mix[2..5] = x1, y1, x2, y2 of the cutmix box (extras.py:81-84).
+ * The partner of sample b is sample b-1 (mod B): `batch.roll(1, 0)`, extras.py:34,69.
+ * vt_softmax_xent_mix: loss / gradient against the soft target
+ *   lambda * onehot(labels[b]) + (1 - lambda) * onehot(labels[b-1]), then label smoothing --
+ *   what F.cross_entropy(logits, mixed_onehot, label_smoothing) computes (classifier.py:92).
+ * vt_mix_nchw_to_nhwc: vt_nchw_to_nhwc of the mixed images (mixup: lambda*x[b] + (1-lambda)*x[b-1];
+ *   cutmix: x[b-1] inside the box, x[b] outside). */
+int vt_softmax_xent_mix(const void* logits, int32_t ldl, const int64_t* labels,
+                        float label_smoothing, float grad_scale, float* loss, void* dlogits,
+                        int32_t lddl, int32_t B, int32_t N, int32_t dtype, const float* mix,
+                        void* stream);
+int vt_mix_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t H, int32_t W,
+                        int32_t Cpad, int32_t dtype, const float* mix, void* stream);
+
 /* ---- optimiser (classifier.py:161-169: torch.optim.SGD, momentum) -------- */
 /* g' = g*grad_scale + wd*p; m = mu*m + g'; p -= lr*m; mirror = cast(p).
  * lr_dev (optional, device float[1]) overrides `lr`, so a captured graph can

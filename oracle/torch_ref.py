@@ -344,3 +344,27 @@ def pan(sd, p, xs, training: bool):
     """PAN.forward (necks.py:117-120).  NOTE the reference builds `bottom_up` with FPN's default
     top_down=True (necks.py:109-115), so both passes run top-down; restated as written."""
     return fpn(sd, p + "bottom_up.", fpn(sd, p + "top_down.", xs, True, training), True, training)
+
+
+# ---- MixUp / CutMix of the training step (SURVEY 8(f) rank 3): extras.py:14-109, classifier.py:86-92 ----
+def mix_batch(images, labels, num_classes: int, mode: str, lam: float, box=(0, 0, 0, 0)):
+    """RandomMixup.forward (extras.py:22-43) / RandomCutmix.forward (extras.py:57-93) with the random
+    draws (lambda, box) passed in: returns (mixed images, soft targets [B, num_classes])."""
+    target = F.one_hot(labels, num_classes=num_classes).to(dtype=images.dtype)
+    if mode == "none":
+        return images.clone(), target
+    batch, batch_rolled, target_rolled = images.clone(), images.roll(1, 0), target.roll(1, 0)
+    if mode == "mixup":
+        batch = batch * lam + batch_rolled * (1.0 - lam)
+    elif mode == "cutmix":
+        x1, y1, x2, y2 = box
+        batch[:, :, y1:y2, x1:x2] = batch_rolled[:, :, y1:y2, x1:x2]
+    else:
+        raise KeyError(mode)
+    return batch, target * lam + target_rolled * (1.0 - lam)
+
+
+def classifier_loss_soft(name: str, sd, x, target, label_smoothing: float, training: bool = True):
+    """classifier.py:91-92 with probability targets (what it computes after mixup_cutmix)."""
+    logits = classifier_logits(name, sd, x, training)
+    return F.cross_entropy(logits, target, label_smoothing=label_smoothing), logits

@@ -687,7 +687,8 @@ __device__ __forceinline__ float ldf(const T* p) { return (float)(*p); }
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
 xent_kernel(const T* __restrict__ logits, int ldl, const int64_t* __restrict__ labels, float eps,
-            float grad_scale, float* __restrict__ loss, T* __restrict__ dlogits, int lddl, int B, int N) {
+            float grad_scale, float* __restrict__ loss, T* __restrict__ dlogits, int lddl, int B, int N,
+            const float* __restrict__ mix) {
     __shared__ float sred[kThreads / 64];
     __shared__ float sbc;
     const int b = blockIdx.x, t = threadIdx.x;
@@ -727,8 +728,12 @@ xent_kernel(const T* __restrict__ logits, int ldl, const int64_t* __restrict__ l
     }
     const float lse = mx + logf(tse);
     const int64_t yb = labels[b];
+    // MixUp / CutMix: the target is lam * onehot(own label) + (1 - lam) * onehot(label of sample b-1)
+    const bool mixed = mix && mix[0] != 0.f;
+    const float lam = mixed ? mix[1] : 1.f;
+    const int64_t yp = mixed ? labels[(b + B - 1) % B] : yb;
     if (t == 0) {
-        const float zy = ldf(lp + yb);
+        const float zy = lam * ldf(lp + yb) + (1.f - lam) * ldf(lp + yp);
         const float l = lse - (1.f - eps) * zy - (eps / (float)N) * tsz;
         atomicAdd(loss, l / (float)B);
     }
@@ -737,7 +742,9 @@ xent_kernel(const T* __restrict__ logits, int ldl, const int64_t* __restrict__ l
         const float q0 = eps / (float)N;
         for (int i = t; i < N; i += kThreads) {
             const float pr = expf(ldf(lp + i) - lse);
-            const float q = q0 + ((int64_t)i == yb ? 1.f - eps : 0.f);
+            float q = q0;
+            if ((int64_t)i == yb) q += (1.f - eps) * lam;
+            if ((int64_t)i == yp) q += (1.f - eps) * (1.f - lam);
             dp[i] = from_float<T>((pr - q) * grad_scale);
         }
     }
@@ -807,6 +814,35 @@ nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int C, long 
         const long b = i / HW, hw = i - b * HW;
         for (int c = 0; c < Cpad; ++c) {
             const float v = c < C ? x[(b * C + c) * HW + hw] : 0.f;
+            y[i * Cpad + c] = from_float<T>(v);
+        }
+    }
+}
+
+// the same with MixUp / CutMix applied on the way (mix: mode, lambda, x1, y1, x2, y2)
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+mix_nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int C, int W, long HW, int Cpad,
+                        long total, const float* __restrict__ mix) {
+    const int mode = (int)mix[0];
+    const float lam = mix[1];
+    const int x1 = (int)mix[2], y1 = (int)mix[3], x2 = (int)mix[4], y2 = (int)mix[5];
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+        const long b = i / HW, hw = i - b * HW;
+        const long bp = (b + B - 1) % B;
+        const int h = (int)(hw / W), w = (int)(hw - (long)h * W);
+        const bool inbox = mode == 2 && h >= y1 && h < y2 && w >= x1 && w < x2;
+        for (int c = 0; c < Cpad; ++c) {
+            float v = 0.f;
+            if (c < C) {
+                const float own = x[(b * C + c) * HW + hw];
+                if (mode == 1)
+                    v = own * lam + x[(bp * C + c) * HW + hw] * (1.f - lam);  // extras.py:38-39
+                else if (inbox)
+                    v = x[(bp * C + c) * HW + hw];                            // extras.py:87
+                else
+                    v = own;
+            }
             y[i * Cpad + c] = from_float<T>(v);
         }
     }
@@ -1143,8 +1179,22 @@ int vt_softmax_xent(const void* logits, int32_t ldl, const int64_t* labels, floa
     VT_DISPATCH_T(dtype, "vt_softmax_xent",
                   hipLaunchKernelGGL(xent_kernel<T>, dim3(B), dim3(kThreads), 0, (hipStream_t)stream,
                                      (const T*)logits, ldl, labels, label_smoothing, grad_scale, loss,
-                                     (T*)dlogits, lddl, B, N));
+                                     (T*)dlogits, lddl, B, N, (const float*)nullptr));
     VT_CHECK_LAUNCH("vt_softmax_xent");
+    return VT_OK;
+}
+
+int vt_softmax_xent_mix(const void* logits, int32_t ldl, const int64_t* labels, float label_smoothing,
+                        float grad_scale, float* loss, void* dlogits, int32_t lddl, int32_t B, int32_t N,
+                        int32_t dtype, const float* mix, void* stream) {
+    VT_REQUIRE(logits && labels && loss && mix && B > 0 && N > 0 && ldl >= N, VT_ERR_INVALID,
+               "vt_softmax_xent_mix: bad argument");
+    VT_REQUIRE(!dlogits || lddl >= N, VT_ERR_INVALID, "vt_softmax_xent_mix: lddl < N");
+    VT_DISPATCH_T(dtype, "vt_softmax_xent_mix",
+                  hipLaunchKernelGGL(xent_kernel<T>, dim3(B), dim3(kThreads), 0, (hipStream_t)stream,
+                                     (const T*)logits, ldl, labels, label_smoothing, grad_scale, loss,
+                                     (T*)dlogits, lddl, B, N, mix));
+    VT_CHECK_LAUNCH("vt_softmax_xent_mix");
     return VT_OK;
 }
 
@@ -1203,6 +1253,18 @@ int vt_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t H, in
                   hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(flat_blocks(total)), dim3(kThreads), 0,
                                      (hipStream_t)stream, x, (T*)y, C, (long)H * W, Cpad, total));
     VT_CHECK_LAUNCH("vt_nchw_to_nhwc");
+    return VT_OK;
+}
+
+int vt_mix_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t Cpad,
+                        int32_t dtype, const float* mix, void* stream) {
+    VT_REQUIRE(x && y && mix && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, VT_ERR_INVALID,
+               "vt_mix_nchw_to_nhwc: bad argument");
+    const long total = (long)B * H * W;
+    VT_DISPATCH_T(dtype, "vt_mix_nchw_to_nhwc",
+                  hipLaunchKernelGGL(mix_nchw_to_nhwc_kernel<T>, dim3(flat_blocks(total)), dim3(kThreads), 0,
+                                     (hipStream_t)stream, x, (T*)y, B, C, W, (long)H * W, Cpad, total, mix));
+    VT_CHECK_LAUNCH("vt_mix_nchw_to_nhwc");
     return VT_OK;
 }
 

@@ -103,7 +103,10 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
                                    I[6], I[7], I[8], st);
         case VT_OP_COLSUM:  // ptr: a out | i: lda C dtype | f: M
             return vt_colsum(P[0], I[0], (int64_t)F[0], I[1], I[2], (float*)P[1], st);
-        case VT_OP_XENT:  // ptr: logits labels loss dlogits | i: ldl lddl B N dtype | f: eps grad_scale
+        case VT_OP_XENT:  // ptr: logits labels loss dlogits [mix] | i: ldl lddl B N dtype | f: eps grad_scale
+            if (P[4])
+                return vt_softmax_xent_mix(P[0], I[0], (const int64_t*)P[1], (float)F[0], (float)F[1], (float*)P[2],
+                                           P[3], I[1], I[2], I[3], I[4], (const float*)P[4], st);
             return vt_softmax_xent(P[0], I[0], (const int64_t*)P[1], (float)F[0], (float)F[1], (float*)P[2],
                                    P[3], I[1], I[2], I[3], I[4], st);
         case VT_OP_SGD:  // ptr: p g m mirror lr_dev | i: mirror_dtype | f: n lr momentum wd grad_scale
@@ -111,7 +114,10 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
                                    (float)F[1], (float)F[2], (float)F[3], (float)F[4], (const float*)P[4], st);
         case VT_OP_COPY2D:  // ptr: src dst | i: src_dtype dst_dtype cols accumulate | f: lds ldd rows
             return vt_copy2d(P[0], I[0], (int64_t)F[0], P[1], I[1], (int64_t)F[1], (int64_t)F[2], I[2], I[3], st);
-        case VT_OP_NCHW_TO_NHWC:  // ptr: x y | i: B C H W Cpad dtype
+        case VT_OP_NCHW_TO_NHWC:  // ptr: x y [mix] | i: B C H W Cpad dtype
+            if (P[2])
+                return vt_mix_nchw_to_nhwc((const float*)P[0], P[1], I[0], I[1], I[2], I[3], I[4], I[5],
+                                           (const float*)P[2], st);
             return vt_nchw_to_nhwc((const float*)P[0], P[1], I[0], I[1], I[2], I[3], I[4], I[5], st);
         case VT_OP_NHWC_TO_NCHW:  // ptr: y x | i: ldy B C H W dtype
             return vt_nhwc_to_nchw(P[0], I[0], (float*)P[1], I[1], I[2], I[3], I[4], I[5], st);

@@ -145,6 +145,8 @@ SYMBOLS = {
     "vt_ese_gate_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vt_colsum": (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "vt_softmax_xent": (_i32, [_vp, _i32, _vp, _f32, _f32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "vt_softmax_xent_mix": (_i32, [_vp, _i32, _vp, _f32, _f32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "vt_mix_nchw_to_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "vt_sgd_momentum": (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _f32, _f32, _f32, _f32, _vp, _vp]),
     "vt_copy2d": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i64, _i32, _i32, _vp]),
     "vt_nchw_to_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -429,12 +429,16 @@ class Builder:
         return self._gref(t)
 
     # -- input / output plumbing -------------------------------------------------------
-    def input_images(self, B, C_, H, W, requires_grad=False) -> TRef:
-        """NCHW f32 images (base INPUT) -> NHWC dtype with channels padded to 16 bytes."""
+    MIX_OFF = 32  # byte offset of the MixUp / CutMix parameter block inside the HYPER buffer
+
+    def input_images(self, B, C_, H, W, requires_grad=False, mix: bool = False) -> TRef:
+        """NCHW f32 images (base INPUT) -> NHWC dtype with channels padded to 16 bytes; with `mix` the
+        conversion applies MixUp / CutMix from the device parameter block (classifier.py:86-87)."""
         epc = _EPC[self.dtype]
         cpad = _round_up(C_, epc)
         x = self.act(B, H, W, cpad, "images", needs_grad=requires_grad)
-        self.emit(N.OP_NCHW_TO_NHWC, [(INPUT, 0), x.addr()], [B, C_, H, W, cpad, self.dtype])
+        self.emit(N.OP_NCHW_TO_NHWC, [(INPUT, 0), x.addr(), (HYPER, self.MIX_OFF) if mix else None],
+                  [B, C_, H, W, cpad, self.dtype])
         x.logical_C = C_
         if requires_grad and self.need_grad:
             dx_buf = self.alloc(B * C_ * H * W * 4, "d_images")
@@ -819,7 +823,7 @@ class Builder:
         return y
 
     # -- classifier head + loss (reference classifier.py:58-64, 92) -----------------------
-    def xent(self, logits: TRef, label_smoothing: float, grad_scale: float) -> Buf:
+    def xent(self, logits: TRef, label_smoothing: float, grad_scale: float, mix: bool = False) -> Buf:
         self.tag += 1
         loss = self.zeroed_f32(64, "loss")
         Bn, Ncls = logits.B, logits.C
@@ -828,7 +832,8 @@ class Builder:
             gs = self._gs(logits)
             g = self._gref(logits)
             gs.init.append((logits.coff, logits.coff + logits.C))
-        self.emit(N.OP_XENT, [logits.addr(), (LABELS, 0), self.bp(loss), g.addr() if g else None],
+        self.emit(N.OP_XENT, [logits.addr(), (LABELS, 0), self.bp(loss), g.addr() if g else None,
+                              (HYPER, self.MIX_OFF) if mix else None],
                   [logits.ld, g.ld if g else 0, Bn, Ncls, self.dtype], [label_smoothing, grad_scale])
         return loss
 

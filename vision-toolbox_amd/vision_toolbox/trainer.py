@@ -73,6 +73,33 @@ def warmup_cosine_lr(epoch: int, max_epochs: int, lr: float, warmup_epochs: int 
     return eta_min + (lr - eta_min) * (1 + math.cos(math.pi * t / T)) / 2
 
 
+def sample_mix(cutmix_alpha: float, mixup_alpha: float, width: int, height: int):
+    """Draw (mode, lambda, box) the way RandomCutMixMixUp.forward does (extras.py:96-109), with the
+    same torch CPU RNG calls in the same order, so a seeded run pairs with the reference's:
+    rand -> choose; then RandomMixup (extras.py:29,37) or RandomCutmix (extras.py:64,72-88)."""
+    import math as _m
+
+    if cutmix_alpha == 0 and mixup_alpha == 0:
+        raise ValueError
+    use_mixup = cutmix_alpha <= 0 or torch.rand(1).item() >= 0.5
+    if use_mixup:
+        if torch.rand(1).item() >= 1.0:  # p = 1: never taken, but the draw is part of the stream
+            return "none", 1.0, (0, 0, 0, 0)
+        lam = float(torch._sample_dirichlet(torch.tensor([mixup_alpha, mixup_alpha], dtype=torch.float32))[0])
+        return "mixup", lam, (0, 0, 0, 0)
+    if torch.rand(1).item() >= 1.0:
+        return "none", 1.0, (0, 0, 0, 0)
+    lam = float(torch._sample_dirichlet(torch.tensor([cutmix_alpha, cutmix_alpha], dtype=torch.float32))[0])
+    r_x = int(torch.randint(width, (1,)))
+    r_y = int(torch.randint(height, (1,)))
+    r = 0.5 * _m.sqrt(1.0 - lam)
+    r_w_half, r_h_half = int(r * width), int(r * height)
+    x1, y1 = max(r_x - r_w_half, 0), max(r_y - r_h_half, 0)
+    x2, y2 = min(r_x + r_w_half, width), min(r_y + r_h_half, height)
+    lam = float(1.0 - (x2 - x1) * (y2 - y1) / (width * height))
+    return "cutmix", lam, (x1, y1, x2, y2)
+
+
 def _grad_write_offsets(op: N.Op) -> list[int]:
     """element offsets in the flat gradient buffer this backward op writes."""
     return [op.ptr[k].offset // 4 for k in range(N.VT_OP_MAX_PTR) if op.ptr[k].base == E.GRADS]
@@ -98,6 +125,7 @@ class TrainStep:
         use_graphs: bool = True,
         plan_only: bool = False,
         sync_bn: bool = False,
+        mix: bool = False,
     ):
         N.lib()
         self.device = torch.device(device if device is not None else "cuda")
@@ -120,7 +148,9 @@ class TrainStep:
             st.ensure(self.device)
             self.gflat = torch.zeros_like(st.pflat)
             self.mflat = torch.zeros_like(st.pflat)
-            self.lr_dev = torch.full((4,), lr, dtype=torch.float32, device=self.device)
+            # HYPER buffer: [0] learning rate; [8..13] MixUp / CutMix block (mode, lambda, x1, y1, x2, y2)
+            self.lr_dev = torch.zeros(16, dtype=torch.float32, device=self.device)
+            self.lr_dev[:4] = lr
             self.images = torch.zeros(batch_size, 3, image_size, image_size, device=self.device)
             self.labels = torch.zeros(batch_size, dtype=torch.int64, device=self.device)
         self.lr = lr
@@ -134,11 +164,12 @@ class TrainStep:
         # strictly sequential collectives per unit (67 + 67 for CSPDarknet-53).
         self.sync_bn = bool(sync_bn) and self.world > 1
         b.bn_world = self.world if self.sync_bn else 1
-        x = b.input_images(batch_size, 3, image_size, image_size)
+        self.mix = bool(mix)  # MixUp / CutMix applied on device from a per-step parameter block
+        x = b.input_images(batch_size, 3, image_size, image_size, mix=self.mix)
         fmap = backbone._vt_emit_maps(b, x)[-1]
         pooled = b.global_avgpool(fmap, "head.pool")
         logits = b.conv_unit(pooled, _LinearAsConv(head), None, False, name="head.linear")
-        self._loss_buf = b.xent(logits, label_smoothing, 1.0 / batch_size)
+        self._loss_buf = b.xent(logits, label_smoothing, 1.0 / batch_size, mix=self.mix)
         self._logits = logits
         b.build_backward()
         self.prog = Program(b, [logits], [])
@@ -262,7 +293,17 @@ class TrainStep:
 
     def set_lr(self, lr: float) -> None:
         self.lr = lr
-        self.lr_dev.fill_(lr)
+        self.lr_dev[:4] = lr
+
+    def set_mix(self, mode: str = "none", lam: float = 1.0, box=(0, 0, 0, 0)) -> None:
+        """MixUp / CutMix parameters of the NEXT step(s) (TrainStep(mix=True)): mode 'none' | 'mixup' |
+        'cutmix'; `lam` as sampled (mixup) or 1 - box area / image area (cutmix, extras.py:88);
+        box = (x1, y1, x2, y2).  `sample_mix` draws them exactly as extras.py does."""
+        if not self.mix:
+            raise RuntimeError("this TrainStep was built without mix=True")
+        code = {"none": 0.0, "mixup": 1.0, "cutmix": 2.0}[mode]
+        vals = torch.tensor([code, float(lam), *[float(v) for v in box], 0.0, 0.0], dtype=torch.float32)
+        self.lr_dev[8:16].copy_(vals, non_blocking=True)
 
     # -- one step ----------------------------------------------------------------------------------
     def _segment_ops(self):
