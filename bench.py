@@ -33,25 +33,26 @@ PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
 
 
-def conv_roofline(B, C, HW, dtype_id, iters=30, warmup=10):
-    """time the dominant kernel (input-span implicit-GEMM 3x3 conv, 256x128 tile) standalone on
-    the layer shape it spends most time on: CxC 3x3 s1 at HWxHW, batch B, with the training
-    epilogue (BN statistics)."""
+def conv_roofline(B, C, HW, dtype_id, iters=30, warmup=10, k=3, Cout=None):
+    """time one conv kernel standalone (HIP events on its launch stream) on a layer shape of the
+    model: C -> Cout (default C) kxk stride 1 at HWxHW, batch B, with the training epilogue (BN
+    statistics).  The dominant kernel is the input-span implicit-GEMM 3x3 conv."""
     from vision_toolbox import _native as N
 
+    Cout = Cout or C
     dev = torch.device("cuda", torch.cuda.current_device())
     x = torch.randn(B, HW, HW, C, device=dev).to(torch.bfloat16)
-    w = (torch.randn(C, 3, 3, C, device=dev) * (2.0 / (9 * C)) ** 0.5).to(torch.bfloat16)
-    y = torch.empty(B, HW, HW, C, device=dev, dtype=torch.bfloat16)
-    stats = torch.zeros(N.VT_STAT_REPLICAS, 2, C, device=dev)
+    w = (torch.randn(Cout, k, k, C, device=dev) * (2.0 / (k * k * C)) ** 0.5).to(torch.bfloat16)
+    y = torch.empty(B, HW, HW, Cout, device=dev, dtype=torch.bfloat16)
+    stats = torch.zeros(N.VT_STAT_REPLICAS, 2, Cout, device=dev)
     d = N.ConvDesc()
     d.dtype = dtype_id
     d.B, d.Hi, d.Wi, d.Cin, d.ldx = B, HW, HW, C, C
-    d.Ho, d.Wo, d.sh, d.sw, d.h0, d.w0 = HW, HW, 1, 1, -1, -1
-    d.Cout, d.ldy, d.oH, d.oW, d.oHs, d.oWs = C, C, HW, HW, 1, 1
-    d.ldw, d.flags, d.ntaps = 9 * C, N.VT_CONV_STATS, 9
-    for i in range(9):
-        d.dh[i], d.dw[i] = i // 3, i % 3
+    d.Ho, d.Wo, d.sh, d.sw, d.h0, d.w0 = HW, HW, 1, 1, -(k // 2), -(k // 2)
+    d.Cout, d.ldy, d.oH, d.oW, d.oHs, d.oWs = Cout, Cout, HW, HW, 1, 1
+    d.ldw, d.flags, d.ntaps = k * k * C, N.VT_CONV_STATS, k * k
+    for i in range(k * k):
+        d.dh[i], d.dw[i] = i // k, i % k
     s = int(torch.cuda.current_stream().cuda_stream)
     lib = N.lib()
 
@@ -67,9 +68,16 @@ def conv_roofline(B, C, HW, dtype_id, iters=30, warmup=10):
         launch()
     e1.record(s)
     ms = e0.elapsed_ms(e1) / iters
-    flops = 2.0 * B * HW * HW * C * 9 * C
-    return {"ms": ms, "tflops": flops / ms / 1e9, "flops": flops,
-            "shape": f"conv3x3 s1 {C}->{C} @{HW}x{HW} B={B} (M={B*HW*HW} N={C} K={9*C})"}
+    flops = 2.0 * B * HW * HW * Cout * k * k * C
+    nbytes = 2.0 * (B * HW * HW * (C + Cout) + Cout * k * k * C)  # input + output + filter once, bf16
+    return {"ms": ms, "tflops": flops / ms / 1e9, "flops": flops, "gbs": nbytes / ms / 1e6, "bytes": nbytes,
+            "shape": f"conv{k}x{k} s1 {C}->{Cout} @{HW}x{HW} B={B} (M={B*HW*HW} N={Cout} K={k*k*C})"}
+
+
+def _percentiles(v):
+    v = sorted(v)
+    pick = lambda q: v[min(len(v) - 1, int(round(q * (len(v) - 1))))]
+    return pick(0.1), pick(0.5), pick(0.9)
 
 
 def pmc_traffic():
@@ -183,8 +191,12 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    s_handle = int(torch.cuda.current_stream().cuda_stream)
+    marks = [N.Event() for _ in range(args.steps + 1)]
+    marks[0].record(s_handle)
+    for i in range(args.steps):
         ts.step()
+        marks[i + 1].record(s_handle)  # no host sync: read back after the timed region
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -204,6 +216,9 @@ def main():
         layers = [conv_roofline(args.batch, 128, 28, N.VT_BF16), conv_roofline(args.batch, 256, 14, N.VT_BF16),
                   conv_roofline(args.batch, 512, 7, N.VT_BF16)]
         dom = layers[0]
+        # HBM-bound layers of stages 0-2 (HBM fraction on the 1x1 and early-stage convs)
+        hbm_layers = [conv_roofline(args.batch, 64, 112, N.VT_BF16, k=1), conv_roofline(args.batch, 128, 56, N.VT_BF16, k=1),
+                      conv_roofline(args.batch, 8, 224, N.VT_BF16, k=3, Cout=32)]
         out = {
             "metric": f"images/sec (node) {LABELS.get(args.model, args.model)} bf16 train step @{args.image_size}px",
             "value": round(value, 2),
@@ -228,6 +243,11 @@ def main():
                          "layer": dom["shape"]},
             "roofline_layers": [{"layer": l["shape"], "ms": round(l["ms"], 4), "tflops": round(l["tflops"], 1),
                                  "frac": round(l["tflops"] / PEAK_BF16_TFLOPS, 4)} for l in layers],
+            "ms_per_step_p10_p50_p90": [round(float(v), 3) for v in
+                                        _percentiles([marks[i].elapsed_ms(marks[i + 1]) for i in range(args.steps)])],
+            "roofline_hbm_layers": [{"layer": l["shape"], "ms": round(l["ms"], 4), "gbs": round(l["gbs"], 1),
+                                     "frac": round(l["gbs"] / PEAK_HBM_GBS, 4), "algorithmic_bytes": int(l["bytes"])}
+                                    for l in hbm_layers],
             "train_step_tflops": round(28.0e9 * (args.batch / 1.0) * world / (ms * 1e-3) / 1e12, 1)
             if args.model == "cspdarknet53" and args.image_size == 224 else None,
         }
