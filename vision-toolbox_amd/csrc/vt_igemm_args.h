@@ -13,6 +13,7 @@ struct IgemmArgs {
     int B, Hi, Wi, Cin, ldx, Ho, Wo, sh, sw, h0, w0, Cout, ldy, oH, oW, oHs, oWs, oh0, ow0;
     int ldw, ldr, flags, ntaps;
     int M, Ktot, tiles_m, tiles_n, chunk, dense_out;
+    int fast_dma;  // span kernel: scalar-base LDS-DMA addressing on interior tiles
     int8_t dh[VT_MAX_TAPS];
     int8_t dw[VT_MAX_TAPS];
 };

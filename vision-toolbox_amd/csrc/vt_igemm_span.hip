@@ -66,6 +66,20 @@ __device__ __forceinline__ void glds16(unsigned long gsrc, unsigned lds_base) {
         : "memory");
 }
 
+// same, SGPR base + per-lane 32-bit byte offset: no 64-bit VALU address arithmetic per instruction
+__device__ __forceinline__ void glds16s(unsigned voff, const void* sbase, unsigned lds_base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_base)
+        : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void vm_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -202,10 +216,32 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
     const int nsteps = nchunks * p.ntaps;
     const int b_lane = (lane & 15) * 4 + ((lane >> 4) ^ swz(lane & 15));
 
+    // Fast DMA addressing (interior tiles: every span row inside [0, M), every filter row < Cout, all
+    // byte offsets < 4 GiB): scalar base + constant per-lane 32-bit offset, no VALU per instruction.
+    const bool a_fast = __all(pix0 >= 0 && pix0 + 16l * NW * (ita - 1) < p.M) && p.fast_dma &&
+                        (unsigned long)p.M * p.ldx * sizeof(T) < 0xffff0000ul;
+    bool bv_all = true;
+#pragma unroll
+    for (int i = 0; i < ITB; ++i) bv_all = bv_all && bvalid[i];
+    const bool b_fast = __all(bv_all) && p.fast_dma;
+    const char* a_sbase = (const char*)xg + (m0 + dmin) * (long)p.ldx * (long)sizeof(T);  // may precede x: unused then
+    const unsigned a_voff0 = (unsigned)((16 * wave + (lane >> 2)) * p.ldx + cj * EPC) * (unsigned)sizeof(T);
+    const unsigned a_vstep = (unsigned)(16 * NW * p.ldx) * (unsigned)sizeof(T);
+    unsigned b_voff[ITB];
+#pragma unroll
+    for (int i = 0; i < ITB; ++i)
+        b_voff[i] = (unsigned)((tn * BN + 16 * (wave + NW * i) + (lane >> 2)) * p.ldw + cj * EPC) * (unsigned)sizeof(T);
+
     // span of channel chunk `ic` into slot `sl`
 #define VT_ISSUE_A(sl, ic)                                                                   \
     do {                                                                                     \
         const unsigned long cofs = (unsigned long)(ic) * (CH * sizeof(T));                   \
+        if (a_fast) {                                                                        \
+            const char* sb = a_sbase + cofs;                                                 \
+            for (int i = 0; i < ita; ++i)                                                    \
+                glds16s(a_voff0 + i * a_vstep, sb, a_base + (unsigned)(((sl)*aslot + (wave + NW * i) * 64) * 16)); \
+            break;                                                                           \
+        }                                                                                    \
         for (int i = 0; i < ita; ++i) {                                                      \
             const long pix = pix0 + 16l * NW * i;                                            \
             const unsigned long src = (pix >= 0 && pix < p.M) ? a_src0 + i * a_istep + cofs : zero_src; \
@@ -216,6 +252,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
 #define VT_ISSUE_B(bslot, ic, it)                                                          \
     do {                                                                                   \
         const long koff = ((long)(it)*p.Cin + (long)(ic)*CH) * (long)sizeof(T);            \
+        if (b_fast) {                                                                      \
+            const char* sb = (const char*)wg + koff;                                       \
+            _Pragma("unroll") for (int i = 0; i < ITB; ++i)                                \
+                glds16s(b_voff[i], sb, b_base + (unsigned)(((bslot)*BSLOT + (wave + NW * i) * 64) * 16)); \
+            break;                                                                         \
+        }                                                                                  \
         _Pragma("unroll") for (int i = 0; i < ITB; ++i) {                                  \
             const unsigned long ps = bvalid[i] ? bbase[i] + koff : zero_src;               \
             glds16(ps, b_base + (unsigned)(((bslot)*BSLOT + (wave + NW * i) * 64) * 16));  \
@@ -614,6 +656,8 @@ int launch_span_bn(IgemmArgs& a, int dmin, int span, hipStream_t st) {
 int vt_span_dispatch(IgemmArgs& a, int dtype, void* stream) {
     static const int enabled = getenv("VT_IGEMM_SPAN") ? atoi(getenv("VT_IGEMM_SPAN")) : 1;
     if (!enabled) return -1;
+    static const int fast_dma = getenv("VT_SPAN_FAST_DMA") ? atoi(getenv("VT_SPAN_FAST_DMA")) : 1;
+    a.fast_dma = fast_dma;
     const int ch = 4 * vt_epc(dtype);
     if (a.sh != 1 || a.sw != 1 || a.Ho != a.Hi || a.Wo != a.Wi) return -1;
     if (a.Cin % ch != 0 || a.ntaps > 32) return -1;
