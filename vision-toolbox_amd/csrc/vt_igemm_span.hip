@@ -380,14 +380,20 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
         // slice of its step).  A' is needed at the first tap of its chunk; if that is NOW (few taps),
         // only the slices issued after A' may stay in flight.
         const int nb = min(PD - 1, nsteps - 1 - s);
-        int allowed = nb * ITB;
-        if (a_age >= 1 && a_age <= PD - 1) {
+        if (a_age >= 1 && a_age <= PD - 1) {  // once or twice per chunk: a span is in the window
+            int allowed = nb * ITB;
             if (it == 0 && ic > 0 && a_age == p.ntaps)
                 allowed = min(a_age, nb) * ITB;
             else
                 allowed += ita;
+            vm_wait_dyn(allowed);
+        } else if (nb >= 2) {  // the common steps: two or three compile-time counts, no decision tree
+            vm_wait<2 * ITB>();
+        } else if (nb == 1) {
+            vm_wait<ITB>();
+        } else {
+            vm_wait<0>();
         }
-        vm_wait_dyn(allowed);
         VT_LOOP_CLK(c1);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
