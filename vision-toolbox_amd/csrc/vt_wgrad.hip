@@ -35,6 +35,7 @@ struct WgradArgs {
     float* dw;
     int B, Hi, Wi, Cin, ldx, Ho, Wo, sh, sw, h0, w0, Cout, ldy, ntaps;
     int M, Ktot, ldgw, tiles_n, tiles_k, chunk, ablate;
+    unsigned magic_w, magic_h;  // ceil(2^32 / Wo), ceil(2^32 / Ho): exact n / d for n < 2^16
     int8_t dh[VT_MAX_TAPS];
     int8_t dwv[VT_MAX_TAPS];
 };
@@ -67,7 +68,10 @@ constexpr int kTapHdr = VT_MAX_TAPS * 8;
 // through its own LDS-DMA ring, and the G partial tiles are summed in LDS before ONE set of
 // global atomics leaves the workgroup -- the atomic traffic of a launch is
 // (#workgroups x 64 KiB), so more waves per workgroup means fewer atomic bytes per FLOP.
-template <typename T, int G, int kPD>
+// kUnit: 1x1 stride-1 unpadded conv -- the gathered x row of output pixel m IS input pixel m, so the
+// per-lane (image, row, column) tracking (two divergent `while` loops and ~60 VALU per step, against
+// 16 MFMAs) disappears from the loop.
+template <typename T, int G, int kPD, bool kUnit = false>
 __global__ void __launch_bounds__(256 * G) wgrad_kernel(const WgradArgs p) {
     constexpr int kNS = kPD + 1;      // ring slots per group
     constexpr int EPC = 16 / sizeof(T);
@@ -150,6 +154,13 @@ __global__ void __launch_bounds__(256 * G) wgrad_kernel(const WgradArgs p) {
         }                                                                                         \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                           \
             const int jj = wave + 4 * i;                                                          \
+            if constexpr (kUnit) {                                                                \
+                const bool xv = mrow[i] < m_end && kvalid;                                        \
+                const unsigned long px = (unsigned long)(xg + ((long)mrow[i] * p.ldx + cc));      \
+                glds16(xv ? px : zero_src,                                                        \
+                       ring_base + (unsigned)((((st)*STAGE + TILE) * (int)sizeof(T)) + jj * 1024)); \
+                mrow[i] += PK * G;                                                                \
+            } else {                                                                              \
             const int hi = pi[i] * p.sh + p.h0 + dd.x;                                            \
             const int wi = pj[i] * p.sw + p.w0 + dd.y;                                            \
             const bool xv = mrow[i] < m_end && kvalid && (unsigned)hi < (unsigned)p.Hi &&         \
@@ -159,14 +170,15 @@ __global__ void __launch_bounds__(256 * G) wgrad_kernel(const WgradArgs p) {
             glds16(xv ? px : zero_src,                                                            \
                    ring_base + (unsigned)((((st)*STAGE + TILE) * (int)sizeof(T)) + jj * 1024));    \
             mrow[i] += PK * G;                                                                    \
+            /* advance PK*G pixels: quotients by multiply-high (the `while` form cost two divergent     \
+               loops per row and step, up to 9 trips on the 7x7 maps) */                            \
             pj[i] += PK * G;                                                                      \
-            while (pj[i] >= p.Wo) {                                                               \
-                pj[i] -= p.Wo;                                                                    \
-                pi[i] += 1;                                                                       \
-            }                                                                                     \
-            while (pi[i] >= p.Ho) {                                                               \
-                pi[i] -= p.Ho;                                                                    \
-                pb[i] += 1;                                                                       \
+            const int qw = p.Wo == 1 ? pj[i] : (int)__umulhi((unsigned)pj[i], p.magic_w);         \
+            pj[i] -= qw * p.Wo;                                                                   \
+            pi[i] += qw;                                                                          \
+            const int qh = p.Ho == 1 ? pi[i] : (int)__umulhi((unsigned)pi[i], p.magic_h);         \
+            pi[i] -= qh * p.Ho;                                                                   \
+            pb[i] += qh;                                                                          \
             }                                                                                     \
         }                                                                                         \
     } while (0)
@@ -337,6 +349,8 @@ extern "C" int vt_conv_wgrad(const vt_conv_desc* d, const void* x, const void* d
     a.M = (int)M;
     a.Ktot = d->ntaps * d->Cin;
     a.ldgw = ldgw;
+    a.magic_w = (unsigned)((0x100000000ull + d->Wo - 1) / d->Wo);
+    a.magic_h = (unsigned)((0x100000000ull + d->Ho - 1) / d->Ho);
     a.tiles_n = (d->Cout + 127) / 128;
     a.tiles_k = (a.Ktot + 127) / 128;
     memcpy(a.dh, d->dh, VT_MAX_TAPS);
@@ -368,13 +382,16 @@ extern "C" int vt_conv_wgrad(const vt_conv_desc* d, const void* x, const void* d
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)tiles, (unsigned)split);
     const int stage = 2 * pk * 128 * vt_elem_size(d->dtype);  // 16 KiB
+    const bool unit = d->ntaps == 1 && d->sh == 1 && d->sw == 1 && d->h0 + d->dh[0] == 0 && d->w0 + d->dw[0] == 0 &&
+                      d->Ho == d->Hi && d->Wo == d->Wi;
 #define VT_WG_LAUNCH(TT, GG, PDD)                                                                      \
     do {                                                                                               \
         int smem = kTapHdr + GG * (PDD + 1) * stage;                                                   \
         if (GG > 1 && smem < kTapHdr + 65536) smem = kTapHdr + 65536; /* the f32 reduction image */   \
-        auto kern = wgrad_kernel<TT, GG, PDD>;                                                         \
+        auto kern = unit ? wgrad_kernel<TT, GG, PDD, true> : wgrad_kernel<TT, GG, PDD, false>;         \
         if (smem > 64 * 1024) {                                                                        \
-            static bool raised = false;                                                                \
+            static bool raised_k[2] = {false, false};                                                  \
+            bool& raised = raised_k[unit ? 1 : 0];                                                     \
             if (!raised) {                                                                             \
                 hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
                 if (e != hipSuccess) {                                                                 \
