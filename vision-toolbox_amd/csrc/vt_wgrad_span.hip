@@ -39,6 +39,7 @@ struct WsArgs {
     int PH, PW, S, NP;       // padded rows / pitch / positions per image / total positions
     int dmin, NH, RX;        // smallest tap offset, halo chunks, ring rows (power of two)
     int tiles_n, tiles_c, chunk, ablate;
+    unsigned magic_pw, magic_ph;  // ceil(2^32 / PW), ceil(2^32 / PH)  (PW, PH >= 2)
     short o[9];              // d_t - dmin
 };
 
@@ -74,10 +75,15 @@ struct Pos {  // a padded position, decomposed; advanced 32 positions per step
         i = (int)(rem / PW);
         j = (int)(rem - (long)i * PW);
     }
-    __device__ __forceinline__ void advance32(int PH, int PW) {
+    // multiply-high quotients instead of `while` loops (divergent, one trip per wrapped row)
+    __device__ __forceinline__ void advance32(int PH, int PW, unsigned magic_pw, unsigned magic_ph) {
         j += 32;
-        while (j >= PW) j -= PW, ++i;
-        while (i >= PH) i -= PH, ++b;
+        const int qw = (int)__umulhi((unsigned)j, magic_pw);
+        j -= qw * PW;
+        i += qw;
+        const int qh = (int)__umulhi((unsigned)i, magic_ph);
+        i -= qh * PH;
+        b += qh;
     }
 };
 
@@ -137,7 +143,7 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
         glds16(ok ? (unsigned long)(src_base + pix * src_ld) : zero_src, (dst) + (unsigned)wave * 1024u); \
         ++nissued;                                                                                \
         Ps += 32;                                                                                 \
-        ps.advance32(p.PH, p.PW);                                                                 \
+        ps.advance32(p.PH, p.PW, p.magic_pw, p.magic_ph);                                         \
     } while (0)
 #define VT_WS_ISSUE_STEP(slot)                                                                    \
     do {                                                                                          \
@@ -310,6 +316,8 @@ int vt_wgrad_span_dispatch(const vt_conv_desc* d, const void* x, const void* dz,
     a.ldgw = ldgw;
     a.PH = d->Hi + ph, a.PW = d->Wi + pw;
     a.S = a.PH * a.PW;
+    a.magic_pw = (unsigned)((0x100000000ull + a.PW - 1) / a.PW);
+    a.magic_ph = (unsigned)((0x100000000ull + a.PH - 1) / a.PH);
     const long NP = (long)d->B * a.S;
     if (NP > 0x7ffffff0L) return -1;
     a.NP = (int)NP;
