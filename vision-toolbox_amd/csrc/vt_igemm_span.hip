@@ -611,14 +611,14 @@ int launch_span_pd(IgemmArgs& a, int dmin, int span, hipStream_t st) {
 
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_span(IgemmArgs& a, int dmin, int span, hipStream_t st) {
-    // three filter slices in flight when the step count makes it worthwhile and two workgroups
-    // still fit a CU (VT_SPAN_PD=2/3 overrides)
+    // two filter slices in flight; a third (VT_SPAN_PD=3, where two workgroups still fit a CU) measured
+    // 3 % slower once the issue stream was cleaned up (703 vs 727 TFLOP/s on 128ch @28x28)
     static const int pd_env = getenv("VT_SPAN_PD") ? atoi(getenv("VT_SPAN_PD")) : 0;
     constexpr int NW = WM * WN;
     const int ita = (span + 16 * NW - 1) / (16 * NW);
     const int nchunks = a.Cin / (64 / (int)sizeof(T));
     const bool fits3 = 2 * SpanLds<BM, BN, 3>::bytes(ita, nchunks > 1 ? 2 : 1, NW) <= 160 * 1024;
-    const bool pd3 = pd_env ? pd_env == 3 : (fits3 && nchunks * a.ntaps >= 6);
+    const bool pd3 = pd_env == 3 && fits3 && nchunks * a.ntaps >= 6;
     if (pd3) return launch_span_pd<T, BM, BN, WM, WN, 3>(a, dmin, span, st);
     return launch_span_pd<T, BM, BN, WM, WN, 2>(a, dmin, span, st);
 }
