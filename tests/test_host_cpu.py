@@ -70,12 +70,23 @@ def test_conv_norm_act_constructor_contract():
     assert w.std().item() == pytest.approx((2 / (1.04 * 256 * 9)) ** 0.5, rel=0.05)
 
 
-def test_cpu_tensor_is_rejected_loudly():
+def test_gpu_path_never_falls_back_to_the_eager_path(monkeypatch):
+    """dispatch rule: CPU tensors -> the modules' own torch children; a GPU tensor must go to
+    libvt_amd and fail loudly when the library is missing -- never silently through the eager path"""
     m = backbones.darknet19()
-    with pytest.raises(RuntimeError, match="no CPU/eager fallback"):
-        m(torch.zeros(1, 3, 64, 64))
-    with pytest.raises(RuntimeError, match="no CPU/eager fallback"):
-        m.get_feature_maps(torch.zeros(1, 3, 64, 64))
+    assert m(torch.zeros(1, 3, 64, 64)).shape == (1, 1024, 2, 2)
+
+    class _FakeCuda(torch.Tensor):
+        is_cuda = True
+
+    x = torch.zeros(1, 3, 64, 64).as_subclass(_FakeCuda)
+    monkeypatch.setattr(N, "_lib", None)
+    monkeypatch.setattr(N, "LIB_PATH", ROOT / "nope.so")
+    called = []
+    monkeypatch.setattr(type(m), "_eager_maps", lambda self, x: called.append(1) or [])
+    with pytest.raises(ImportError, match="no CPU/eager fallback"):
+        m(x)
+    assert not called
 
 
 def test_parameter_groups_follow_classifier_py():

@@ -165,8 +165,8 @@ def gen_blocks():
     print("blocks:", len(out), "arrays")
 
 
-MODEL_CASES = ["darknet19", "cspdarknet53", "darknet53", "darknet_yolov5n", "vovnet39", "vovnet19_slim_ese",
-               "vovnet27_slim"]
+MODEL_CASES = ["darknet19", "cspdarknet53", "darknet53", "darknet_yolov5n", "darknet_yolov5x", "vovnet39",
+               "vovnet19_slim_ese", "vovnet27_slim"]
 NUM_CLASSES, LABEL_SMOOTHING = 16, 0.1
 
 
@@ -244,6 +244,20 @@ def gen_models():
         out["darknet19.cfg1.last.summary"] = summary(f)
         out["darknet19.cfg1.last.samples"] = samples(f, 256)
         out["darknet19.cfg1.logits"] = np_(model(x))
+    # BASELINE config 5: Darknet-YOLOv5x get_feature_maps() @640px.  Eval mode (running statistics), so an
+    # image's maps do not depend on its batch mates: the GPU test places these two images at positions 0
+    # and 63 of its 64-image batch.
+    model = FACTORIES["darknet_yolov5x"]()
+    filler.fill_module(model, "darknet_yolov5x.cfg5.")
+    model.eval()
+    x = filler.images(2, 640, seed=640)
+    with torch.no_grad():
+        maps = model.get_feature_maps(x)
+    for i, mp in enumerate(maps):
+        out[f"darknet_yolov5x.cfg5.map{i}.shape"] = np.array(mp.shape)
+        for b in range(2):
+            out[f"darknet_yolov5x.cfg5.map{i}.img{b}.summary"] = summary(mp[b])
+            out[f"darknet_yolov5x.cfg5.map{i}.img{b}.samples"] = samples(mp[b], 512)
     np.savez_compressed(GOLDEN / "models.npz", **out)
     print("models:", len(out), "arrays")
 

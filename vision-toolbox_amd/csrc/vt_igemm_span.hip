@@ -51,6 +51,12 @@ __device__ unsigned long long vt_span_loop[8192 * 4];
 #define VT_LOOP_ACC(k, a, b) do { } while (0)
 #endif
 
+// diagnostic builds only (tools/build_diag.sh): -DVT_SPAN_ABLATE=<bits>  1: no MFMA, 2: no LDS-DMA inside the
+// main loop, 4: no fragment reads.  Results are wrong by construction; only the time is read.
+#ifndef VT_SPAN_ABLATE
+#define VT_SPAN_ABLATE 0
+#endif
+
 __device__ __forceinline__ int swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
 
 __device__ __forceinline__ void glds16(unsigned long gsrc, unsigned lds_base) {
@@ -380,6 +386,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
         // slice of its step).  A' is needed at the first tap of its chunk; if that is NOW (few taps),
         // only the slices issued after A' may stay in flight.
         const int nb = min(PD - 1, nsteps - 1 - s);
+        if constexpr ((VT_SPAN_ABLATE & 2) != 0) {
+            if (s == 0) vm_wait<0>();
+        } else
         if (a_age >= 1 && a_age <= PD - 1) {  // once or twice per chunk: a span is in the window
             int allowed = nb * ITB;
             if (it == 0 && ic > 0 && a_age == p.ntaps)
@@ -400,6 +409,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
         VT_LOOP_CLK(c2);
         // issue: next chunk's span at the first tap of a chunk, then the slice of step s+PD
         a_age = a_age ? a_age + 1 : 0;
+        if constexpr ((VT_SPAN_ABLATE & 2) == 0) {
         if (it == 0 && ic + 1 < nchunks) {
             VT_ISSUE_A((ic + 1) & 1, ic + 1);
             a_age = 1;
@@ -407,6 +417,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
         if (s + PD < nsteps) {
             VT_ISSUE_B(bnxt, ic_n, it_n);
             if (++it_n == p.ntaps) it_n = 0, ++ic_n;
+        }
         }
 
         VT_LOOP_CLK(c3);
@@ -418,12 +429,16 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
             uint4 af[FM], bf[FN];
             // filter fragments first: every MFMA of the first A row needs them
 #pragma unroll
-            for (int j = 0; j < FN; ++j) bf[j] = Bt[j * 64];
+            for (int j = 0; j < FN; ++j) {
+                if constexpr ((VT_SPAN_ABLATE & 4) != 0) bf[j] = make_uint4(lane + j, s, lane, 0x3f803f80u);
+                else bf[j] = Bt[j * 64];
+            }
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 // (sZ - i*64)[i*64] == sZ[0]: the constant stays in the instruction's offset field
                 const uint4* src = ((fmask[i] >> it) & 1u) ? A : sZ - i * 64;
-                af[i] = src[i * 64];
+                if constexpr ((VT_SPAN_ABLATE & 4) != 0) af[i] = make_uint4(0x3f803f80u, lane * 3 + i, s, (unsigned)(unsigned long)src);
+                else af[i] = src[i * 64];
             }
             // all fragment reads are issued before the first MFMA (the scheduler otherwise funnels
             // the A fragments through one register quad: read, wait lgkmcnt(0), 4 MFMAs, read, ...)
@@ -431,7 +446,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) mma<T>(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < FN; ++j) {
+                    if constexpr ((VT_SPAN_ABLATE & 1) != 0)
+                        asm volatile("" ::"v"(af[i].x), "v"(af[i].y), "v"(af[i].z), "v"(af[i].w), "v"(bf[j].x), "v"(bf[j].y), "v"(bf[j].z), "v"(bf[j].w));
+                    else mma<T>(af[i], bf[j], acc[i][j]);
+                }
         }
 #ifdef VT_SPAN_STAMPS
         asm volatile("s_nop 0" ::: "memory");

@@ -43,6 +43,9 @@ class DarknetBlock(HipModule):
     def _vt_emit_maps(self, b, x):
         return [self._vt_emit(b, x)]
 
+    def _eager_maps(self, x):
+        return [x + self.conv2._eager(self.conv1._eager(x))]
+
 
 def _emit_chain(blocks: Sequence[DarknetBlock], b, x, out, name: str):
     last = len(blocks) - 1
@@ -66,6 +69,12 @@ class DarknetStage(nn.Sequential, HipModule):
 
     def _vt_emit_maps(self, b, x):
         return [self._vt_emit(b, x)]
+
+    def _eager_maps(self, x):
+        h = self.conv._eager(x)
+        for blk in self.blocks:
+            h = blk._eager(h)
+        return [h]
 
     def forward(self, x):
         return HipModule.forward(self, x)
@@ -96,6 +105,15 @@ class CSPDarknetStage(HipModule):
 
     def _vt_emit_maps(self, b, x):
         return [self._vt_emit(b, x)]
+
+    def _eager_maps(self, x):
+        import torch
+
+        o = self.conv._eager(x)
+        bypass, h = self.conv1._eager(o), self.conv2._eager(o)
+        for blk in self.blocks:
+            h = blk._eager(h)
+        return [self.out_conv._eager(torch.cat((bypass, h), dim=1))]
 
 
 class DarknetStageConfig(NamedTuple):
@@ -133,6 +151,13 @@ class Darknet(BaseBackbone):
             maps.append(o)
         return maps  # the stem is not a feature map (ref :87)
 
+    def _eager_maps(self, x):
+        h, maps = self.stem._eager(x), []
+        for stage in self.stages:
+            h = stage._eager(h)
+            maps.append(h)
+        return maps
+
     _VARIANTS = {
         # name: (blocks per stage, stage class, checkpoint)
         "darknet19": ((0, 1, 1, 2, 2), DarknetStage, "darknet19-2cb641ca.pth"),
@@ -166,6 +191,12 @@ class DarknetYOLOv5(BaseBackbone):
         maps = [self.stem._vt_emit(b, x, name="stem")]  # the stem IS returned here (ref :120)
         for i, stage in enumerate(self.stages):
             maps.append(stage._vt_emit(b, maps[-1], name=f"stages.{i}"))
+        return maps
+
+    def _eager_maps(self, x):
+        maps = [self.stem._eager(x)]
+        for stage in self.stages:
+            maps.append(stage._eager(maps[-1]))
         return maps
 
     _SCALES = {

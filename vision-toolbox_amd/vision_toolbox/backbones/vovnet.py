@@ -42,6 +42,9 @@ class ESEBlock(HipModule):
     def _vt_emit_maps(self, b, x):
         return [self._vt_emit(b, x)]
 
+    def _eager_maps(self, x):
+        return [x * self.gate(self.linear(self.pool(x)))]
+
 
 class OSABlock(HipModule):
     def __init__(self, in_channels: int, mid_channels: int, num_layers: int, out_channels: int,
@@ -84,6 +87,17 @@ class OSABlock(HipModule):
 
     def _vt_emit_maps(self, b, x):
         return [self._vt_emit(b, x)]
+
+    def _eager_maps(self, x):
+        import torch
+
+        feats = [x]
+        for conv in self.convs:
+            feats.append(conv._eager(feats[-1]))
+        y = self.out_conv._eager(torch.cat(feats, dim=1))
+        if self.ese is not None:
+            y = self.ese._eager(y)
+        return [y + x if self.residual else y]
 
 
 class VoVNetStageConfig(NamedTuple):
@@ -142,6 +156,17 @@ class VoVNet(BaseBackbone):
                 o = blk._vt_emit_from_concat(b, joined, out=out, name=f"stages.{si}.module_{bi}")
                 joined = nxt
             maps.append(o)
+        return maps
+
+    def _eager_maps(self, x):
+        h = x
+        for unit in self.stem:
+            h = unit._eager(h)
+        maps = [h]
+        for stage in self.stages:
+            for m in stage.children():
+                h = m._eager(h) if isinstance(m, HipModule) else m(h)  # MaxPool2d, then the OSA blocks
+            maps.append(h)
         return maps
 
     _DEPTHS = {

@@ -7,6 +7,7 @@ isinstance-based parameter grouping (classifier.py:111-155) keeps working.  What
 is execution: on the GPU the unit is not three ATen calls but a few launches of
 libvt_amd (implicit-GEMM conv on MFMA with the BN statistics in its epilogue, one
 normalise+ReLU(+residual) pass), emitted into a static launch list by `_vt_emit`.
+CPU tensors run the children with plain torch ops (`_eager_maps`), as in the reference.
 """
 from __future__ import annotations
 
@@ -46,6 +47,15 @@ class HipModule(nn.Module):
 
     def _vt_emit(self, b, x, out=None):
         return self._vt_emit_maps(b, x)[-1]
+
+    # Dispatch rule: the SAME module class serves CPU tensors through plain torch ops over
+    # its own nn.Conv2d / nn.BatchNorm2d / nn.ReLU children (`_eager*`), and GPU tensors through
+    # libvt_amd.  The runner picks by `x.is_cuda`; a GPU tensor never takes the eager path.
+    def _eager_maps(self, x: Tensor) -> "list[Tensor]":  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    def _eager(self, x: Tensor) -> Tensor:
+        return self._eager_maps(x)[-1]
 
     def forward(self, x: Tensor) -> Tensor:
         return self._vt_runner()(x, all_maps=False, compute_dtype=self.compute_dtype)[-1]
@@ -111,6 +121,9 @@ class ConvNormAct(nn.Sequential, HipModule):
 
     def _vt_emit_maps(self, b, x):
         return [self._vt_emit(b, x)]
+
+    def _eager_maps(self, x: Tensor) -> "list[Tensor]":
+        return [self.act(self.norm(self.conv(x)))]
 
     def forward(self, x: Tensor) -> Tensor:
         return HipModule.forward(self, x)

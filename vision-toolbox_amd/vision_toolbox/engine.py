@@ -11,7 +11,8 @@ unit (no autograd inside), which is what allows concat elision, residual adds
 folded into epilogues and gradient accumulation folded into the data-gradient
 epilogue.
 
-Only CUDA (HIP) tensors are accepted; there is no CPU path in this package.
+Only CUDA (HIP) tensors reach this module; CPU tensors are served by the modules' own
+torch children (program.py dispatch rule) and never by these launch lists.
 """
 from __future__ import annotations
 
@@ -526,7 +527,10 @@ class Builder:
             assert (residual.B, residual.H, residual.W, residual.C) == (B, Ho, Wo, Cout)
 
         track = self.need_grad
-        fused = has_bn and not self.training and not track
+        # the unit follows ITS BatchNorm's flag (a frozen bn.eval() inside a training model uses the
+        # running statistics and leaves them untouched, like nn.BatchNorm2d)
+        unit_training = bool(norm.training) if has_bn else self.training
+        fused = has_bn and not unit_training and not track
         y = out if out is not None else self.act(B, Ho, Wo, Cout, name + ".y")
         z = None
         coef = None
@@ -543,7 +547,7 @@ class Builder:
                                         residual.addr() if residual else None, None], desc=d)
         elif has_bn:
             z = self.act(B, Ho, Wo, Cout, name + ".z")
-            if self.training:
+            if unit_training:
                 stats = self.zeroed_f32(N.VT_STAT_REPLICAS * 2 * Cout, "stats")
                 d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, z.ld, ldw, N.VT_CONV_STATS)
                 self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, z.addr(), None, None, None, self.bp(stats)], desc=d)
@@ -567,7 +571,7 @@ class Builder:
 
         if track:
             tag = self.tag
-            training = self.training
+            training = unit_training
 
             def bwd():
                 self.tag = tag

@@ -22,7 +22,7 @@ from torch import Tensor, nn
 from . import _native as N
 from . import engine as E
 from .components import ConvNormAct
-from .program import Program, current_stream_handle, tracing_paused
+from .program import Program, current_stream_handle, mode_signature, tracing_paused
 
 __all__ = ["FPN", "PAN"]
 
@@ -51,8 +51,8 @@ class _NeckRunner:
         self.cache: dict = {}
 
     def program(self, xs: Sequence[Tensor], dtype: int, need_grad: bool) -> Program:
-        key = (tuple(tuple(x.shape) for x in xs), dtype, self.module.training, need_grad,
-               tuple(bool(x.requires_grad) for x in xs), self.store.version)
+        key = (tuple(tuple(x.shape) for x in xs), dtype, need_grad,
+               tuple(bool(x.requires_grad) for x in xs), self.store.version, mode_signature(self.module, self.store))
         prog = self.cache.get(key)
         if prog is None:
             b = E.Builder(self.store, dtype, self.module.training, need_grad)
@@ -75,10 +75,11 @@ class _NeckRunner:
         xs = list(xs)
         if not xs or any((not isinstance(x, Tensor)) or x.dim() != 4 for x in xs):
             raise ValueError("expected a list of 4-D NCHW feature maps")
+        if all(not x.is_cuda for x in xs):
+            return self.module._eager_list(xs)  # dispatch rule: CPU tensors -> plain torch ops
         if any(not x.is_cuda for x in xs):
-            raise RuntimeError("vision_toolbox (MI355X build) runs its necks only on the GPU through libvt_amd; "
-                               "there is deliberately no CPU/eager fallback (use oracle/ for a CPU reference).")
-        N.lib()
+            raise RuntimeError("feature maps on different devices")
+        N.lib()  # a GPU tensor never falls back to the eager path
         if len({x.dtype for x in xs}) != 1:
             raise ValueError("feature maps of one dtype expected")
         if xs[0].dtype == torch.bfloat16 or (torch.is_autocast_enabled() and
@@ -208,6 +209,18 @@ class FPN(_NeckBase):
             outs[dst] = oc._vt_emit(b, fused, name=f"{name}.output_convs.{i}")
         return outs
 
+    def _eager_list(self, xs):
+        """CPU tensors: the same wiring with torch ops over this module's children."""
+        if self.fuse_fn != "sum":
+            raise NotImplementedError("fuse_fn other than 'sum' is outside the hot path")
+        assert len(xs) == len(self.lateral_convs)
+        outs = [lat(x) for lat, x in zip(self.lateral_convs, xs)]
+        n = len(outs)
+        for i, oc in enumerate(self.output_convs):
+            dst, src = (n - 2 - i, n - 1 - i) if self.top_down else (i + 1, i)
+            outs[dst] = oc(outs[dst] + self.upsample(outs[src]))
+        return outs
+
 
 # https://arxiv.org/abs/1803.01534
 class PAN(_NeckBase):
@@ -228,3 +241,6 @@ class PAN(_NeckBase):
     def _vt_emit_list(self, b, xs, name: str = "pan"):
         return self.bottom_up._vt_emit_list(b, self.top_down._vt_emit_list(b, xs, name + ".top_down"),
                                             name + ".bottom_up")
+
+    def _eager_list(self, xs):
+        return self.bottom_up._eager_list(self.top_down._eager_list(xs))

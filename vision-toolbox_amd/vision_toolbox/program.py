@@ -54,6 +54,14 @@ def resolve_dtype(x: torch.Tensor, override: Optional[torch.dtype]) -> int:
     raise TypeError(f"vision_toolbox (MI355X): compute dtype {dt} is not supported (float32 or bfloat16)")
 
 
+def mode_signature(module: nn.Module, store: "E.ParamStore") -> tuple:
+    """what a compiled program bakes in besides shapes: the train/eval flag of every BatchNorm (a
+    frozen `bn.eval()` inside a training model must use its running statistics, as nn.BatchNorm2d
+    does) and which parameters receive gradients."""
+    bn = tuple(m.training for m in module.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm))
+    return bn, tuple(p.requires_grad for p in store.params)
+
+
 class Program:
     """Forward (+ backward) launch lists over one arena."""
 
@@ -136,8 +144,8 @@ class BackboneRunner:
 
     # -- compile ------------------------------------------------------------------
     def program(self, x: torch.Tensor, dtype: int, all_maps: bool, need_grad: bool) -> Program:
-        key = (tuple(x.shape), dtype, self.module.training, all_maps, need_grad, x.requires_grad and need_grad,
-               self.store.version)
+        key = (tuple(x.shape), dtype, all_maps, need_grad, x.requires_grad and need_grad,
+               self.store.version, mode_signature(self.module, self.store))
         prog = self.cache.get(key)
         if prog is None:
             B, C_, H, W = x.shape
@@ -163,12 +171,11 @@ class BackboneRunner:
         if not isinstance(x, torch.Tensor) or x.dim() != 4:
             raise ValueError("expected a 4-D NCHW image tensor")
         if not x.is_cuda:
-            raise RuntimeError(
-                "vision_toolbox (MI355X build) runs its backbones only on the GPU through libvt_amd; "
-                f"got a {x.device.type} tensor. There is deliberately no CPU/eager fallback "
-                "(use oracle/ for a CPU reference)."
-            )
-        N.lib()  # raises if the extension is missing
+            # dispatch rule: CPU tensors run the module's own nn children with plain torch
+            # ops, exactly what the reference does; nothing here touches libvt_amd or oracle/
+            maps = self.module._eager_maps(x)
+            return list(maps) if all_maps else list(maps[-1:])
+        N.lib()  # raises if the extension is missing: a GPU tensor never falls back to the eager path
         dtype = resolve_dtype(x, compute_dtype)
         tracing = torch._C._get_tracing_state() is not None
         with tracing_paused():
