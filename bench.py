@@ -7,8 +7,14 @@ A step = forward + label-smoothing CE + backward + gradient all-reduce (N>1) + S
 over one synthetic batch resident in HBM (BASELINE.json configs[1]: batch 256 per GPU,
 3x224x224, uniform [0,1) images, random-init weights; weak scaling for N>1).
 Rank 0 prints ONE JSON line with the metric, the roofline of the dominant kernel
-(measured live with HIP events on the launch stream) and the CPU baseline (the oracle,
-timed on the host cores on a bounded sample).
+(measured live, IN SITU: HIP events around that layer's launches inside the step's own forward
+list, on the launch stream) and the CPU baseline (the oracle, timed on the host cores on a
+bounded sample).
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own N
+ranks (fresh child processes, one per GPU, rendezvous on 127.0.0.1) the way Lightning spawns the
+reference's ranks from one command (configs/base.yaml:17-19); under torch.distributed.run it
+uses the ranks it is given.
 """
 from __future__ import annotations
 
@@ -74,33 +80,182 @@ def conv_roofline(B, C, HW, dtype_id, iters=30, warmup=10, k=3, Cout=None):
             "shape": f"conv{k}x{k} s1 {C}->{Cout} @{HW}x{HW} B={B} (M={B*HW*HW} N={Cout} K={k*k*C})"}
 
 
+def self_launch(n: int) -> int:
+    """start `n` ranks of this script as child processes (never re-exec a process that touched the
+    GPU: the parent has not, and only waits); rank 0 prints the JSON line; returns the worst rc."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:  # a dead rank leaves the others stuck in a collective
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def host_cpu():
+    """(physical cores, model name) of the host; os.cpu_count() counts SMT threads"""
+    model, pairs, phys, core = "", set(), None, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and not model:
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None and core is not None:
+                pairs.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            pairs.add((phys, core))
+    except OSError:
+        pass
+    ncores = len(pairs) or (os.cpu_count() or 1)
+    try:  # respect a cgroup / affinity limit (the build container exposes 8 CPUs of a bigger host)
+        ncores = min(ncores, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    return ncores, model
+
+
+def insitu_layer_times(ts, Cin, Cout, ntaps, HW, reps=4):
+    """HIP-event time of every forward launch of the conv layer shape (Cin -> Cout, ntaps, HW x HW, stride 1)
+    INSIDE the step's forward list: the list is run in pieces with events around those ops, so each launch
+    reads what the previous kernels of the step left behind a 20 GB arena (not a cache-resident toy).
+    Returns (mean ms, launches timed, kernel name chosen by the dispatcher)."""
+    from vision_toolbox import _native as N
+
+    p = ts.prog
+    idxs = []
+    for i in range(p.n_fwd):
+        op = p.fwd_ops[i]
+        if (op.kind & 0xFFFF) != N.OP_CONV_IGEMM:
+            continue
+        d = N.ConvDesc.from_buffer_copy(bytes(op.i)[: ctypes.sizeof(N.ConvDesc)])
+        if (d.Cin, d.Cout, d.ntaps, d.Hi, d.Wi, d.sh) == (Cin, Cout, ntaps, HW, HW, 1):
+            idxs.append(i)
+    if not idxs:
+        return None, 0, ""
+    s = int(torch.cuda.current_stream().cuda_stream)
+    side = int(ts._side.cuda_stream) if ts._side is not None else 0
+    sz = ctypes.sizeof(N.Op)
+
+    def run(lo, hi):
+        if hi > lo:
+            sub = (N.Op * (hi - lo)).from_address(ctypes.addressof(p.fwd_ops) + lo * sz)
+            N.run_ops(sub, hi - lo, ts.bases, s, side=side)
+
+    pairs, name = [], ""
+    for _ in range(reps):
+        N.run_ops(ts.zero_ops, 1, ts.bases, s)
+        lo = 0
+        for i in idxs:
+            run(lo, i)
+            e0, e1 = N.Event(), N.Event()
+            e0.record(s)
+            run(i, i + 1)
+            e1.record(s)
+            name = N.last_kernel_name()
+            pairs.append((e0, e1))
+            lo = i + 1
+        run(lo, p.n_fwd)
+    torch.cuda.synchronize()
+    ms = [a.elapsed_ms(b) for a, b in pairs]
+    return sum(ms) / len(ms), len(ms), name
+
+
+def pmc_traffic_live(layer: str, kernel_substr: str, timeout_s: int = 150):
+    """HBM-side bytes per launch of the dominant kernel, measured NOW: two rocprofv3 child runs
+    (FETCH_SIZE and WRITE_SIZE in SEPARATE passes, as MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled
+    on gfx950) of tools/bench_conv.py on that layer.  None if the profiler is unavailable."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="vt_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            env.pop("WORLD_SIZE", None)
+            subprocess.run([prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", tmp, "--",
+                            sys.executable, str(ROOT / "tools" / "bench_conv.py"), "fwd", layer],
+                           cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            files = glob.glob(f"{tmp}/**/*counter_collection.csv", recursive=True)
+            vals = []
+            for f in files:
+                for r in csv.DictReader(open(f)):
+                    if kernel_substr in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None
+            out[counter] = sum(vals) / len(vals)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    # rocprofv3 reports both in KB; FETCH_SIZE counts 64 B per 128-B request on gfx950 -> doubled
+    return {"bytes": out["FETCH_SIZE"] * 1024 * 2 + out["WRITE_SIZE"] * 1024,
+            "fetch_kb_raw": out["FETCH_SIZE"], "write_kb": out["WRITE_SIZE"]}
+
+
 def _percentiles(v):
     v = sorted(v)
     pick = lambda q: v[min(len(v) - 1, int(round(q * (len(v) - 1))))]
     return pick(0.1), pick(0.5), pick(0.9)
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC pass
-    (profiles/r01_dominant_kernel_pmc.json: FETCH_SIZE x2 (gfx950) + WRITE_SIZE, separate runs)."""
-    f = ROOT / "profiles" / "r01_dominant_kernel_pmc.json"
-    try:
-        return float(json.loads(f.read_text())["traffic_bytes"])
-    except Exception:
-        return None
-
-
-def cpu_baseline(seconds: float = 12.0):
-    """oracle (pure torch CPU fp32 restatement of the reference) CSPDarknet-53 train step."""
+def cpu_baseline(budget_s: float = 75.0):
+    """the oracle (pure torch CPU fp32 restatement of the reference) on the host's physical
+    cores: CSPDarknet-53 train step (fwd + CE + bwd + SGD) at batch 32, and Darknet-19 forward at batch 1,
+    3 warm-up + 10 timed each (the train-step loop stops early once `budget_s` is spent, and says so)."""
     from oracle import filler
     from oracle import torch_ref as R
 
+    cores, cpu_model = host_cpu()
+    torch.set_num_threads(cores)
     torch.manual_seed(0)
-    name, ncls, bs = "cspdarknet53", 1000, 8
-    sd = {}
-    for k, shape in R.classifier_spec(name, ncls).items():
-        dt = torch.int64 if k.endswith("num_batches_tracked") else torch.float32
-        sd[k] = filler.fill_tensor("cpu." + k, torch.zeros(shape, dtype=dt))
+
+    def state(name, ncls):
+        sd = {}
+        for k, shape in R.classifier_spec(name, ncls).items():
+            dt = torch.int64 if k.endswith("num_batches_tracked") else torch.float32
+            sd[k] = filler.fill_tensor("cpu." + k, torch.zeros(shape, dtype=dt))
+        return sd
+
+    name, ncls, bs = "cspdarknet53", 1000, 32
+    sd = state(name, ncls)
     params = {k: v for k, v in sd.items()
               if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))}
     for v in params.values():
@@ -116,17 +271,37 @@ def cpu_baseline(seconds: float = 12.0):
         R.sgd_step(params, {k: v.grad for k, v in params.items()}, mom, 0.05, 0.9,
                    lambda k: R.weight_decay_group(k, 2e-5, 0.0, 0.0))
 
-    step()  # warm-up
+    t_start = time.perf_counter()
+    warm = 0
+    for _ in range(3):
+        step()
+        warm += 1
+        if time.perf_counter() - t_start > budget_s * 0.3:
+            break
     n, t0 = 0, time.perf_counter()
-    while True:
+    while n < 10:
         step()
         n += 1
-        el = time.perf_counter() - t0
-        if el >= seconds and n >= 2:
+        if time.perf_counter() - t_start > budget_s and n >= 2:
             break
-    return {"value": round(bs * n / el, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+    el = time.perf_counter() - t0
+
+    sd19 = state("darknet19", ncls)
+    x1 = filler.images(1, 224, seed=224)
+    with torch.no_grad():
+        for _ in range(3):
+            R.classifier_logits("darknet19", sd19, x1, False)
+        t1 = time.perf_counter()
+        for _ in range(10):
+            R.classifier_logits("darknet19", sd19, x1, False)
+        d19_ms = (time.perf_counter() - t1) / 10 * 1e3
+    return {"value": round(bs * n / el, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model, "logical_cpus": os.cpu_count(),
+            "darknet19_fwd_b1_ms": round(d19_ms, 2),
             "sample": f"oracle/torch_ref.py CSPDarknet-53 fp32 train step (fwd+CE+bwd+SGD), batch {bs} @224, "
-                      f"{n} steps in {el:.1f}s after 1 warm-up, torch {torch.__version__} CPU"}
+                      f"{n} timed steps in {el:.1f}s after {warm} warm-up; Darknet-19 forward batch 1 @224 "
+                      f"(BASELINE configs[0]) 3 warm-up + 10 timed; torch {torch.__version__} CPU, "
+                      f"{cores} threads = physical cores"}
 
 
 def main():
@@ -149,7 +324,14 @@ def main():
     ap.add_argument("--main-priority", type=int, default=0,
                     help="run the step on a torch stream of this priority (-1 = high): the filter-gradient side "
                          "stream then only fills what the critical path leaves")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 child runs that measure `traffic`")
+    ap.add_argument("--plan-only", action="store_true",
+                    help="(tests) build the launch lists and the bucket plan on the CPU, run the first collectives "
+                         "over the given backend and exit: exercises the N>1 launch path without a GPU")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))  # before anything touches the GPU
 
     from vision_toolbox import _native as N
     from vision_toolbox import backbones
@@ -163,7 +345,28 @@ def main():
         os.environ["LOCAL_RANK"] = os.environ["VT_FORCE_DEVICE"]
     rank, local, world = init_from_env(backend)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.plan_only:
+        torch.manual_seed(0)
+        ts = TrainStep(getattr(backbones, args.model)(), 1000, args.batch, args.image_size, torch.bfloat16,
+                       device="cpu", bucket_mb=args.bucket_mb, plan_only=True, sync_bn=args.sync_bn)
+        ts.store.pflat.add_(float(rank))  # ranks start different; the broadcast must make them equal
+        ts.broadcast_parameters(0)
+        ts.gflat.fill_(float(rank + 1))
+        ts.bucketer.reduce_all()
+        ts.bucketer.finish()
+        ok = bool((ts.gflat == world * (world + 1) / 2).all())
+        chk = torch.tensor([float(ts.store.pflat.double().sum())], dtype=torch.float64)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"plan_only": True, "n_gpus": world, "backend": backend, "buckets": len(ts.bucketer.buckets),
+                              "bwd_segments": len(ts.bwd_cuts), "allreduce_ok": ok,
+                              "params_equal": bool(lo.item() == hi.item())}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -211,11 +414,30 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = args.batch * world * args.steps / elapsed
-        # dominant kernel: span_kernel<bf16,224,128> (vt_igemm_span.hip; 224-row tiles at this pixel count) on the stride-1 3x3 convs and
-        # their data gradients; roofline on the layer shape with the largest share of the step
+        # Dominant kernel: the input-span implicit-GEMM conv (vt_igemm_span.hip) on the stride-1 3x3 convs and
+        # their data gradients.  Its roofline entry is measured IN SITU on the layer shape with the largest
+        # share of the step (cspdarknet53: 128 -> 128 3x3 @28x28, 8 instances): events around those launches
+        # inside the forward list.  `roofline_layers` keeps the standalone (back-to-back, cache-warm) numbers.
+        scale = args.image_size / 224.0
+        dom_shape = (128, 128, 9, int(round(28 * scale))) if args.model in ("cspdarknet53", "darknet53") else None
+        insitu = None
+        if dom_shape is not None:
+            ms_l, n_l, kname = insitu_layer_times(ts, *dom_shape)
+            if ms_l:
+                fl = 2.0 * args.batch * dom_shape[3] ** 2 * dom_shape[1] * dom_shape[2] * dom_shape[0]
+                insitu = {"ms": ms_l, "n": n_l, "kernel": kname, "tflops": fl / ms_l / 1e9, "flops": fl,
+                          "shape": f"conv3x3 s1 {dom_shape[0]}->{dom_shape[1]} @{dom_shape[3]}x{dom_shape[3]} B={args.batch} "
+                                   f"(M={args.batch * dom_shape[3] ** 2} N={dom_shape[1]} K={dom_shape[2] * dom_shape[0]})"}
         layers = [conv_roofline(args.batch, 128, 28, N.VT_BF16), conv_roofline(args.batch, 256, 14, N.VT_BF16),
                   conv_roofline(args.batch, 512, 7, N.VT_BF16)]
-        dom = layers[0]
+        standalone_name = None
+        conv_roofline(args.batch, 128, 28, N.VT_BF16, iters=1, warmup=0)
+        standalone_name = N.last_kernel_name()
+        dom = insitu or {"ms": layers[0]["ms"], "n": 30, "kernel": standalone_name, "tflops": layers[0]["tflops"],
+                         "flops": layers[0]["flops"], "shape": layers[0]["shape"]}
+        traffic = None
+        if world == 1 and not args.no_pmc:
+            traffic = pmc_traffic_live("128,128,3,1,28", "span_kernel")
         # HBM-bound layers of stages 0-2 (HBM fraction on the 1x1 and early-stage convs)
         hbm_layers = [conv_roofline(args.batch, 64, 112, N.VT_BF16, k=1), conv_roofline(args.batch, 128, 56, N.VT_BF16, k=1),
                       conv_roofline(args.batch, 8, 224, N.VT_BF16, k=3, Cout=32)]
@@ -238,9 +460,13 @@ def main():
                        "hip_graphs": bool(args.graphs), "sync_bn": bool(args.sync_bn), "final_loss": round(loss, 4)},
             "roofline": {"bound": "mfma", "achieved": round(dom["tflops"], 1), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4),
-                         "traffic": pmc_traffic(),
-                         "kernel": "span_kernel<bf16,224,128,2,2>", "launch_ms": round(dom["ms"], 4),
-                         "layer": dom["shape"]},
+                         "traffic": traffic["bytes"] if traffic else None,
+                         "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH x2 on gfx950) "
+                                            "run by this bench on tools/bench_conv.py" if traffic else None),
+                         "algorithmic_bytes": 2.0 * (args.batch * 28 * 28 * 256 + 128 * 1152),
+                         "kernel": dom["kernel"], "launch_ms": round(dom["ms"], 4), "launches_timed": dom["n"],
+                         "measured": "in situ (events around the layer's launches inside the step's forward list)"
+                         if insitu else "standalone", "layer": dom["shape"]},
             "roofline_layers": [{"layer": l["shape"], "ms": round(l["ms"], 4), "tflops": round(l["tflops"], 1),
                                  "frac": round(l["tflops"] / PEAK_BF16_TFLOPS, 4)} for l in layers],
             "ms_per_step_p10_p50_p90": [round(float(v), 3) for v in

@@ -79,6 +79,9 @@ typedef struct vt_conv_desc {
 /* ---- library ------------------------------------------------------------ */
 int vt_version(void);
 const char* vt_last_error(void);
+/* name (template instantiation) of the convolution / filter-gradient kernel the calling thread's most
+ * recent vt_conv_igemm / vt_conv_wgrad dispatch chose; bench.py labels its roofline entry with it. */
+const char* vt_last_kernel_name(void);
 /* number of kernel launches issued by this process through the library; the
  * GPU tests assert it advances, i.e. that the HIP path is what ran. */
 uint64_t vt_launch_count(void);

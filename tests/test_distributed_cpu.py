@@ -104,3 +104,28 @@ def test_two_rank_gloo_bucketed_allreduce_and_train_plan():
     assert sorted(r[0] for r in results) == [0, 1]
     for r in results:
         assert all(r[1:]), r
+
+
+def test_bench_launches_its_own_ranks_from_one_command():
+    """`python bench.py --gpus 2` (the driver's command shape) must start its two ranks itself, the way
+    Lightning does for the reference (configs/base.yaml:17-19).  Plan-only over gloo: launch lists and the
+    bucket plan are built on the CPU, then the first collectives (parameter broadcast, every gradient bucket)
+    run; rank 0 prints one JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, VT_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--plan-only", "--model",
+                          "darknet_yolov5n", "--batch", "2", "--image-size", "64", "--bucket-mb", "1"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["allreduce_ok"] and rec["params_equal"] and rec["buckets"] >= 2

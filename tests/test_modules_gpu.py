@@ -118,8 +118,8 @@ def test_block_vs_reference(tag, dtype, golden_dir):
     _run_case(f(), tag, g, shape, dtype)
 
 
-MODELS = ["darknet19", "cspdarknet53", "darknet53", "darknet_yolov5n", "vovnet39", "vovnet19_slim_ese",
-          "vovnet27_slim"]
+MODELS = ["darknet19", "cspdarknet53", "darknet53", "darknet_yolov5n", "darknet_yolov5x", "vovnet39",
+          "vovnet19_slim_ese", "vovnet27_slim"]
 
 
 def _classifier(name, dtype):

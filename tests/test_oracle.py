@@ -46,8 +46,8 @@ def _clf_sd(name, num_classes):
     return sd
 
 
-MODELS = ["darknet19", "cspdarknet53", "darknet53", "darknet_yolov5n", "vovnet39", "vovnet19_slim_ese",
-          "vovnet27_slim"]
+MODELS = ["darknet19", "cspdarknet53", "darknet53", "darknet_yolov5n", "darknet_yolov5x", "vovnet39",
+          "vovnet19_slim_ese", "vovnet27_slim"]
 
 
 @pytest.fixture(scope="module")
@@ -148,3 +148,18 @@ def test_sgd_restatement_matches_torch_optim():
         R.sgd_step(p, grads, mom, 0.05, 0.9, lambda k: R.weight_decay_group(k, 2e-5, 0.0, 0.0))
     for k in p:
         torch.testing.assert_close(p[k], q[k].data, rtol=1e-6, atol=1e-7)
+
+
+def test_oracle_config5_yolov5x_640(gm):
+    """BASELINE.json configs[4]: Darknet-YOLOv5x get_feature_maps() @640px (two images; eval mode)."""
+    sd = {k: filler.fill_tensor("darknet_yolov5x.cfg5." + k, v) for k, v in R.empty_state_dict("darknet_yolov5x").items()}
+    x = filler.images(2, 640, seed=640)
+    with torch.no_grad():
+        maps = R.feature_maps("darknet_yolov5x", sd, x, False)
+    assert [tuple(m.shape) for m in maps] == [tuple(gm[f"darknet_yolov5x.cfg5.map{i}.shape"]) for i in range(5)]
+    for i, m in enumerate(maps):
+        for b in range(2):
+            flat = m[b].reshape(-1)
+            idx = torch.linspace(0, flat.numel() - 1, 512).long()
+            ref = gm[f"darknet_yolov5x.cfg5.map{i}.img{b}.samples"]
+            np.testing.assert_allclose(flat[idx].numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())

@@ -16,6 +16,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // ---- host side error plumbing ----------------------------------------------
 void vt_set_error(const char* fmt, ...);
 void vt_count_launch();
+void vt_note_kernel(const char* fmt, ...);                            // name of the conv kernel a dispatch chose
+int vt_raise_dynamic_lds(const void* kern, int bytes, const char* who);  // per (kernel, device), thread-safe
 
 #define VT_REQUIRE(cond, code, ...)   \
     do {                              \

@@ -426,16 +426,10 @@ int launch(IgemmArgs& a, hipStream_t st) {
     auto kern = (a.Cin % BKe == 0) ? igemm_kernel<T, BM, BN, WM, WN, PD, true>
                                    : igemm_kernel<T, BM, BN, WM, WN, PD, false>;
     if (smem > 64 * 1024) {
-        static bool raised = false;  // per instantiation
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            if (e != hipSuccess) {
-                vt_set_error("vt_conv_igemm: cannot raise dynamic LDS to %d: %s", smem, hipGetErrorString(e));
-                return VT_ERR_HIP;
-            }
-            raised = true;
-        }
+        const int rc = vt_raise_dynamic_lds((const void*)kern, smem, "vt_conv_igemm");
+        if (rc != VT_OK) return rc;
     }
+    vt_note_kernel("igemm_kernel<%s,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", BM, BN, WM, WN, PD);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, st, a);
     VT_CHECK_LAUNCH("vt_conv_igemm");
     return VT_OK;

@@ -581,17 +581,11 @@ int launch_span_pd(IgemmArgs& a, int dmin, int span, hipStream_t st) {
     const int smem = L::bytes(ita, nchunks > 1 ? 2 : 1, NW);
     const long blocks = (long)8 * a.chunk * a.tiles_n;
     auto kern = span_kernel<T, BM, BN, WM, WN, PD, PP>;
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024);
-        if (e != hipSuccess) {
-            vt_set_error("vt_conv_igemm(span): cannot raise dynamic LDS to %d: %s", 160 * 1024,
-                         hipGetErrorString(e));
-            return VT_ERR_HIP;
-        }
-        raised = true;
+    {
+        const int rc = vt_raise_dynamic_lds((const void*)kern, 160 * 1024, "vt_conv_igemm(span)");
+        if (rc != VT_OK) return rc;
     }
+    vt_note_kernel("span_kernel<%s,%d,%d,%d,%d,%d%s>", sizeof(T) == 2 ? "bf16" : "f32", BM, BN, WM, WN, PD, PP ? ",pingpong" : "");
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NW), smem, st, a, dmin, ita);
     VT_CHECK_LAUNCH("vt_conv_igemm(span)");
 #ifdef VT_SPAN_STAMPS

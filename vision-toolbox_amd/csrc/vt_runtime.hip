@@ -9,6 +9,9 @@
 #include <stdarg.h>
 
 #include <atomic>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "vt_common.h"
@@ -23,6 +26,33 @@ void vt_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 void vt_count_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
+
+static thread_local char g_kernel[128] = "";
+void vt_note_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+
+// Function attributes are per device and per kernel: remember what has been raised for each
+// (kernel, device) pair; safe from any thread.
+int vt_raise_dynamic_lds(const void* kern, int bytes, const char* who) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, int> raised;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    int& have = raised[std::make_pair(kern, dev)];
+    if (have >= bytes) return VT_OK;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        vt_set_error("%s: cannot raise dynamic LDS to %d: %s", who, bytes, hipGetErrorString(e));
+        return VT_ERR_HIP;
+    }
+    have = bytes;
+    return VT_OK;
+}
 
 namespace {
 
@@ -138,6 +168,7 @@ extern "C" {
 
 int vt_version(void) { return 100; }
 const char* vt_last_error(void) { return g_err; }
+const char* vt_last_kernel_name(void) { return g_kernel; }
 uint64_t vt_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
 
 int vt_memset(void* ptr, int value, uint64_t bytes, void* stream) {

@@ -212,6 +212,7 @@ int launch_stem(const IgemmArgs& a, hipStream_t st) {
     const int smem = StemLds<BN>::bytes(span_instr);
     if (smem > 64 * 1024) return -1;
     const long blocks = ((long)a.M + kBM - 1) / kBM;
+    vt_note_kernel("stem_kernel<%d>", BN);
     hipLaunchKernelGGL(stem_kernel<BN>, dim3((unsigned)blocks), dim3(256), smem, st, a, span_instr);
     VT_CHECK_LAUNCH("vt_conv_igemm(stem)");
     return VT_OK;

@@ -390,17 +390,10 @@ extern "C" int vt_conv_wgrad(const vt_conv_desc* d, const void* x, const void* d
         if (GG > 1 && smem < kTapHdr + 65536) smem = kTapHdr + 65536; /* the f32 reduction image */   \
         auto kern = unit ? wgrad_kernel<TT, GG, PDD, true> : wgrad_kernel<TT, GG, PDD, false>;         \
         if (smem > 64 * 1024) {                                                                        \
-            static bool raised_k[2] = {false, false};                                                  \
-            bool& raised = raised_k[unit ? 1 : 0];                                                     \
-            if (!raised) {                                                                             \
-                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
-                if (e != hipSuccess) {                                                                 \
-                    vt_set_error("vt_conv_wgrad: cannot raise dynamic LDS to %d: %s", smem, hipGetErrorString(e)); \
-                    return VT_ERR_HIP;                                                                 \
-                }                                                                                      \
-                raised = true;                                                                         \
-            }                                                                                          \
+            const int rc_ = vt_raise_dynamic_lds((const void*)kern, smem, "vt_conv_wgrad");            \
+            if (rc_ != VT_OK) return rc_;                                                              \
         }                                                                                              \
+        vt_note_kernel("wgrad_kernel<%s,%d,%d,%s>", sizeof(TT) == 2 ? "bf16" : "f32", GG, PDD, unit ? "unit" : "gather"); \
         hipLaunchKernelGGL(kern, grid, dim3(256 * GG), smem, st, a);                                   \
     } while (0)
     if (d->dtype == VT_BF16) {

@@ -277,15 +277,11 @@ int launch_ws(const WsArgs& a, long split, hipStream_t st) {
     const int image = 2 * 32 * FI * (32 * FJ + 4) * 4;
     const int smem = rings > image ? rings : image;
     auto kern = wgrad_span_kernel<FI, FJ, PD>;
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (e != hipSuccess) {
-            vt_set_error("vt_conv_wgrad(span): cannot raise dynamic LDS: %s", hipGetErrorString(e));
-            return VT_ERR_HIP;
-        }
-        raised = true;
+    {
+        const int rc = vt_raise_dynamic_lds((const void*)kern, 96 * 1024, "vt_conv_wgrad(span)");
+        if (rc != VT_OK) return rc;
     }
+    vt_note_kernel("wgrad_span_kernel<%d,%d,%d>", FI, FJ, PD);
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_n * a.tiles_c), (unsigned)split), dim3(512), smem, st, a);
     VT_CHECK_LAUNCH("vt_conv_wgrad(span)");
     return VT_OK;

@@ -4,7 +4,7 @@ Import name and module layout mirror the reference package (vision_toolbox/__ini
 so `from vision_toolbox import backbones` keeps working; the arithmetic runs in
 libvt_amd.so (hand-written HIP for gfx950) and only on the GPU.
 """
-from . import backbones, components, necks
+from . import backbones, checkpoint, components, necks
 from .components import ConvNormAct
 from .necks import FPN, PAN
 

@@ -124,6 +124,7 @@ _vp, _i32, _i64, _u64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
 SYMBOLS = {
     "vt_version": (_i32, []),
     "vt_last_error": (C.c_char_p, []),
+    "vt_last_kernel_name": (C.c_char_p, []),
     "vt_launch_count": (_u64, []),
     "vt_memset": (_i32, [_vp, _i32, _u64, _vp]),
     "vt_conv_igemm": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -192,6 +193,10 @@ def lib() -> C.CDLL:
 
 def last_error() -> str:
     return lib().vt_last_error().decode(errors="replace")
+
+
+def last_kernel_name() -> str:
+    return lib().vt_last_kernel_name().decode(errors="replace")
 
 
 def check(rc: int) -> None:
