@@ -149,21 +149,23 @@ class _StoreBf16(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, round_grad):
         ctx.round_grad = round_grad
-        return t.to(torch.bfloat16).float()
+        return t.to(torch.bfloat16).to(t.dtype)
 
     @staticmethod
     def backward(ctx, g):
-        return (g.to(torch.bfloat16).float() if ctx.round_grad else g), None
+        return (g.to(torch.bfloat16).to(g.dtype) if ctx.round_grad else g), None
 
 
 def _unit_reference(x, conv_w, gamma, beta, gy, s, pad, bf16_storage):
     st = (lambda t, rg: _StoreBf16.apply(t, rg)) if bf16_storage else (lambda t, rg: t)
-    xr = x.detach().clone().requires_grad_(True)
-    w = conv_w.detach().clone().requires_grad_(True)
-    g, b = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+    # float64 arithmetic: at 0.2 - 12.8 M rows per channel the f32 reductions of a CPU reference would
+    # themselves be a visible part of the 2e-4 budget
+    xr = x.detach().double().requires_grad_(True)
+    w = conv_w.detach().double().requires_grad_(True)
+    g, b = gamma.detach().double().requires_grad_(True), beta.detach().double().requires_grad_(True)
     z = st(F.conv2d(st(xr, True), w, None, s, pad), True)  # dx and dz are stored in bf16, and so is z
     y = st(torch.relu(F.batch_norm(z, None, None, g, b, True, 0.1, 1e-5)), False)
-    y.backward(gy)
+    y.backward(gy.double())
     return y.detach(), xr.grad, w.grad, g.grad, b.grad, z.detach()
 
 
@@ -204,46 +206,42 @@ def test_conv_norm_act_unit_forward_backward_at_batch_256(unit, dtype):
 
     bf = dtype == torch.bfloat16
     errs = {"y": (rel(y.detach().float(), ry), 4e-3 if bf else 2e-4),
-            "dw": (rel(m.conv.weight.grad, rdw), 2e-3 if bf else 2e-4),
+            "dw": (rel(m.conv.weight.grad, rdw), 4e-3 if bf else 2e-3),  # f32: a handful of the 25.7 M
+            # pre-activations sit within f32 rounding of 0; each one on the other side of the ReLU costs 2.8e-4
             "dgamma": (rel(m.norm.weight.grad, rdg), 2e-3 if bf else 2e-4),
             "dbeta": (rel(m.norm.bias.grad, rdb), 2e-3 if bf else 2e-4)}
     if Cin != 3:
-        errs["dx"] = (rel(xg.grad, rdx), 4e-3 if bf else 2e-4)
-    assert all(v < t for v, t in errs.values()), errs
+        errs["dx"] = (rel(xg.grad, rdx), 4e-3 if bf else 2e-3)
+    assert all(v < t for v, t in errs.values()), sorted(errs.items())
     # running statistics: momentum 0.1 update with the UNBIASED batch variance (components.py:36)
     mean, var = rz.mean((0, 2, 3)), rz.var((0, 2, 3), unbiased=True)
-    np.testing.assert_allclose(m.norm.running_mean.cpu(), 0.1 * mean, rtol=5e-3, atol=2e-4)
-    np.testing.assert_allclose(m.norm.running_var.cpu(), 0.9 + 0.1 * var, rtol=5e-3)
+    np.testing.assert_allclose(m.norm.running_mean.cpu(), 0.1 * mean.float(), rtol=5e-3, atol=2e-4)
+    np.testing.assert_allclose(m.norm.running_var.cpu(), 0.9 + 0.1 * var.float(), rtol=5e-3)
 
 
 # ---- whole model at batch 256: the tiled-batch property ---------------------------------------------
 # A batch made of T copies of the same n images has the same BatchNorm batch statistics, the same mean
-# loss and the same mean gradient as the n images alone (sums scale by T, counts too).  So the bench's
-# EXACT program (TrainStep at 256 images: every kernel at its full-size tile shapes and row counts) can be
-# checked against an oracle step the CPU can afford (n = 16).
-@pytest.mark.parametrize("name,dtype,n", [("cspdarknet53", torch.bfloat16, 16), ("cspdarknet53", torch.float32, 16),
-                                          ("vovnet39", torch.bfloat16, 16)],
-                         ids=["cspdarknet53-bf16", "cspdarknet53-f32", "vovnet39-bf16"])
-def test_full_batch_train_step_equals_oracle_on_the_tiled_slice(name, dtype, n):
-    from oracle import filler
-    from oracle import torch_ref as R
-    from vision_toolbox import backbones
-    from vision_toolbox.trainer import TrainStep
-
-    ncls = 1000
-    torch.manual_seed(0)
-    ts = TrainStep(getattr(backbones, name)(), ncls, B, 224, dtype, lr=0.0, momentum=0.0, weight_decay=0.0,
-                   label_smoothing=0.1, device="cuda", use_graphs=False)
-    sd0 = {k: v.detach().cpu().clone() for k, v in ts.model.state_dict().items()}
-    x, y = filler.images(n, 224, seed=11), filler.labels(n, ncls, seed=12)
-    reps = B // n
+# loss and the same mean gradient as the n images alone (sums scale by T, and so do the counts; checked on
+# the CPU oracle: 1e-7).  So the bench's EXACT program -- TrainStep at 256 images, every kernel at its
+# full-size tile shapes, grids and row counts -- can be compared with the same TrainStep compiled for the n
+# images alone (small-shape kernels, pinned against the reference by the other GPU tests) and with the
+# oracle on the n images.
+#
+# What can be asserted depends on conditioning, measured here: with train-mode BatchNorm the gradients of
+# these 50-70 unit nets at random init amplify rounding noise ~1e5 x (the f32 CPU oracle is 1.7e-2 away from
+# its own float64 run; two f32 GPU programs that differ only in the ORDER of their reductions are 3.6e-2
+# apart; bf16 storage leaves no digits below the head).  So:
+#   * train-mode BN: loss and head gradients (forward + first backward op) -- tight; gradient scale -- loose;
+#   * frozen BN (running statistics, constants in backward; `freeze_bn`): every sample is independent, the
+#     chain is well conditioned -- EVERY gradient, full-size program vs small program vs float64 oracle.
+def _train_step_grads(ts, x, y):
+    reps = ts.B // x.shape[0]
     ts.images.copy_(x.repeat(reps, 1, 1, 1))
     ts.labels.copy_(y.repeat(reps))
     before = N.launch_count()
     ts.step()  # lr = 0: parameters stay, the flat gradient buffer holds this step's gradients
     torch.cuda.synchronize()
     assert N.launch_count() > before
-    loss = ts.loss()
     grads = {}
     for k, p in ts.model.named_parameters():
         _, off, cnt = ts.store.where(p)
@@ -251,31 +249,66 @@ def test_full_batch_train_step_equals_oracle_on_the_tiled_slice(name, dtype, n):
         if p.dim() == 4:
             o, i, kh, kw = p.shape
             g = g.view(o, kh, kw, i).permute(0, 3, 1, 2)
-        grads[k] = g.reshape(p.shape).float().cpu()
+        grads[k] = g.reshape(p.shape).double().cpu()
+    return ts.loss(), grads
 
-    sd = {k: v.clone() for k, v in sd0.items()}
+
+def _rel_by_key(a, b):
+    return {k: ((a[k] - b[k]).norm() / b[k].norm().clamp_min(1e-12)).item() for k in b}
+
+
+@pytest.mark.parametrize("freeze_bn", [False, True], ids=["trainbn", "frozenbn"])
+@pytest.mark.parametrize("name,dtype", [("cspdarknet53", torch.bfloat16), ("cspdarknet53", torch.float32),
+                                        ("vovnet39", torch.bfloat16)],
+                         ids=["cspdarknet53-bf16", "cspdarknet53-f32", "vovnet39-bf16"])
+def test_full_batch_train_step_equals_small_batch_step_and_oracle(name, dtype, freeze_bn):
+    from oracle import filler
+    from oracle import torch_ref as R
+    from vision_toolbox import backbones
+    from vision_toolbox.trainer import TrainStep
+
+    ncls, n = 1000, 16
+    kw = dict(lr=0.0, momentum=0.0, weight_decay=0.0, label_smoothing=0.1, device="cuda", use_graphs=False,
+              freeze_bn=freeze_bn)
+    torch.manual_seed(0)
+    small = TrainStep(getattr(backbones, name)(), ncls, n, 224, dtype, **kw)
+    sd0 = {k: v.detach().cpu().clone() for k, v in small.model.state_dict().items()}
+    x, y = filler.images(n, 224, seed=11), filler.labels(n, ncls, seed=12)
+    loss_s, g_s = _train_step_grads(small, x, y)
+    del small
+    torch.cuda.empty_cache()
+    full = TrainStep(getattr(backbones, name)(), ncls, B, 224, dtype, **kw)
+    full.model.load_state_dict(sd0)
+    full.weights_changed()
+    loss_f, g_f = _train_step_grads(full, x, y)
+    bf = dtype == torch.bfloat16
+
+    sd = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
     params = {k: v.requires_grad_(True) for k, v in sd.items()
               if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))}
-    ref_loss, _ = R.classifier_loss(name, sd, x, y, 0.1, training=True)
+    ref_loss, _ = R.classifier_loss(name, sd, x.double(), y, 0.1, training=not freeze_bn)
     ref_loss.backward()
-    bf = dtype == torch.bfloat16
-    assert loss == pytest.approx(ref_loss.item(), rel=2e-2 if bf else 2e-4)
-    keys = list(params)
-    rel = {}
-    for k in keys:
-        ref = params[k].grad
-        rel[k] = ((grads[k].double() - ref.double()).norm() / ref.double().norm().clamp_min(1e-12)).item()
-    head = [k for k in keys if k.startswith("3.")]
-    tail = [k for k in keys if k.startswith("0.stages.4.") or k.startswith("0.stages.3.")]
-    stem = [k for k in keys if k.startswith("0.stem")]
-    worst = lambda ks: max(rel[k] for k in ks)
-    med = float(np.median([rel[k] for k in keys]))
-    # bf16: z / y / dy / dz are stored in bf16 through ~60 units; f32: summation order only
-    if bf:
-        assert worst(head) < 2e-2 and worst(tail) < 8e-2 and med < 8e-2, (worst(head), worst(tail), med)
-    else:
-        assert worst(head) < 1e-3 and worst(tail) < 5e-3 and med < 5e-3 and worst(stem) < 5e-2, \
-            (worst(head), worst(tail), med, worst(stem))
+    g_ref = {k: v.grad for k, v in params.items()}
+    head = [k for k in g_ref if k.startswith("3.")]
+
+    assert loss_f == pytest.approx(loss_s, rel=2e-3 if bf else 1e-5)
+    assert loss_f == pytest.approx(ref_loss.item(), rel=2e-2 if bf else 1e-4)
+    fs, fr = _rel_by_key(g_f, g_s), _rel_by_key(g_f, g_ref)
+    # (two bf16 programs whose f32 reductions run in a different order do not round identically for long: a
+    #  1e-6 difference in a BatchNorm mean moves 1 in 4000 stored values by one bf16 step, and from there the
+    #  two runs decorrelate down to the bf16 noise floor, like either of them against the oracle)
+    assert max(fs[k] for k in head) < (0.25 if bf else 1e-4), [fs[k] for k in head]
+    assert max(fr[k] for k in head) < (0.25 if bf else 1e-3), [fr[k] for k in head]
+    ratio = np.array([g_f[k].norm().item() / max(g_ref[k].norm().item(), 1e-30) for k in g_ref])
+    assert 0.5 < np.median(ratio) < 2.0, float(np.median(ratio))
+    if freeze_bn:
+        a, b = np.array(list(fs.values())), np.array(list(fr.values()))
+        # full-size program vs small program: same values, same roundings; only the order of the f32 sums
+        # differs (and, rarely, the side of a ReLU a pre-activation within rounding of 0 falls on)
+        assert np.median(a) < (4e-2 if bf else 1e-4) and a.max() < (0.2 if bf else 5e-2), \
+            (float(np.median(a)), float(a.max()), max(fs, key=fs.get))
+        assert np.median(b) < (8e-2 if bf else 1e-3) and b.max() < (0.5 if bf else 5e-2), \
+            (float(np.median(b)), float(b.max()), max(fr, key=fr.get))
 
 
 # ---- BASELINE configs[4]: Darknet-YOLOv5x get_feature_maps(), batch 64 @640 ----------------------------

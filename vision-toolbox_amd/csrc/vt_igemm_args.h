@@ -22,5 +22,9 @@ struct IgemmArgs {
 // apply to `a` (the caller then launches the general kernel), else a VT_* status.
 int vt_span_dispatch(IgemmArgs& a, int dtype, void* stream);
 
+// vt_igemm_span3.hip: persistent, software-pipelined span kernel for the MFMA-bound 3x3 stride-1 layers (bf16);
+// -1 when it does not apply.
+int vt_span3_dispatch(IgemmArgs& a, int dtype, void* stream);
+
 // vt_stem.hip: 3x3 stride-1 convolution over 8-channel (padded RGB) pixels; -1 when it does not apply.
 int vt_stem_dispatch(IgemmArgs& a, int dtype, void* stream);

@@ -126,6 +126,7 @@ class TrainStep:
         plan_only: bool = False,
         sync_bn: bool = False,
         mix: bool = False,
+        freeze_bn: bool = False,
     ):
         N.lib()
         self.device = torch.device(device if device is not None else "cuda")
@@ -141,6 +142,12 @@ class TrainStep:
         head = nn.Linear(backbone.get_last_out_channels(), num_classes)
         self.model = nn.Sequential(backbone, nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten(), head)
         self.model.train()
+        if freeze_bn:
+            # fine-tuning with frozen BatchNorm: every unit normalises with its running statistics (constants
+            # in backward) and leaves them untouched, like `bn.eval()` inside a training model
+            for m in self.model.modules():
+                if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                    m.eval()
 
         groups = param_groups(self.model)
         self.store = st = E.ParamStore(self.model, order_key=lambda p: groups[id(p)])
