@@ -471,7 +471,7 @@ int launch3(S3Args& a, int wgs_per_cu, hipStream_t st) {
 
 // returns -1 when this kernel does not apply (the caller then tries vt_span_dispatch)
 int vt_span3_dispatch(IgemmArgs& a0, int dtype, void* stream) {
-    static const int enabled = getenv("VT_SPAN3") ? atoi(getenv("VT_SPAN3")) : 0;
+    const int enabled = getenv("VT_SPAN3") ? atoi(getenv("VT_SPAN3")) : 0;  // TODO static once settled
     if (!enabled || dtype != VT_BF16) return -1;
     if (a0.sh != 1 || a0.sw != 1 || a0.Ho != a0.Hi || a0.Wo != a0.Wi) return -1;
     if (a0.Cin % 32 != 0 || a0.ntaps != 9 || a0.Cout < 64) return -1;
@@ -485,7 +485,7 @@ int vt_span3_dispatch(IgemmArgs& a0, int dtype, void* stream) {
         dmax = d > dmax ? d : dmax;
     }
     // MFMA-bound layers only: enough rows to give every CU at least 4 units
-    static const int wm_env = getenv("VT_SPAN3_WM") ? atoi(getenv("VT_SPAN3_WM")) : 4;
+    const int wm_env = getenv("VT_SPAN3_WM") ? atoi(getenv("VT_SPAN3_WM")) : 4;
     static const int fast_dma = getenv("VT_SPAN_FAST_DMA") ? atoi(getenv("VT_SPAN_FAST_DMA")) : 1;
     S3Args a;
     a.p = a0;
