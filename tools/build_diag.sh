@@ -19,4 +19,13 @@ for k in ${ABLS:-1 2 3 4 5 6}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libvt_abl$k.so" $OTHERS "$OUT/span_abl$k.o"
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libvt_stamps.so" $OTHERS "$OUT/span_stamps.o"
+# span3 ablations
+OTHERS3=$(ls "$CS"/*.o | grep -v vt_igemm_span3.o)
+for k in ${ABLS3:-1 2 3 4 8 15}; do
+  /opt/rocm/bin/hipcc $FLAGS -DVT_SPAN3_ABLATE=$k -c "$CS/vt_igemm_span3.hip" -o "$OUT/span3_abl$k.o" &
+done
+wait
+for k in ${ABLS3:-1 2 3 4 8 15}; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libvt_s3abl$k.so" $OTHERS3 "$OUT/span3_abl$k.o"
+done
 ls -la "$OUT"/*.so

@@ -28,6 +28,12 @@
 #include "vt_common.h"
 #include "vt_igemm_args.h"
 
+// diagnostic builds only (tools/build_diag.sh): -DVT_SPAN3_ABLATE=<bits>  1: no MFMA, 2: no LDS-DMA inside the
+// step loop, 4: no fragment reads, 8: no epilogue stores.  Results are wrong by construction; only time is read.
+#ifndef VT_SPAN3_ABLATE
+#define VT_SPAN3_ABLATE 0
+#endif
+
 namespace {
 
 constexpr int kFMX = 7;    // row fragments (16 rows) per wave, at most
@@ -115,6 +121,15 @@ struct L3 {
 template <int T>
 using I_ = std::integral_constant<int, T>;
 
+// Kernel arguments read where they are used (prologue, row tables, epilogue) instead of living in scalar
+// registers across the step loop: an opaque copy of the kernarg pointer makes every such read a fresh s_load.
+typedef const __attribute__((address_space(4))) S3Args* ArgsPtr;
+__device__ __forceinline__ ArgsPtr fresh_args() {
+    ArgsPtr q = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(q));
+    return q;
+}
+
 template <int WM>
 __global__ void __launch_bounds__(128 * WM, 2) span3_kernel(const S3Args a) {
     constexpr int NW = 2 * WM, NT = 64 * NW;
@@ -124,7 +139,6 @@ __global__ void __launch_bounds__(128 * WM, 2) span3_kernel(const S3Args a) {
     const IgemmArgs& p = a.p;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* sTap = (int*)(smem + L::kTap);
     unsigned* sMask = (unsigned*)(smem + L::kMask);
     int* sPo = (int*)(smem + L::kPo);
     const char* sBb = smem + L::kB;
@@ -163,7 +177,6 @@ __global__ void __launch_bounds__(128 * WM, 2) span3_kernel(const S3Args a) {
     const unsigned b_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)(smem + L::kB);
     const unsigned m0_keep = get_m0();
 
-    if (tid < 9) sTap[tid] = (p.h0 + p.dh[tid]) * W + (p.w0 + p.dw[tid]) - a.dmin;  // span row offset of each tap
     if (tid < 4) ((unsigned*)(smem + L::kZero))[tid] = 0u;
 
     // ---- DMA geometry -------------------------------------------------------------------------
@@ -212,19 +225,21 @@ __global__ void __launch_bounds__(128 * WM, 2) span3_kernel(const S3Args a) {
     // per output row of a tile (into table half par_): which taps stay inside the image, where the row goes
 #define VT_ROW_TABLES(par_, m0_, rows_)                                                          \
     do {                                                                                         \
+        ArgsPtr Q = fresh_args();                                                                \
+        const int W_ = Q->p.Wi, H_ = Q->p.Hi, HW_ = H_ * W_, M_ = Q->p.M;                         \
         for (int r = tid; r < (rows_); r += NT) {                                                \
             const long m = (long)(m0_) + r;                                                      \
             unsigned bits = 0;                                                                   \
             int po = 0;                                                                          \
-            if (m < p.M) {                                                                       \
-                const int b = (int)(m / HW);                                                     \
-                const int rem = (int)(m - (long)b * HW);                                         \
-                const int oi = rem / W, oj = rem - oi * W;                                       \
+            if (m < M_) {                                                                        \
+                const int b = (int)(m / HW_);                                                    \
+                const int rem = (int)(m - (long)b * HW_);                                        \
+                const int oi = rem / W_, oj = rem - oi * W_;                                     \
                 _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                  \
-                    const int eh = p.h0 + p.dh[t], ew = p.w0 + p.dw[t];                          \
-                    if ((unsigned)(oi + eh) < (unsigned)H && (unsigned)(oj + ew) < (unsigned)W) bits |= 1u << t; \
+                    const int eh = Q->p.h0 + Q->p.dh[t], ew = Q->p.w0 + Q->p.dw[t];              \
+                    if ((unsigned)(oi + eh) < (unsigned)H_ && (unsigned)(oj + ew) < (unsigned)W_) bits |= 1u << t; \
                 }                                                                                \
-                po = p.dense_out ? (int)m : (b * p.oH + (oi * p.oHs + p.oh0)) * p.oW + (oj * p.oWs + p.ow0); \
+                po = Q->p.dense_out ? (int)m : (b * Q->p.oH + (oi * Q->p.oHs + Q->p.oh0)) * Q->p.oW + (oj * Q->p.oWs + Q->p.ow0); \
             }                                                                                    \
             sMask[(par_)*L::BMX + r] = bits;                                                     \
             sPo[(par_)*L::BMX + r] = po;                                                         \
@@ -246,12 +261,6 @@ __global__ void __launch_bounds__(128 * WM, 2) span3_kernel(const S3Args a) {
     const int nsteps = nchunks * 9;
     int gleft = ntile * nsteps - 1;  // filter slices after the current step, over all this workgroup's tiles
 
-    const bool affine = p.flags & VT_CONV_AFFINE;
-    const bool relu = p.flags & VT_CONV_RELU;
-    const bool stats = p.flags & VT_CONV_STATS;
-    const bool has_res = (p.flags & VT_CONV_RESIDUAL) != 0;
-    bf16_t* __restrict__ yg = (bf16_t*)p.y;
-    const bf16_t* __restrict__ rg = (const bf16_t*)p.res;
     const int q4 = lane >> 4, c16 = lane & 15;
     // this lane's output channels: ch(h, e8) = tn*128 + wn*64 + h*32 + q4*8 + e8, h = 0,1, e8 = 0..7
     const int ch0 = tn * 128 + wn * 64 + q4 * 8;
@@ -281,89 +290,165 @@ __global__ void __launch_bounds__(128 * WM, 2) span3_kernel(const S3Args a) {
             unsigned fmask[FM];
 #pragma unroll
             for (int i = 0; i < FM; ++i) fmask[i] = sMask[par * L::BMX + wrow + i * 16];
+            // byte offset of this lane's fragment-0 row inside a span slot, per tap
+            unsigned a_off[9];
+            {
+                ArgsPtr Q = fresh_args();
+                const int W_ = Q->p.Wi, h0_ = Q->p.h0, w0_ = Q->p.w0, dmin_ = Q->dmin;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int srow = wrow + (h0_ + Q->p.dh[t]) * W_ + (w0_ + Q->p.dw[t]) - dmin_;
+                    a_off[t] = (unsigned)((srow * 4 + (q4 ^ swz4(srow >> 2))) * 16);
+                }
+            }
+            if (false)
+            for (int t = 0; t < 9; ++t) {
+                const int srow = wrow;
+                a_off[t] = (unsigned)((srow * 4 + (q4 ^ swz4(srow >> 2))) * 16);
+            }
             f32x4 acc[FM][4];
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-            // Steps of this tile: (chunk ic, tap it).  Per-wave DMA issue order inside a step: [span piece],
-            // [filter slice of step s+3].  The span pieces of the NEXT chunk (this tile's, or chunk 0 of the
-            // next tile) go out at taps 0..6, piece index wave + NW*it; a chunk is first read 9 - it >= 3 steps
-            // later, so by then it is always older than the slice being waited for.
-            int ic = 0, it = 0;
-            for (int s = 0; s < nsteps; ++s) {
+            // One step = (chunk ic, tap T).  Per-wave DMA issue order inside a step: [span piece], [filter slice
+            // of step s+3].  The span pieces of the NEXT chunk (this tile's, or chunk 0 of the next tile) go out
+            // at taps 0..np_w-1 (np_w <= 7), piece index wave + NW*T; a chunk is first read 9 - T >= 3 steps
+            // later, so by then it is always older than the filter slice being waited for.
+            for (int ic = 0; ic < nchunks; ++ic) {
+                // (loop-carried wave-uniform state: keep it on the scalar side)
+                gleft = __builtin_amdgcn_readfirstlane(gleft);
+                bcur = __builtin_amdgcn_readfirstlane(bcur);
+                acur = __builtin_amdgcn_readfirstlane(acur);
                 const bool lastc = ic + 1 == nchunks;
                 const bool nextc = !lastc || has_next;
                 const int npc_t = lastc ? npc_nxt : npc_cur;
-                // slice s (issued three steps ago) must have landed; younger: what steps s-2 and s-1 issued
-                {
-                    int allowed = min(2, gleft) * ITB;
-                    if (nextc) {
-                        if (it >= 1 && it - 1 < 7 && wave + NW * (it - 1) < npc_t) ++allowed;
-                        if (it >= 2 && it - 2 < 7 && wave + NW * (it - 2) < npc_t) ++allowed;
+                const int np_w = nextc ? min(7, max(0, (npc_t - wave + NW - 1) / NW)) : 0;  // pieces this wave issues
+                const long prow_t = (lastc ? m0_nxt : m0_cur) + a.dmin;                       // first span row of the target
+                const char* a_src = xg + (prow_t + wave * 16) * ldx2 + (lastc ? 0 : (ic + 1) * 64);
+                const long a_stride = (long)NW * 16 * ldx2;
+                unsigned a_m0 = a_base + (unsigned)((acur ^ 1) * aslot_bytes + wave * 1024);
+                // pieces [pc_lo, pc_hi) lie inside the tensor (all of them, except at the two ends of the tensor)
+                const int pc_lo = prow_t >= 0 ? 0 : (int)((-prow_t + 15) / 16);
+                const int pc_hi = (int)min((long)npc_t, ((long)p.M - prow_t) / 16);
+                const char* wb_cur = wg + (long)ic * 64;
+                const char* wb_nxt = wg + (long)(lastc ? 0 : ic + 1) * 64;
+                const unsigned a_rd = (unsigned)(acur * aslot_bytes);
+
+                auto step = [&](auto Tc) {
+                    constexpr int T = decltype(Tc)::value;
+                    // slice s (issued three steps ago) must have landed; younger: what steps s-2 and s-1 issued
+                    if constexpr ((VT_SPAN3_ABLATE & 2) != 0) {
+                        vm_wait3<0>();
+                    } else if (gleft < 2) {
+                        vm_wait3<0>();  // the last two steps of the workgroup
+                    } else {
+                        constexpr int P1 = T - 1, P2 = T - 2;  // taps of the two previous steps (negative: none)
+                        const int cnt = ((P1 >= 0 && P1 < np_w) ? 1 : 0) + ((P2 >= 0 && P2 < np_w) ? 1 : 0);
+                        if (cnt == 2) vm_wait3<2 * ITB + 2>();
+                        else if (cnt == 1) vm_wait3<2 * ITB + 1>();
+                        else vm_wait3<2 * ITB>();
                     }
-                    vm_wait3_dyn(allowed);
-                }
-                // every wave is past the MFMAs of step s-1, i.e. has the fragments of every earlier step in
-                // registers: the ring slot of step s-1 and (at tap 0) the other span slot may be overwritten
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                if (nextc && it < 7 && wave + NW * it < npc_t) {
-                    const long prow = (lastc ? m0_nxt : m0_cur) + a.dmin;
-                    const int cb = lastc ? 0 : (ic + 1) * 64;
-                    VT_ISSUE_A_PIECE(acur ^ 1, prow, cb, wave + NW * it);
-                }
-                if (gleft >= 3) {
-                    int t3 = it + 3, c3 = ic;
-                    if (t3 >= 9) {
-                        t3 -= 9;
-                        c3 = lastc ? 0 : ic + 1;
+                    // every wave is past the MFMAs of step s-1, i.e. has the fragments of every earlier step in
+                    // registers: the ring slot of step s-1 and (at tap 0) the other span slot may be overwritten
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if constexpr ((VT_SPAN3_ABLATE & 2) == 0 && T < 7) {
+                        if (T < np_w) {
+                            const int pc = wave + NW * T;
+                            set_m0(a_m0);
+                            if (pc >= pc_lo && pc < pc_hi) {
+                                glds_s<0>(a_vo, a_src);
+                            } else {
+                                long pix = prow_t + pc * 16 + (lane >> 2);
+                                pix = pix < 0 ? 0 : (pix >= (long)p.M ? (long)p.M - 1 : pix);
+                                glds_v((unsigned long)xg + (unsigned long)(pix * ldx2 + (lastc ? 0 : (ic + 1) * 64) + cjA * 16));
+                            }
+                            a_src += a_stride;
+                            a_m0 += NW * 1024;
+                        }
                     }
-                    VT_ISSUE_B3((bcur + 3) & 3, c3 * 64, t3);
-                }
-                {
-                    const int srow = wrow + __builtin_amdgcn_readfirstlane(sTap[it]);
-                    const char* A = sAb + acur * aslot_bytes + (srow * 4 + (q4 ^ swz4(srow >> 2))) * 16;
-                    const char* Bt = sBb + bcur * kBSlot + b_lane;
-                    uint4 af[FM], bf[4];
-                    bf[0] = *(const uint4*)(Bt);
-                    bf[1] = *(const uint4*)(Bt + 256);
-                    bf[2] = *(const uint4*)(Bt + 2048);
-                    bf[3] = *(const uint4*)(Bt + 2304);
-#pragma unroll
-                    for (int i = 0; i < FM; ++i) {
-                        // (sZb - i*1024) + i*1024 == the zero block: the constant stays in the offset field
-                        const char* src = ((fmask[i] >> it) & 1u) ? A : sZb - i * 1024;
-                        af[i] = *(const uint4*)(src + i * 1024);
+                    if constexpr ((VT_SPAN3_ABLATE & 2) == 0) {
+                        if (gleft >= 3) {
+                            constexpr int T3 = (T + 3) % 9;
+                            const char* sb = (T < 6 ? wb_cur : wb_nxt) + (long)(T3 * cin2);
+                            set_m0(b_base + (unsigned)((((bcur + 3) & 3) << 13) + wave * ITB * 1024));
+                            glds_s<0>(b_voff[0], sb);
+                            // the immediate moves the LDS AND the global address: take it back out of the base
+                            if constexpr (ITB == 2) glds_s<1024>(b_voff[1], sb - 1024);
+                        }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    {
+                        const char* A = sAb + (a_rd + a_off[T]);
+                        const char* Bt = sBb + ((bcur << 13) + b_lane);
+                        uint4 af[FM], bf[4];
+                        if constexpr ((VT_SPAN3_ABLATE & 4) != 0) {
 #pragma unroll
-                    for (int i = 0; i < FM; ++i)
+                            for (int j = 0; j < 4; ++j) bf[j] = make_uint4(lane + j, T, (unsigned)(unsigned long)Bt, 0x3f803f80u);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf[j]),
-                                                                                __builtin_bit_cast(bf16x8, af[i]),
-                                                                                acc[i][j], 0, 0, 0);
-                }
-                --gleft;
-                bcur = (bcur + 1) & 3;
-                if (++it == 9) {
-                    it = 0;
-                    ++ic;
-                    acur ^= 1;
-                }
+                            for (int i = 0; i < FM; ++i) {
+                                const char* src = ((fmask[i] >> T) & 1u) ? A : sZb - i * 1024;
+                                af[i] = make_uint4(0x3f803f80u, lane * 3 + i, T, (unsigned)(unsigned long)src);
+                            }
+                        } else {
+                            bf[0] = *(const uint4*)(Bt);
+                            bf[1] = *(const uint4*)(Bt + 256);
+                            bf[2] = *(const uint4*)(Bt + 2048);
+                            bf[3] = *(const uint4*)(Bt + 2304);
+#pragma unroll
+                            for (int i = 0; i < FM; ++i) {
+                                // (sZb - i*1024) + i*1024 == the zero block: the constant stays in the offset field
+                                const char* src = ((fmask[i] >> T) & 1u) ? A : sZb - i * 1024;
+                                af[i] = *(const uint4*)(src + i * 1024);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < FM; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                if constexpr ((VT_SPAN3_ABLATE & 1) != 0)
+                                    asm volatile("" ::"v"(af[i].x), "v"(af[i].y), "v"(af[i].z), "v"(af[i].w), "v"(bf[j].x), "v"(bf[j].y), "v"(bf[j].z), "v"(bf[j].w));
+                                else
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                        __builtin_bit_cast(bf16x8, bf[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+                            }
+                    }
+                    --gleft;
+                    bcur = (bcur + 1) & 3;
+                };
+                step(I_<0>{});
+                step(I_<1>{});
+                step(I_<2>{});
+                step(I_<3>{});
+                step(I_<4>{});
+                step(I_<5>{});
+                step(I_<6>{});
+                step(I_<7>{});
+                step(I_<8>{});
+                acur ^= 1;
             }
 
             // ---- epilogue: two 16-byte stores per row fragment, straight from the accumulators ----------
+            ArgsPtr Q = fresh_args();
+            const bool affine = Q->p.flags & VT_CONV_AFFINE, relu = Q->p.flags & VT_CONV_RELU;
+            const bool stats = Q->p.flags & VT_CONV_STATS, has_res = (Q->p.flags & VT_CONV_RESIDUAL) != 0;
+            const int Cout_ = Q->p.Cout, M_ = Q->p.M, ldy_ = Q->p.ldy, ldr_ = Q->p.ldr;
+            const bool dense_ = Q->p.dense_out;
+            bf16_t* __restrict__ yg = (bf16_t*)Q->p.y;
+            const bf16_t* __restrict__ rg = (const bf16_t*)Q->p.res;
+            const float* scale_ = Q->p.scale;
+            const float* shift_ = Q->p.shift;
+            float* stats_ = Q->p.stats;
             float s1[16], s2[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) s1[e] = 0.f, s2[e] = 0.f;
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int tr = wrow + i * 16;  // row inside the tile
-                const bool row_ok = tr < rows_tile && m0_cur + tr < (long)p.M;
-                const long po = p.dense_out ? m0_cur + tr : (long)sPo[par * L::BMX + tr];
+                const bool row_ok = tr < rows_tile && m0_cur + tr < (long)M_;
+                const long po = dense_ ? m0_cur + tr : (long)sPo[par * L::BMX + tr];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int n = ch0 + h * 32;
@@ -372,14 +457,14 @@ __global__ void __launch_bounds__(128 * WM, 2) span3_kernel(const S3Args a) {
                     for (int e = 0; e < 8; ++e) {
                         float t = acc[i][2 * h + (e >> 2)][e & 3];
                         if (affine) {
-                            const int ne = min(n + e, p.Cout - 1);
-                            t = fmaf(t, p.scale ? p.scale[ne] : 1.f, p.shift[ne]);
+                            const int ne = min(n + e, Cout_ - 1);
+                            t = fmaf(t, scale_ ? scale_[ne] : 1.f, shift_[ne]);
                         }
                         if (relu) t = fmaxf(t, 0.f);
                         v[e] = t;
                     }
                     uint4 out = VecIO<bf16_t>::pack(v);
-                    if (row_ok && n < p.Cout) {
+                    if (row_ok && n < Cout_) {
                         if (stats) {
                             float r8[8];
                             VecIO<bf16_t>::unpack(out, r8);
@@ -390,7 +475,7 @@ __global__ void __launch_bounds__(128 * WM, 2) span3_kernel(const S3Args a) {
                             }
                         }
                         if (has_res) {
-                            const uint4 rr = *(const uint4*)(rg + (po * p.ldr + n));
+                            const uint4 rr = *(const uint4*)(rg + (po * ldr_ + n));
                             float fv[8], fr[8];
                             VecIO<bf16_t>::unpack(out, fv);
                             VecIO<bf16_t>::unpack(rr, fr);
@@ -398,7 +483,8 @@ __global__ void __launch_bounds__(128 * WM, 2) span3_kernel(const S3Args a) {
                             for (int e = 0; e < 8; ++e) fv[e] += fr[e];
                             out = VecIO<bf16_t>::pack(fv);
                         }
-                        *(uint4*)(yg + (po * p.ldy + n)) = out;
+                        if constexpr ((VT_SPAN3_ABLATE & 8) == 0) *(uint4*)(yg + (po * ldy_ + n)) = out;
+                        else asm volatile("" ::"v"(out.x), "v"(out.y), "v"(out.z), "v"(out.w));
                     }
                 }
             }
@@ -418,9 +504,9 @@ __global__ void __launch_bounds__(128 * WM, 2) span3_kernel(const S3Args a) {
                     v = c16 == e ? x2 : v;
                 }
                 const int n = ch0 + (c16 >> 3) * 32 + (c16 & 7);
-                if (n < p.Cout) {
-                    atomicAdd(&p.stats[((long)rep * 2 + 0) * p.Cout + n], u);
-                    atomicAdd(&p.stats[((long)rep * 2 + 1) * p.Cout + n], v);
+                if (n < Cout_) {
+                    atomicAdd(&stats_[((long)rep * 2 + 0) * Cout_ + n], u);
+                    atomicAdd(&stats_[((long)rep * 2 + 1) * Cout_ + n], v);
                 }
             }
         };
