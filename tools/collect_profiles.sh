@@ -1,50 +1,91 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence bench.py's numbers rest on (run on the GPU box via gpurun):
-#   1. kernel-trace + stats of the exact bench command           -> gpurun_out/prof_bench/
-#   2. PMC passes (FETCH_SIZE, WRITE_SIZE in SEPARATE runs, as MI355X_MICROARCH.md prescribes)
-#      of the dominant kernel on its dominant layer                -> gpurun_out/pmc_fetch/, pmc_write/
-#   3. a JSON summary                                              -> gpurun_out/r01_dominant_kernel_pmc.json
+#   tools/collect_profiles.sh <tag>          e.g. r02_a
+#   1. kernel-trace + stats of the exact bench command                 -> gpurun_out/<tag>_prof_bench/
+#   2. PMC passes of the dominant kernel on the three dominant 3x3 shapes, each counter group in
+#      its OWN run with --kernel-trace only (MI355X_MICROARCH.md, rocprofv3 PMC slots):
+#         FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES | GRBM_GUI_ACTIVE
+#   3. JSON summaries                                                  -> gpurun_out/<tag>_*.json
 # Copy what should be judged into profiles/ afterwards.
 set -u
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_bench" -- \
-    python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/prof_bench.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_prof_bench" -- \
+    python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-pmc > "$OUT/${TAG}_prof_bench.log" 2>&1
 echo "bench profile exit $?"
 
-LAYER="128,128,3,1,28"
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- \
-    python3 "$ROOT/tools/bench_conv.py" fwd $LAYER > "$OUT/pmc_fetch.log" 2>&1
-echo "pmc fetch exit $?"
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- \
-    python3 "$ROOT/tools/bench_conv.py" fwd $LAYER > "$OUT/pmc_write.log" 2>&1
-echo "pmc write exit $?"
+LAYERS="128,128,3,1,28 256,256,3,1,14 512,512,3,1,7"
+for grp in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" GRBM_GUI_ACTIVE; do
+    name=$(echo $grp | cut -d' ' -f1)
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/${TAG}_pmc_$name" -- \
+        python3 "$ROOT/tools/bench_conv.py" fwd $LAYERS > "$OUT/${TAG}_pmc_$name.log" 2>&1
+    echo "pmc $name exit $?"
+done
 
-python3 - "$OUT" <<'EOF'
+python3 - "$OUT" "$TAG" <<'EOF'
 import csv, glob, json, sys
-out = sys.argv[1]
-def avg(counter, d):
-    f = glob.glob(f"{out}/{d}/*/*counter_collection.csv")[0]
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-            if "span_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
-    return sum(vals) / max(len(vals), 1), len(vals)
-fetch_kb, n1 = avg("FETCH_SIZE", "pmc_fetch")
-write_kb, n2 = avg("WRITE_SIZE", "pmc_write")
-f = glob.glob(f"{out}/pmc_fetch/*/*kernel_trace.csv")[0]
-durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(f))
-        if "span_kernel" in r["Kernel_Name"]]
-res = {
-    "kernel": "span_kernel<bf16,224,128,2,2>", "layer": "conv3x3 s1 128->128 @28x28 B=256",
-    "launches": n1, "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb,
-    # gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads -> doubled
-    "hbm_read_bytes": fetch_kb * 1024 * 2, "hbm_write_bytes": write_kb * 1024,
-    "traffic_bytes": fetch_kb * 1024 * 2 + write_kb * 1024,
-    "algorithmic_bytes": (200704 * 128 + 128 * 1152 + 200704 * 128) * 2,
-    "avg_duration_us_under_pmc": sum(durs) / max(len(durs), 1),
-}
-json.dump(res, open(f"{out}/r01_dominant_kernel_pmc.json", "w"), indent=1)
-print(json.dumps(res))
+from collections import defaultdict
+out, tag = sys.argv[1], sys.argv[2]
+# the three shapes are launched in this order, 25 launches each (5 warm-up + 20 timed): split by dispatch order
+SHAPES = [("conv3x3 s1 128->128 @28x28 B=256", 200704, 128, 1152), ("conv3x3 s1 256->256 @14x14 B=256", 50176, 256, 2304),
+          ("conv3x3 s1 512->512 @7x7 B=256", 12544, 512, 4608)]
+def conv_rows(path):
+    rows = [r for r in csv.DictReader(open(path)) if "span_kernel" in r["Kernel_Name"] or "igemm_kernel" in r["Kernel_Name"]]
+    return rows
+def per_shape(d, counter=None):
+    """{shape index: [values]} for a counter (or durations in us when counter is None)"""
+    res = defaultdict(list)
+    if counter is None:
+        f = glob.glob(f"{out}/{tag}_pmc_{d}/*/*kernel_trace.csv")[0]
+        rows = conv_rows(f)
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        for i, r in enumerate(rows):
+            res[i // 25].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        names = [rows[k * 25]["Kernel_Name"] for k in range(len(rows) // 25)]
+        return res, names
+    f = glob.glob(f"{out}/{tag}_pmc_{d}/*/*counter_collection.csv")[0]
+    rows = [r for r in conv_rows(f) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    for i, r in enumerate(rows):
+        res[i // 25].append(float(r["Counter_Value"]))
+    return res, None
+avg = lambda v: sum(v) / max(len(v), 1)
+summary = []
+try:
+    fetch, _ = per_shape("FETCH_SIZE", "FETCH_SIZE")
+    write, _ = per_shape("WRITE_SIZE", "WRITE_SIZE")
+    mfma, _ = per_shape("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES")
+    sqbusy, _ = per_shape("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES")
+    wavecyc, _ = per_shape("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES")
+    gui, _ = per_shape("GRBM_GUI_ACTIVE", "GRBM_GUI_ACTIVE")
+    dur, names = per_shape("GRBM_GUI_ACTIVE")
+    dur_m, _ = per_shape("SQ_VALU_MFMA_BUSY_CYCLES")
+    for k, (layer, M, N, K) in enumerate(SHAPES):
+        flop = 2.0 * M * N * K
+        n_mfma = flop / (2 * 16 * 16 * 32)
+        e = {"layer": layer, "kernel": names[k] if names and k < len(names) else "?",
+             "launches": len(dur[k]),
+             "avg_duration_us_GRBM_pass": avg(dur[k][5:]), "avg_duration_us_SQ_pass": avg(dur_m[k][5:]),
+             "flop_per_launch": flop, "mfma_16x16x32_per_launch": n_mfma,
+             "FETCH_SIZE_KB_raw": avg(fetch[k]), "WRITE_SIZE_KB": avg(write[k]),
+             # gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads -> doubled
+             "hbm_traffic_bytes": avg(fetch[k]) * 1024 * 2 + avg(write[k]) * 1024,
+             "algorithmic_bytes": 2.0 * (M * K / 9 + N * K + M * N),
+             "SQ_VALU_MFMA_BUSY_CYCLES": avg(mfma[k]), "SQ_BUSY_CYCLES": avg(sqbusy[k]), "SQ_WAVE_CYCLES": avg(wavecyc[k]),
+             "GRBM_GUI_ACTIVE_sum_over_8_XCDs": avg(gui[k])}
+        # issue-slot cycles the MFMAs of one launch need at 16 cycles each, spread over 1024 SIMDs
+        e["mfma_busy_cycles_per_mfma"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / n_mfma
+        e["kernel_cycles"] = e["GRBM_GUI_ACTIVE_sum_over_8_XCDs"] / 8
+        e["effective_clock_GHz"] = e["kernel_cycles"] / (e["avg_duration_us_GRBM_pass"] * 1e3)
+        e["mfma_pipe_utilisation"] = (n_mfma * 16 / 1024) / e["kernel_cycles"]
+        e["tflops_SQ_pass"] = flop / e["avg_duration_us_SQ_pass"] / 1e6
+        summary.append(e)
+except Exception as ex:  # keep whatever was collected
+    summary.append({"error": repr(ex)})
+json.dump(summary, open(f"{out}/{tag}_dominant_kernel_pmc.json", "w"), indent=1)
+print(json.dumps(summary, indent=1))
 EOF

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Callable, Optional
 
@@ -235,6 +236,8 @@ class Builder:
         # weights, so their (tiny, launch-bound) pack kernels leave the backward critical path
         # and run on the side stream while the forward list executes
         self.hoist_dgrad_packs = False
+        # release each filter gradient to the side stream after (True) or before (False) the unit's data gradient
+        self.wgrad_late = os.environ.get("VT_WGRAD_LATE", "1") != "0"
         self._hoisted: list[N.Op] = []
         # SyncBatchNorm (configs/base.yaml:22): the trainer all-reduces every layer's statistics
         # between the kernel that accumulates them and the finalize kernel; the finalize kernels
@@ -597,9 +600,13 @@ class Builder:
                     dz = dy
                     if conv.bias is not None and conv.bias.requires_grad:
                         self.emit(N.OP_COLSUM, [dz.addr(), self.pgrad(conv.bias)], [dz.ld, Cout, dt], [M])
-                # filter gradient: needs only x and dz and nothing in backward waits for it, so
-                # it goes to the side stream and overlaps the (HBM-bound) chain that follows
-                if w.requires_grad:
+                # filter gradient: needs only x and dz and nothing in backward waits for it, so it goes to the
+                # side stream.  It is released AFTER this unit's data gradient (wgrad_late): both are MFMA-bound
+                # and only slow each other down, whereas the HBM-bound BatchNorm passes of the next unit in
+                # backward order leave the matrix pipes to it.
+                def emit_wgrad():
+                    if not w.requires_grad:
+                        return
                     dfwd = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, dz.ld, ldw, 0)
                     self.emit(N.OP_FORK)
                     if padded:
@@ -611,10 +618,15 @@ class Builder:
                     else:
                         self.emit(N.OP_CONV_WGRAD, [x.addr(), dz.addr(), self.pgrad(w)], desc=dfwd,
                                   extra_ints=[ldw], side=True)
+
+                if not self.wgrad_late:
+                    emit_wgrad()
                 # data gradient
                 if x.needs_grad:
                     self._dgrad(x, dz, wptr if not padded else self.bp(wpack), dt if (padded or dt != N.VT_F32) else N.VT_F32,
                                 ldw, Cout, k, s, pad, Ho, Wo)
+                if self.wgrad_late:
+                    emit_wgrad()
 
             self.nodes.append(bwd)
         return y
