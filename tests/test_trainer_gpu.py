@@ -122,23 +122,27 @@ def test_cspdarknet53_frozen_bn_step_gradients_match_oracle_tightly():
 
 def test_cspdarknet53_train_bn_first_step_gradients_track_oracle():
     """Train-mode BatchNorm, step 1 only (no trajectory): per-parameter gradients against the float64 oracle.
-    53 BatchNorm layers over 72 samples per channel amplify f32 rounding (a few ReLU masks flip in ANY f32
-    implementation, see above), so the bound is on the distribution: median relative error < 5e-3, at most
-    5 % of the 200 parameters above 5e-2, none above 0.3 (a wrong or missing gradient scores >= 1)."""
+    53 BatchNorm layers over 72 samples per channel amplify f32 rounding: the f32 CPU oracle ITSELF sits 2.6 %
+    (median over the 203 parameters, max 3.7 %) from the float64 oracle on this input.  The bound is therefore
+    relative to that measured conditioning: the HIP path may be no further from float64 than 1.5x what the f32
+    CPU oracle is (median and worst parameter), while a wrong or missing gradient scores >= 1."""
     name, ncls, B, S = "cspdarknet53", 16, 8, 96
     x, y = filler.images(B, S), filler.labels(B, ncls)
     ref_loss, ref = _oracle_grads(name, ncls, x, y, "trh.", training=True, double=True)
+    _, cpu32 = _oracle_grads(name, ncls, x, y, "trh.", training=True, double=False)
     ts = TrainStep(backbones.cspdarknet53(), ncls, B, S, torch.float32, lr=0.0, momentum=0.0, weight_decay=0.0,
                    label_smoothing=0.1, device="cuda", use_graphs=False)
     filler.fill_module(ts.model, "trh.")
     ts.weights_changed()
     ts.step(x.cuda(), y.cuda())
-    assert ts.loss() == pytest.approx(ref_loss, rel=2e-3)
+    assert ts.loss() == pytest.approx(ref_loss, rel=1e-5)
     got = _device_grads(ts)
-    errs = sorted(rel_err(got[k], ref[k]) for k in got if k in ref)
-    assert len(errs) == len(ref)
-    assert errs[len(errs) // 2] < 5e-3, errs[len(errs) // 2]
-    assert sum(e > 5e-2 for e in errs) <= len(errs) // 20 and errs[-1] < 0.3, errs[-10:]
+    assert set(got) == set(ref)
+    errs = sorted(rel_err(got[k], ref[k]) for k in ref)
+    base = sorted(rel_err(cpu32[k], ref[k]) for k in ref)
+    mid = len(errs) // 2
+    assert errs[mid] < 1.5 * base[mid] + 1e-3, (errs[mid], base[mid])
+    assert errs[-1] < 1.5 * base[-1] + 1e-3, (errs[-5:], base[-5:])
 
 
 def test_bf16_train_step_decreases_loss_and_matches_f32_roughly():

@@ -67,6 +67,9 @@ def main():
         d, Ho = desc_for(B, Cin, Cout, k, s, H, 0 if os.environ.get("VT_BENCH_NOSTATS") else N.VT_CONV_STATS)
         x = torch.randn(B, H, H, Cin, device="cuda").to(torch.bfloat16)
         w = (torch.randn(Cout, k * k, Cin, device="cuda") * (2.0 / (k * k * Cin)) ** 0.5).to(torch.bfloat16)
+        if os.environ.get("VT_BENCH_ZERO"):  # DVFS probe: the same launches on all-zero operands (guide: give-back item 1)
+            x.zero_()
+            w.zero_()
         y = torch.empty(B, Ho, Ho, Cout, device="cuda", dtype=torch.bfloat16)
         stats = torch.zeros(N.VT_STAT_REPLICAS, 2, Cout, device="cuda")
         dz = torch.randn(B, Ho, Ho, Cout, device="cuda").to(torch.bfloat16)

@@ -47,6 +47,16 @@ def run(d, x, w, y, stats, res=None, iters=0):
     return name, ms
 
 
+# (tag, environment) per variant; the first one is the reference.  VT_CHECK_VARIANTS="tag:K=V,K=V;tag2:K=V" overrides
+VARIANTS = [("old", {"VT_SPAN3": "0", "VT_SPAN_DB": "0"}), ("dbuf", {"VT_SPAN3": "0", "VT_SPAN_DB": "1"})]
+if os.environ.get("VT_CHECK_VARIANTS"):
+    VARIANTS = [(v.split(":")[0], dict(kv.split("=") for kv in v.split(":")[1].split(",") if kv))
+                for v in os.environ["VT_CHECK_VARIANTS"].split(";")]
+
+
+ROUNDS = int(os.environ.get("VT_CHECK_ROUNDS", "7"))
+
+
 def main():
     shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(128, 128, 28), (256, 256, 14), (160, 160, 28),
                                                                             (128, 128, 56), (64, 64, 56), (512, 512, 7)]
@@ -58,30 +68,38 @@ def main():
         w = (torch.randn(Cout, 3, 3, Cin, device="cuda") * (2.0 / (9 * Cin)) ** 0.5).to(torch.bfloat16)
         res = torch.randn(B, H, H, Cout, device="cuda").to(torch.bfloat16)
         flops = 2.0 * B * H * H * Cout * 9 * Cin
+        allkeys = {k for _, env in VARIANTS for k in env}
         for mode, flags in (("stats", N.VT_CONV_STATS), ("residual", N.VT_CONV_RESIDUAL)):
             outs = {}
-            for tag, env in (("old", {"VT_SPAN3": "0"}), ("wm4", {"VT_SPAN3": "1", "VT_SPAN3_WM": "4"}),
-                             ("wm2", {"VT_SPAN3": "1", "VT_SPAN3_WM": "2"})):
+            d = desc(B, Cin, Cout, H, flags, ldr=Cout if flags & N.VT_CONV_RESIDUAL else 0)
+            r_ = res if flags & N.VT_CONV_RESIDUAL else None
+            for tag, env in VARIANTS:
+                os.environ.update({k: "0" for k in allkeys})
                 os.environ.update(env)
                 y = torch.full((B, H, H, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
                 st = torch.zeros(N.VT_STAT_REPLICAS, 2, Cout, device="cuda") if flags & N.VT_CONV_STATS else None
-                d = desc(B, Cin, Cout, H, flags, ldr=Cout if flags & N.VT_CONV_RESIDUAL else 0)
-                name, _ = run(d, x, w, y, st, res if flags & N.VT_CONV_RESIDUAL else None)
-                st_sum = st.double().sum(0).cpu() if st is not None else None
-                _, ms = run(d, x, w, y, torch.zeros_like(st) if st is not None else None,
-                            res if flags & N.VT_CONV_RESIDUAL else None, iters=20 if mode == "stats" else 0)
-                outs[tag] = (y, st_sum, name, ms)
-            y0, s0 = outs["old"][0], outs["old"][1]
+                name, _ = run(d, x, w, y, st, r_)
+                outs[tag] = [y, st.double().sum(0).cpu() if st is not None else None, name, []]
+            if mode == "stats":  # interleaved timing rounds (guide rule 24): median and min per variant
+                st = torch.zeros(N.VT_STAT_REPLICAS, 2, Cout, device="cuda")
+                ysc = torch.empty_like(outs[VARIANTS[0][0]][0])
+                for _ in range(ROUNDS):
+                    for tag, env in VARIANTS:
+                        os.environ.update({k: "0" for k in allkeys})
+                        os.environ.update(env)
+                        outs[tag][3].append(run(d, x, w, ysc, st, r_, iters=10)[1])
+            y0, s0 = outs[VARIANTS[0][0]][0], outs[VARIANTS[0][0]][1]
             line = f"{Cin}->{Cout} @{H} B={B} {mode:8s}"
-            for tag in ("old", "wm4", "wm2"):
-                y, ssum, name, ms = outs[tag]
+            for tag in [v[0] for v in VARIANTS]:
+                y, ssum, name, mss = outs[tag]
                 nan = int(torch.isnan(y.float()).sum())
-                diff = (y.float() - y0.float()).abs().max().item() if nan == 0 else float("nan")
                 neq = int((y != y0).sum())
                 serr = ((ssum - s0).abs().max() / s0.abs().max()).item() if ssum is not None else 0.0
-                line += f" | {tag} [{name}] maxdiff {diff:.3g} neq {neq} nan {nan} stats {serr:.2g}"
-                if ms:
-                    line += f" {ms*1e3:.1f}us {flops/ms/1e9:.0f}TF"
+                line += f" | {tag} [{name.replace('span_kernel', 'sk')}] neq {neq} nan {nan} st {serr:.1g}"
+                if mss:
+                    mss = sorted(mss)
+                    med = mss[len(mss) // 2]
+                    line += f" med {med*1e3:.1f}us {flops/med/1e9:.0f}TF min {mss[0]*1e3:.1f}"
             print(line, flush=True)
 
 

@@ -26,5 +26,9 @@ int vt_span_dispatch(IgemmArgs& a, int dtype, void* stream);
 // -1 when it does not apply.
 int vt_span3_dispatch(IgemmArgs& a, int dtype, void* stream);
 
+// vt_igemm_span5.hip: persistent span kernel with a dedicated LDS-DMA loader wave (bf16, 3x3 stride 1, Cout >= 64);
+// -1 when it does not apply.
+int vt_span5_dispatch(IgemmArgs& a, int dtype, void* stream);
+
 // vt_stem.hip: 3x3 stride-1 convolution over 8-channel (padded RGB) pixels; -1 when it does not apply.
 int vt_stem_dispatch(IgemmArgs& a, int dtype, void* stream);

@@ -146,7 +146,7 @@ struct SpanLds {
 };
 
 // ita: span DMA instructions per wave per chunk (span = 64*ita rows >= BM + dmax - dmin)
-template <typename T, int BM, int BN, int WM, int WN, int PD, bool PP = false>
+template <typename T, int BM, int BN, int WM, int WN, int PD, bool PP = false, bool DB = false>
 __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel(const IgemmArgs p, const int dmin, const int ita) {
     constexpr int NW = WM * WN;  // waves: 4, or 8 for the 256 x 128 tile (wave tile 64 x 64, 16 waves per CU)
     constexpr int NT = 64 * NW;
@@ -224,12 +224,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
 
     // Fast DMA addressing (interior tiles: every span row inside [0, M), every filter row < Cout, all
     // byte offsets < 4 GiB): scalar base + constant per-lane 32-bit offset, no VALU per instruction.
-    const bool a_fast = __all(pix0 >= 0 && pix0 + 16l * NW * (ita - 1) < p.M) && p.fast_dma &&
+    const bool a_fast = __all(pix0 >= 0 && pix0 + 16l * NW * (ita - 1) < p.M) && (p.fast_dma & 1) &&
                         (unsigned long)p.M * p.ldx * sizeof(T) < 0xffff0000ul;
     bool bv_all = true;
 #pragma unroll
     for (int i = 0; i < ITB; ++i) bv_all = bv_all && bvalid[i];
-    const bool b_fast = __all(bv_all) && p.fast_dma;
+    const bool b_fast = __all(bv_all) && (p.fast_dma & 1);
     const char* a_sbase = (const char*)xg + (m0 + dmin) * (long)p.ldx * (long)sizeof(T);  // may precede x: unused then
     const unsigned a_voff0 = (unsigned)((16 * wave + (lane >> 2)) * p.ldx + cj * EPC) * (unsigned)sizeof(T);
     const unsigned a_vstep = (unsigned)(16 * NW * p.ldx) * (unsigned)sizeof(T);
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
     VT_ISSUE_A(0, 0);
     int ic_n = 0, it_n = 0;  // (chunk, tap) of the next filter slice to issue
 #pragma unroll
-    for (int s = 0; s < PD; ++s) {
+    for (int s = 0; s < PD + (DB ? 1 : 0); ++s) {
         if (s < nsteps) {
             VT_ISSUE_B(s, ic_n, it_n);
             if (++it_n == p.ntaps) it_n = 0, ++ic_n;
@@ -302,6 +302,19 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
     __syncthreads();  // tap table, row masks, zero block
 
     VT_STAMP(1);
+    // Static priority split (fast_dma bits 1..2 = mode): two workgroups share a CU, one wave of each per SIMD.  At
+    // equal priority the matrix pipe is shared evenly, which locks the two waves IN phase (both in their MFMA
+    // block together, both in their scalar / DMA / barrier block together) and the phases add up instead of
+    // overlapping.  Raising the wave in the odd hardware slot makes its MFMA block pre-empt the other wave's, so
+    // the pair settles half a step apart (guide: 'static priority for the younger half', no per-segment flips).
+    if (p.fast_dma & 6) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID.WAVE_ID
+        if (hw & 1u) {
+            if ((p.fast_dma & 6) == 2) __builtin_amdgcn_s_setprio(1);
+            else if ((p.fast_dma & 6) == 4) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(3);
+        }
+    }
     unsigned fmask[FM];
 #pragma unroll
     for (int i = 0; i < FM; ++i) fmask[i] = sMask[wm * TM + i * 16 + (lane & 15)];
@@ -376,6 +389,72 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
             if (++it == p.ntaps) it = 0, ++ic;
             bcur = (bcur + 1 == NSB) ? 0 : bcur + 1;
             bnxt = (bnxt + 1 == NSB) ? 0 : bnxt + 1;
+        }
+    } else if constexpr (DB) {
+        // ---- register double buffering: the fragments of step s+1 are read while step s's MFMAs run --------
+        // Invariant at the top of step s: filter slices <= s+2 have been issued, slice s+1 (and with it everything
+        // older, in particular the span of its chunk) must have landed before the barrier, because every wave
+        // reads step s+1's fragments during step s.  Slice s+3 is issued after the barrier into the ring slot of
+        // slice s, whose fragments are in registers (read during step s-1; the lgkmcnt wait before the barrier
+        // retires this wave's reads, the barrier everybody else's).  Ring: PD + 1 = 3 slots.  Requires
+        // ntaps >= 3: a span issued at the first tap of a chunk is older than the slice issued with it, which is
+        // waited for two steps later, before the span's first reader.
+        static_assert(PD == 2, "double-buffered fragments: three ring slots");
+        uint4 af0[FM], bf0[FN], af1[FM], bf1[FN];
+        auto read_frags = [&](uint4 (&af)[FM], uint4 (&bf)[FN], int ic_r, int it_r, int bslot) {
+            const int d = __builtin_amdgcn_readfirstlane(sTap[it_r].x);
+            const int srow0 = wm * TM + (lane & 15) + d;
+            const uint4* A = sA + (ic_r & 1) * aslot + srow0 * 4 + ((lane >> 4) ^ swz(srow0));
+            const uint4* Bt = sB + bslot * BSLOT + wn * TN * 4 + b_lane;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bf[j] = Bt[j * 64];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const uint4* src = ((fmask[i] >> it_r) & 1u) ? A : sZ - i * 64;
+                af[i] = src[i * 64];
+            }
+        };
+        bool a_prev = false;  // a span was issued in the previous step
+        int icr = 0, itr = 0, br = 0;  // (chunk, tap, ring slot) of the step whose fragments are read next
+        read_frags(af0, bf0, 0, 0, 0);
+        if (++itr == p.ntaps) itr = 0, ++icr;
+        br = 1;
+        auto step = [&](int s, uint4 (&caf)[FM], uint4 (&cbf)[FN], uint4 (&naf)[FM], uint4 (&nbf)[FN]) {
+            const bool more = s + 1 < nsteps;
+            if (more) {
+                if (a_prev) vm_wait_dyn((s + 2 < nsteps ? ITB : 0) + ita);
+                else if (s + 2 < nsteps) vm_wait<ITB>();
+                else vm_wait<0>();
+            }
+            lds_fence();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            a_prev = false;
+            if (it == 0 && ic + 1 < nchunks) {
+                VT_ISSUE_A((ic + 1) & 1, ic + 1);
+                a_prev = true;
+            }
+            if (s + 3 < nsteps) {
+                VT_ISSUE_B(bcur, ic_n, it_n);  // slot of slice s == slot of slice s+3
+                if (++it_n == p.ntaps) it_n = 0, ++ic_n;
+            }
+            // (unconditional: the last step re-reads its own, still valid, fragments -- a branch here makes the
+            //  compiler wait for these reads before the MFMAs below)
+            read_frags(naf, nbf, more ? icr : ic, more ? itr : it, more ? br : bcur);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) mma<T>(caf[i], cbf[j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (++it == p.ntaps) it = 0, ++ic;
+            if (++itr == p.ntaps) itr = 0, ++icr;
+            bcur = (bcur + 1 == NSB) ? 0 : bcur + 1;
+            br = (br + 1 == NSB) ? 0 : br + 1;
+        };
+        for (int s = 0; s < nsteps; s += 2) {
+            step(s, af0, bf0, af1, bf1);
+            if (s + 1 < nsteps) step(s + 1, af1, bf1, af0, bf0);
         }
     } else
     for (int s = 0; s < nsteps; ++s) {
@@ -568,7 +647,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
 template <typename L>
 bool smem_ok(int ita, int nw, int nchunks) { return L::bytes(ita, nchunks > 1 ? 2 : 1, nw) <= 160 * 1024; }
 
-template <typename T, int BM, int BN, int WM, int WN, int PD, bool PP = false>
+template <typename T, int BM, int BN, int WM, int WN, int PD, bool PP = false, bool DB = false>
 int launch_span_pd(IgemmArgs& a, int dmin, int span, hipStream_t st) {
     using L = SpanLds<BM, BN, PD>;
     constexpr int NW = WM * WN;
@@ -580,12 +659,13 @@ int launch_span_pd(IgemmArgs& a, int dmin, int span, hipStream_t st) {
     const int nchunks = a.Cin / (64 / (int)sizeof(T));
     const int smem = L::bytes(ita, nchunks > 1 ? 2 : 1, NW);
     const long blocks = (long)8 * a.chunk * a.tiles_n;
-    auto kern = span_kernel<T, BM, BN, WM, WN, PD, PP>;
+    auto kern = span_kernel<T, BM, BN, WM, WN, PD, PP, DB>;
     {
         const int rc = vt_raise_dynamic_lds((const void*)kern, 160 * 1024, "vt_conv_igemm(span)");
         if (rc != VT_OK) return rc;
     }
-    vt_note_kernel("span_kernel<%s,%d,%d,%d,%d,%d%s>", sizeof(T) == 2 ? "bf16" : "f32", BM, BN, WM, WN, PD, PP ? ",pingpong" : "");
+    vt_note_kernel("span_kernel<%s,%d,%d,%d,%d,%d%s>", sizeof(T) == 2 ? "bf16" : "f32", BM, BN, WM, WN, PD,
+                   PP ? ",pingpong" : (DB ? ",dbuf" : ""));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NW), smem, st, a, dmin, ita);
     VT_CHECK_LAUNCH("vt_conv_igemm(span)");
 #ifdef VT_SPAN_STAMPS
@@ -633,6 +713,12 @@ int launch_span(IgemmArgs& a, int dmin, int span, hipStream_t st) {
     const bool fits3 = 2 * SpanLds<BM, BN, 3>::bytes(ita, nchunks > 1 ? 2 : 1, NW) <= 160 * 1024;
     const bool pd3 = pd_env == 3 && fits3 && nchunks * a.ntaps >= 6;
     if (pd3) return launch_span_pd<T, BM, BN, WM, WN, 3>(a, dmin, span, st);
+    if constexpr (sizeof(T) == 2 && BN == 128 && WM == 2 && WN == 2 && (BM == 224 || BM == 256)) {
+        // the MFMA-bound 3x3 layers: fragments of step s+1 are read under the MFMAs of step s
+        const int db_env = getenv("VT_SPAN_DB") ? atoi(getenv("VT_SPAN_DB")) : 0;  // TODO static once settled
+        if (db_env && a.ntaps >= 3 && nchunks * a.ntaps >= 4)
+            return launch_span_pd<T, BM, BN, WM, WN, 2, false, true>(a, dmin, span, st);
+    }
     return launch_span_pd<T, BM, BN, WM, WN, 2>(a, dmin, span, st);
 }
 
@@ -676,7 +762,8 @@ int vt_span_dispatch(IgemmArgs& a, int dtype, void* stream) {
     static const int enabled = getenv("VT_IGEMM_SPAN") ? atoi(getenv("VT_IGEMM_SPAN")) : 1;
     if (!enabled) return -1;
     static const int fast_dma = getenv("VT_SPAN_FAST_DMA") ? atoi(getenv("VT_SPAN_FAST_DMA")) : 1;
-    a.fast_dma = fast_dma;
+    const int prio = getenv("VT_SPAN_PRIO") ? atoi(getenv("VT_SPAN_PRIO")) : 0;  // TODO static once settled
+    a.fast_dma = (fast_dma & 1) | ((prio & 3) << 1);
     const int ch = 4 * vt_epc(dtype);
     if (a.sh != 1 || a.sw != 1 || a.Ho != a.Hi || a.Wo != a.Wi) return -1;
     if (a.Cin % ch != 0 || a.ntaps > 32) return -1;

@@ -237,7 +237,7 @@ class Builder:
         # and run on the side stream while the forward list executes
         self.hoist_dgrad_packs = False
         # release each filter gradient to the side stream after (True) or before (False) the unit's data gradient
-        self.wgrad_late = os.environ.get("VT_WGRAD_LATE", "1") != "0"
+        self.wgrad_late = os.environ.get("VT_WGRAD_LATE", "0") != "0"
         self._hoisted: list[N.Op] = []
         # SyncBatchNorm (configs/base.yaml:22): the trainer all-reduces every layer's statistics
         # between the kernel that accumulates them and the finalize kernel; the finalize kernels
