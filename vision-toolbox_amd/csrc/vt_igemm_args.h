@@ -30,5 +30,9 @@ int vt_span3_dispatch(IgemmArgs& a, int dtype, void* stream);
 // -1 when it does not apply.
 int vt_span5_dispatch(IgemmArgs& a, int dtype, void* stream);
 
+// vt_igemm_span6.hip: persistent span kernel, one 12-wave workgroup per CU (two compute groups half a step apart +
+// four loader waves); -1 when it does not apply.
+int vt_span6_dispatch(IgemmArgs& a, int dtype, void* stream);
+
 // vt_stem.hip: 3x3 stride-1 convolution over 8-channel (padded RGB) pixels; -1 when it does not apply.
 int vt_stem_dispatch(IgemmArgs& a, int dtype, void* stream);

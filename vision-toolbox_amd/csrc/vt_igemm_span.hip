@@ -78,7 +78,7 @@ __device__ __forceinline__ void glds16s(unsigned voff, const void* sbase, unsign
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
+        "s_nop 2\n\t"  // 5 wait states in all before a VMEM instruction may read a VALU-written (e.g. reloaded) SGPR base
         "global_load_lds_dwordx4 %1, %2\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)

@@ -70,7 +70,7 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p) {
 }
 // LDS-DMA, 16 B per lane: LDS address = M0 + lane*16, global address = sbase + voff (or the per-lane address)
 __device__ __forceinline__ void glds_s(unsigned voff, const void* sbase) {
-    asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(uniform_ptr(sbase)) : "memory");
+    asm volatile("s_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(uniform_ptr(sbase)) : "memory");  // 5 wait states: VALU-written SGPR base
 }
 __device__ __forceinline__ void glds_v(unsigned long gsrc) {
     asm volatile("global_load_lds_dwordx4 %0, off" ::"v"(gsrc) : "memory");

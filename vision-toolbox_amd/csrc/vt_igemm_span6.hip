@@ -1,0 +1,753 @@
+// vt_igemm_span6.hip -- persistent input-span convolution (bf16), one 12-wave workgroup per CU: two compute groups
+// that run half a step apart plus four LDS-DMA loader waves.  For the MFMA-bound stride-1 3x3 layers: every
+// ConvNormAct 3x3 stride-1 forward conv of the Darknet / CSPDarknet / VoVNet stages (reference
+// components.py:26-35, darknet.py:23-24, vovnet.py:41-44) and their stride-1 data gradients.
+//
+// Why this shape (measured on 128->128 3x3 @28x28, tools/exp_span.sh and the VT_SPAN5_ABL ablations):
+//   * in vt_igemm_span.hip a step costs the SUM of scalar bookkeeping + barrier (0.23 us), LDS-DMA issue (0.31 us:
+//     the per-CU global->LDS path at its limit, every wave blocked on it) and the MFMAs (0.40 us): the waves of the
+//     two workgroups on a CU fall into phase and nothing overlaps.
+//   * waves that compute must not issue vector memory at all (vt_igemm_span5.hip: 0.51 us per step with ONE
+//     compute wave per SIMD), but a 5-wave workgroup at 168 registers is admitted only once per CU.
+// So: ONE workgroup per CU, three waves per SIMD --
+//   * compute group 0 (waves 0-3) and group 1 (waves 4-7), each 2 x 2 waves over its own (32*FM) x 128 tile stream.
+//     Time is cut into TICKS, one workgroup barrier each.  Group 0 reads the fragments of step s in tick 2s and
+//     issues its MFMAs in tick 2s+1; group 1 does the same one tick later.  On every SIMD one wave feeds the
+//     matrix pipe while the other reads LDS, by construction (cf. the guide's 8-phase GEMM template).
+//   * both groups walk the same (chunk, tap) sequence, so they share ONE filter-slice ring: a slice is DMA'd once
+//     per 2 x (32*FM) rows -- half the global->LDS bytes per FLOP of the two-workgroup kernel.
+//   * loader waves 8-11 issue every LDS-DMA (filter slices, both groups' input spans), three slices and the next
+//     chunks' spans in flight, retired by exact counted vmcnt waits before the even ticks; they also build the
+//     next tiles' row tables.  A loader wave moves ~25 GB/s, hence four.
+//   * PERSISTENT: a workgroup owns a contiguous range of 32-row units of its XCD's share of the flat pixel index,
+//     half for each group, cut into tiles of 4..kFMX units (no partial last round); the loaders run ahead across
+//     tile boundaries, so the next tile's first span and slices land while the accumulators are stored.
+//   * swapped MFMA operands (filter rows = MFMA rows, pixels = MFMA columns): a lane holds 2 x 8 CONSECUTIVE
+//     output channels of one pixel and stores them straight from the accumulators (no LDS staging).
+// LDS images, swizzles and the summation order are those of vt_igemm_span.hip: outputs are bit-identical to it.
+#include <stdlib.h>
+
+#include <algorithm>
+#include <type_traits>
+#include <vector>
+
+#include "vt_common.h"
+#include "vt_igemm_args.h"
+
+#ifndef VT_SPAN6_FMX
+#define VT_SPAN6_FMX 6
+#endif
+
+namespace {
+
+// diagnostics (ablation bits, stamps, timed barriers) exist only in -DVT_SPAN6_DIAG builds (tools/build_diag.sh);
+// the shipped kernel has none of these branches
+#ifdef VT_SPAN6_DIAG
+constexpr bool kDiag = true;
+#else
+constexpr bool kDiag = false;
+#endif
+#define VT_DBG(bit) (kDiag && (a.debug & (bit)))
+
+constexpr int kFMX = VT_SPAN6_FMX;  // row fragments (16 rows) per compute wave, at most
+constexpr int kNSB = 4;             // filter-slice ring slots (3 slices in flight)
+constexpr int kBSlot = 128 * 64;    // bytes per filter slice: 128 filter rows x 32 channels
+constexpr int kBMX = 32 * kFMX;     // rows of the tallest tile of one group
+
+
+// dev diagnostics (VT_SPAN6_ABL bit 16): wall-clock stamps (100 MHz) per workgroup; never read by the kernel itself
+__device__ unsigned long long vt_span6_stamps[512 * 16];
+#define VT_S6_STAMP(k)                                                                                        \
+    do {                                                                                                      \
+        if (VT_DBG(16) && lane == 0 && blockIdx.x < 512) vt_span6_stamps[blockIdx.x * 16 + (k)] = wall_clock64(); \
+    } while (0)
+
+struct S6Args {
+    IgemmArgs p;
+    int dmin, halo;  // span row of tap t = (eh*W + ew) - dmin, in [0, halo]
+    int units;       // ceil(M / 32)
+    int upx;         // units per XCD
+    int rslots;      // row slots per XCD (workgroups per XCD / tiles_n)
+    int npc;         // span pieces (16 rows x 64 B) per chunk: ceil((32*kFMX + halo) / 16)
+    int ppt;         // pieces issued per tap at taps 0..5: ceil(npc / 6)
+    unsigned hw_magic, w_magic;  // ceil(2^32 / (H*W)), ceil(2^32 / W): quotients by multiply-high (+ one correction)
+    int dtap[9];     // span row of every tap
+    int eh[9], ew[9];  // its (row, column) offset (h0 + dh[t], w0 + dw[t])
+    int debug;       // dev ablations (VT_SPAN6_ABL): 1 no DMA in the loop, 2 no MFMA / reads, 4 no vmcnt wait, 16 stamps
+};
+
+__device__ __forceinline__ int swz4(int g) { return (0x1320 >> ((g & 3) * 4)) & 3; }
+
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {
+    const unsigned long v = (unsigned long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const void*)(((unsigned long)hi << 32) | lo);
+}
+// LDS-DMA, 16 B per lane: LDS address = M0 + lane*16, global address = sbase + voff (or the per-lane address)
+// (s_nop 4: the scalar base may have just been written by a VALU instruction -- v_readfirstlane here, or a
+//  v_readlane reloading a spilled SGPR -- and a VMEM instruction reading such an SGPR needs 5 wait states, which
+//  hipcc does not insert in front of an asm statement.  Without it the load can use a stale base: a memory fault.)
+__device__ __forceinline__ void glds_s(unsigned voff, const void* sbase) {
+    asm volatile("s_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(uniform_ptr(sbase)) : "memory");
+}
+__device__ __forceinline__ void glds_v(unsigned long gsrc) {
+    asm volatile("global_load_lds_dwordx4 %0, off" ::"v"(gsrc) : "memory");
+}
+__device__ __forceinline__ void set_m0(unsigned v) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(__builtin_amdgcn_readfirstlane(v)) : "memory");
+}
+__device__ __forceinline__ unsigned get_m0() {
+    unsigned v;
+    asm volatile("s_mov_b32 %0, m0" : "=s"(v)::"memory");
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void vmw() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// counted wait with a run-time, wave-uniform count (vmcnt takes an immediate)
+__device__ __forceinline__ void vm_wait_dyn(int n) {
+#define VT_W4(b)                                  \
+    switch (n - (b)) {                            \
+        case 0: vmw<(b) + 0>(); break;            \
+        case 1: vmw<(b) + 1>(); break;            \
+        case 2: vmw<(b) + 2>(); break;            \
+        default: vmw<(b) + 3>(); break;           \
+    }
+    if (n <= 0) { vmw<0>(); return; }
+    if (n >= 28) { vmw<28>(); return; }  // (a loader never has more than ~12 in flight: larger counts wait a little early)
+    if (n < 16) {
+        if (n < 8) { if (n < 4) { VT_W4(0) } else { VT_W4(4) } }
+        else { if (n < 12) { VT_W4(8) } else { VT_W4(12) } }
+    } else {
+        if (n < 24) { if (n < 20) { VT_W4(16) } else { VT_W4(20) } }
+        else { VT_W4(24) }
+    }
+#undef VT_W4
+}
+
+// LDS map (bytes): [row masks 2 groups x 2 x kBMX x 4][row output pixel 2 x 2 x kBMX x 4][filter ring kNSB x 8 KiB]
+//                  [zero strip kFMX KiB][group 0: span slot 0, slot 1][group 1: span slot 0, slot 1]
+struct L6 {
+    static constexpr int kMask = 0;
+    static constexpr int kPo = kMask + 4 * kBMX * 4;
+    static constexpr int kB = kPo + 4 * kBMX * 4;
+    static constexpr int kZero = kB + kNSB * kBSlot;
+    static constexpr int kA = kZero + kFMX * 1024;  // zero strip: fragment i of a padded tap reads kZero + i*1024
+    __host__ __device__ static constexpr int bytes(int npc) { return kA + 4 * npc * 1024; }
+};
+
+template <int T>
+using I_ = std::integral_constant<int, T>;
+
+typedef const __attribute__((address_space(4))) S6Args* ArgsPtr;
+__device__ __forceinline__ ArgsPtr fresh_args() {
+    ArgsPtr q = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(q));
+    return q;
+}
+
+__device__ __forceinline__ void wg_barrier() {
+    __builtin_amdgcn_sched_barrier(0);  // nothing migrates across a tick boundary
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// diagnostics: a barrier that adds the cycles this wave spent waiting in it to `w` (debug bit 16 only)
+#define VT_TBAR(w)                                         \
+    do {                                                   \
+        if (VT_DBG(16)) {                                  \
+            const unsigned long long c0_ = clock64();      \
+            wg_barrier();                                  \
+            (w) += clock64() - c0_;                        \
+        } else {                                           \
+            wg_barrier();                                  \
+        }                                                  \
+    } while (0)
+
+// 12 waves: 0-3 compute group 0, 4-7 compute group 1, 8-11 loaders; three per SIMD = at most 168 registers
+template <int MODE>  // epilogue: 0 plain (+ residual), 1 BatchNorm statistics, 2 affine (+ ReLU, + residual)
+__global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
+    const IgemmArgs& p = a.p;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned* sMask = (unsigned*)(smem + L6::kMask);
+    int* sPo = (int*)(smem + L6::kPo);
+    const char* sBb = smem + L6::kB;
+    const char* sZb = smem + L6::kZero;
+    const char* sAb = smem + L6::kA;
+    const int aslot_bytes = a.npc * 1024;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- this workgroup's share: a contiguous range of 32-row units of one XCD, one filter column tile ----
+    const int bid = blockIdx.x, xcd = bid & 7, l = bid >> 3;
+    const int tn = l % p.tiles_n, rs = l / p.tiles_n;
+    const int ux0 = xcd * a.upx, ux1 = min(a.units, ux0 + a.upx);
+    const int nx = max(0, ux1 - ux0);
+    const int ua = __builtin_amdgcn_readfirstlane(ux0 + (int)((unsigned)rs * (unsigned)nx / (unsigned)a.rslots));
+    const int ub = __builtin_amdgcn_readfirstlane(ux0 + (int)((unsigned)(rs + 1) * (unsigned)nx / (unsigned)a.rslots));
+    const int nun = ub - ua;
+    if (nun <= 0) return;
+    // group 0 takes the first ceil(nun/2) units, group 1 the rest; both cut their range into the SAME number of
+    // tiles (the two groups run one schedule), heights within a group differing by at most one unit
+    const int nun0 = (nun + 1) >> 1;
+    const int ntile = __builtin_amdgcn_readfirstlane((nun0 + kFMX - 1) / kFMX);
+    const int nchunks = __builtin_amdgcn_readfirstlane(p.Cin / 32);
+    const int nsteps = nchunks * 9;
+    // tile k of group g: units [gu0 + k*tb + min(k, te), + tb + (k < te)), gu0 = ua (g = 0) / ua + nun0 (g = 1)
+#define VT_G_NUN(g) ((g) ? nun - nun0 : nun0)
+#define VT_G_U0(g) ((g) ? ua + nun0 : ua)
+#define VT_TILE_U0(g, k) (VT_G_U0(g) + (k) * (VT_G_NUN(g) / ntile) + min((k), VT_G_NUN(g) % ntile))
+#define VT_TILE_F(g, k) (VT_G_NUN(g) / ntile + ((k) < VT_G_NUN(g) % ntile ? 1 : 0))
+
+    if (wave >= 8) {
+        // =========================== loader waves ==================================================
+        const int lj = wave - 8;  // 0..3
+        VT_S6_STAMP(0);
+        const char* xg = (const char*)p.x;
+        const char* wg = (const char*)p.w;
+        const unsigned a_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)(smem + L6::kA);
+        const unsigned b_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)(smem + L6::kB);
+        const unsigned m0_keep = get_m0();
+        const long M = p.M;
+        const long ldx2 = (long)p.ldx * 2;
+        const int cin2 = p.Cin * 2;
+        for (int i = lj * 64 + lane; i < kFMX * 64; i += 256) ((uint4*)(smem + L6::kZero))[i] = make_uint4(0, 0, 0, 0);
+
+        // span piece = 16 rows x 64 B: lane owns row (lane>>2), source chunk (lane&3)^swz4(lane>>4)
+        const int cjA = (lane & 3) ^ swz4(lane >> 4);
+        const unsigned a_vo = (unsigned)(((lane >> 2) * p.ldx + cjA * 8) * 2);
+        // filter slice = 8 pieces of 16 rows, this loader's are q = 2*lj, 2*lj+1; row n = 16q + (lane>>2); the
+        // fragment reads address row n with chunk position kq ^ swz4(n>>3), so the source chunk is
+        // (lane&3) ^ swz4(2q + (lane>>5)).  Rows past Cout (N tail) are clamped: their outputs are never stored.
+        unsigned b_voff[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = 2 * lj + i;
+            const int n = min(tn * 128 + 16 * q + (lane >> 2), p.Cout - 1);
+            const int cj = (lane & 3) ^ swz4(2 * q + (lane >> 5));
+            b_voff[i] = (unsigned)(((long)n * p.ldw + cj * 8) * 2);
+        }
+        int issued = 0;  // LDS-DMA instructions this wave has issued
+
+        auto issue_slice = [&](int slot, int ic, int T) {
+            const char* sb = wg + (long)ic * 64 + (long)T * cin2;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                set_m0(b_base + (unsigned)(slot * kBSlot + (2 * lj + i) * 1024));
+                glds_s(b_voff[i], sb);
+            }
+            issued += 2;
+        };
+        // this loader's pieces (pc = lj mod 4) among [p0, p1) of the span of group g that starts at pixel row prow
+        // (may be < 0 / run past M at the two ends of the tensor), channel chunk byte offset cb, into span slot sl.
+        // Rows outside the tensor are clamped: they are padding rows of every tap that could read them, so the
+        // fragment reads take the zero block instead.
+        auto issue_pieces = [&](int g, int sl, long prow, int cb, int p0, int p1) {
+            int pc = p0 + ((lj - p0) & 3);
+            for (; pc < p1; pc += 4) {
+                const long r0 = prow + pc * 16;
+                set_m0(a_base + (unsigned)((g * 2 + sl) * aslot_bytes + pc * 1024));
+                if (r0 >= 0 && r0 + 16 <= M) {
+                    glds_s(a_vo, xg + r0 * ldx2 + cb);
+                } else {
+                    long pix = r0 + (lane >> 2);
+                    pix = pix < 0 ? 0 : (pix >= M ? M - 1 : pix);
+                    glds_v((unsigned long)xg + (unsigned long)(pix * ldx2 + cb + cjA * 16));
+                }
+                ++issued;
+            }
+        };
+        // this loader's quarter (56 rows) of the tables of group g's tile that starts at pixel m0t (table half par)
+        auto row_tables = [&](int g, int par, long m0t) {
+            ArgsPtr Q = fresh_args();
+            const int W_ = Q->p.Wi, H_ = Q->p.Hi, HW_ = H_ * W_;
+            constexpr int QR = (kBMX + 3) / 4;
+            const int r = lj * QR + lane;
+            if (lane < QR && r < kBMX) {
+                const long m = m0t + r;
+                unsigned bits = 0;
+                int po = 0;
+                if (m < M) {
+                    int b = (int)__umulhi((unsigned)m, Q->hw_magic);
+                    int rem = (int)m - b * HW_;
+                    if (rem < 0) rem += HW_, --b;
+                    int oi = (int)__umulhi((unsigned)rem, Q->w_magic);
+                    int oj = rem - oi * W_;
+                    if (oj < 0) oj += W_, --oi;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t)
+                        if ((unsigned)(oi + Q->eh[t]) < (unsigned)H_ && (unsigned)(oj + Q->ew[t]) < (unsigned)W_) bits |= 1u << t;
+                    po = Q->p.dense_out ? (int)m : (b * Q->p.oH + (oi * Q->p.oHs + Q->p.oh0)) * Q->p.oW + (oj * Q->p.oWs + Q->p.ow0);
+                }
+                sMask[(g * 2 + par) * kBMX + r] = bits;
+                sPo[(g * 2 + par) * kBMX + r] = po;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // written before this wave's next barrier
+        };
+
+        // ---- prologue: both groups' first span chunk, slices 0..2, the first tiles' row tables -----------
+        const long S = (long)ntile * nsteps;  // steps of each group
+        long m0c[2] = {(long)VT_TILE_U0(0, 0) * 32, (long)VT_TILE_U0(1, 0) * 32};
+        issue_pieces(0, 0, m0c[0] + a.dmin, 0, 0, a.npc);
+        issue_pieces(1, 0, m0c[1] + a.dmin, 0, 0, a.npc);
+        int h0 = 0, h1 = 0, h2 = 0;  // `issued` right after this wave's share of slices s, s+1, s+2 went out
+        int sic = 0, sT = 0;         // (chunk, tap) of the next slice to issue; slices repeat per tile
+        long sg = 0;                 // its step
+        auto next_slice = [&]() {
+            if (sg < S) {
+                issue_slice((int)(sg & 3), sic, sT);
+                ++sg;
+                if (++sT == 9) {
+                    sT = 0;
+                    if (++sic == nchunks) sic = 0;
+                }
+            }
+            h0 = h1, h1 = h2, h2 = issued;
+        };
+        next_slice();
+        next_slice();
+        next_slice();
+        row_tables(0, 0, m0c[0]);
+        row_tables(1, 0, m0c[1]);
+        VT_S6_STAMP(1);
+
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // zero block and first tables written before barrier 0
+
+        // Tick t starts with barrier t.  Group 0 reads step s in tick 2s, group 1 in tick 2s+1 (and both re-read the
+        // slice during their MFMA ticks 2s+1 / 2s+2), so a slice's ring slot is free from barrier 2s+3 on; group g's
+        // span slot of chunk c-1 is free from its first read tick of chunk c.  Per step this wave issues, in order:
+        //   even tick: [its piece of group 0's next span]      (taps 0..NTP-1: piece 4T + lj)
+        //   odd tick:  [its two pieces of slice s+3] [its piece of group 1's next span]
+        // so before the even tick of tap T exactly 4 + P(T-1) + P(T-2) + P(T-3) [group 1] + P(T-1) + P(T-2) [group 0]
+        // of its instructions are younger than slice s (P(t) = 1 for 0 <= t < NTP): compile-time counts.
+        unsigned long long lwait = 0;
+        const unsigned long long lc0 = clock64();
+        const long rstride = 64 * ldx2;  // this wave's pieces are 4 pieces = 64 rows apart
+        int acur = 0;                    // span slot (both groups) of the chunk being read
+        int bnext = 3;                   // ring slot of the next slice to issue
+        long sleft = S;                  // steps left, the current one included
+        const bool dma = !VT_DBG(1);
+        auto chunks = [&](auto NTPc) {
+            constexpr int NTP = decltype(NTPc)::value;
+            for (int k = 0; k < ntile; ++k) {
+                const bool has_next = k + 1 < ntile;
+                long m0n[2] = {0, 0};
+                if (has_next) m0n[0] = (long)VT_TILE_U0(0, k + 1) * 32, m0n[1] = (long)VT_TILE_U0(1, k + 1) * 32;
+                for (int ic = 0; ic < nchunks; ++ic) {
+                    const bool lastc = ic + 1 == nchunks;
+                    const bool nextc = !lastc || has_next;  // a chunk follows this one (else: this one is re-loaded, unused)
+                    const int cb_t = !nextc ? ic * 64 : (lastc ? 0 : (ic + 1) * 64);
+                    long r0g[2];
+                    const char* srcg[2];
+                    unsigned m0g[2];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        r0g[g] = ((lastc && nextc) ? m0n[g] : m0c[g]) + a.dmin + lj * 16;
+                        srcg[g] = xg + r0g[g] * ldx2 + cb_t;
+                        m0g[g] = a_base + (unsigned)((g * 2 + (acur ^ 1)) * aslot_bytes + lj * 1024);
+                    }
+                    const char* wb_cur = wg + (long)ic * 64;
+                    const char* wb_nxt = wg + (long)(lastc ? 0 : ic + 1) * 64;
+                    auto piece = [&](int g) {
+                        set_m0(m0g[g]);
+                        if (r0g[g] >= 0 && r0g[g] + 16 <= M) {
+                            glds_s(a_vo, srcg[g]);
+                        } else {
+                            long pix = r0g[g] + (lane >> 2);
+                            pix = pix < 0 ? 0 : (pix >= M ? M - 1 : pix);
+                            glds_v((unsigned long)xg + (unsigned long)(pix * ldx2 + cb_t + cjA * 16));
+                        }
+                        r0g[g] += 64;
+                        srcg[g] += rstride;
+                        m0g[g] += 4096;
+                    };
+                    auto step = [&](auto Tc) {
+                        constexpr int T = decltype(Tc)::value;
+                        constexpr auto P = [](int t) { return (t >= 0 && t < NTP) ? 1 : 0; };
+                        constexpr int kYounger = 4 + P(T - 1) + P(T - 2) + P(T - 3) + P(T - 1) + P(T - 2);
+                        // ---- even tick 2s: slice s (and everything older: both groups' spans of its chunk) has landed
+                        if (!VT_DBG(4)) {
+                            if (sleft > 2) vmw<kYounger>();
+                            else vmw<0>();
+                        }
+                        VT_TBAR(lwait);
+                        if (dma && T < NTP) piece(0);
+                        // the next tiles' row tables, behind taps 6 (group 0) and 7 (group 1) of this tile's first chunk:
+                        // the halves they go to were last read by the previous tiles' epilogues, which every compute
+                        // wave left before this tile's first ticks
+                        if (T == 6 && ic == 0 && has_next) row_tables(0, (k + 1) & 1, m0n[0]);
+                        // ---- odd tick 2s+1: group 1 reads step s
+                        VT_TBAR(lwait);
+                        // group 1 has left its MFMA tick of step s-1 (whose second pair of filter fragments it read
+                        // during that tick): the ring slot of slice s-1 takes slice s+3
+                        if (dma && sleft > 3) {
+                            constexpr int T3 = (T + 3) % 9;
+                            const char* sb = (T < 6 ? wb_cur : wb_nxt) + (long)(T3 * cin2);
+                            const unsigned m0b = b_base + (unsigned)(bnext * kBSlot + 2 * lj * 1024);
+                            set_m0(m0b);
+                            glds_s(b_voff[0], sb);
+                            set_m0(m0b + 1024);
+                            glds_s(b_voff[1], sb);
+                        }
+                        if (dma && T < NTP) piece(1);
+                        if (T == 7 && ic == 0 && has_next) row_tables(1, (k + 1) & 1, m0n[1]);
+                        bnext = (bnext + 1) & 3;
+                        --sleft;
+                    };
+                    step(I_<0>{});
+                    step(I_<1>{});
+                    step(I_<2>{});
+                    step(I_<3>{});
+                    step(I_<4>{});
+                    step(I_<5>{});
+                    step(I_<6>{});
+                    step(I_<7>{});
+                    step(I_<8>{});
+                    acur ^= 1;
+                }
+                m0c[0] = m0n[0], m0c[1] = m0n[1];
+            }
+        };
+        switch (a.npc >> 2) {
+            case 4: chunks(I_<4>{}); break;
+            case 5: chunks(I_<5>{}); break;
+            default: chunks(I_<6>{}); break;
+        }
+        wg_barrier();  // tick 2S: group 1's last MFMA tick
+        VT_S6_STAMP(2);
+        if (VT_DBG(16) && lj == 0 && lane == 0 && blockIdx.x < 512) {
+            vt_span6_stamps[blockIdx.x * 16 + 13] = lwait;
+            vt_span6_stamps[blockIdx.x * 16 + 14] = clock64() - lc0;
+        }
+        vmw<0>();
+        set_m0(m0_keep);
+        return;
+    }
+
+    // =============================== compute waves ==================================================
+    const int grp = wave >> 2;  // 0: reads in even ticks, MFMAs in odd ticks; 1: one tick later
+    const int wm = (wave >> 1) & 1, wn = wave & 1;
+    const int q4 = lane >> 4, c16 = lane & 15;
+    // this lane's output channels: ch(h, e8) = tn*128 + wn*64 + h*32 + q4*8 + e8, h = 0,1, e8 = 0..7
+    const int ch0 = tn * 128 + wn * 64 + q4 * 8;
+    // filter fragment j of this lane: MFMA row r = c16 -> slice row n_j = wn*64 + (j>>1)*32 + (r>>2)*8 + (j&1)*4 + (r&3);
+    // (n_j >> 3) & 3 = r >> 2 for every j, so the four fragments share one swizzle term and differ by constants
+    const int nb0 = wn * 64 + (c16 >> 2) * 8 + (c16 & 3);
+    const int b_lane = (nb0 * 4 + (q4 ^ swz4(c16 >> 2))) * 16;  // byte offset inside a slice; j adds {0,256,2048,2304}
+    const int g_nun = VT_G_NUN(grp), g_u0 = VT_G_U0(grp);
+    const int g_tb = g_nun / ntile, g_te = g_nun % ntile;
+    const char* sAg = sAb + grp * 2 * aslot_bytes;  // this group's two span slots
+    int bcur = 0, acur = 0;
+    unsigned long long cwait = 0, cR = 0, cM = 0;
+
+    if (grp == 1) wg_barrier();  // tick 0: group 0 reads its first step
+
+    for (int k = 0; k < ntile; ++k) {
+        const int par = k & 1;
+        const int f_cur = g_tb + (k < g_te ? 1 : 0);
+        const long m0_cur = (long)(g_u0 + k * g_tb + min(k, g_te)) * 32;
+        const int fm = max(f_cur, 4);           // row fragments per wave in this tile (4..kFMX)
+        const int rows_tile = 32 * f_cur;       // rows this tile owns (stores / statistics)
+        const int tbl = (grp * 2 + par) * kBMX;
+
+        auto run = [&](auto FMc) {
+            constexpr int FM = decltype(FMc)::value;
+            int wrow = wm * 16 * FM + c16;  // this lane's row inside the tile, fragment 0
+            asm volatile("" : "+v"(wrow));    // (opaque: nothing derived from it is hoisted out of the tile loop)
+            unsigned mw[(FM + 2) / 3];        // tap masks of this lane's FM rows, 9 bits each, three rows per register
+            unsigned a_off = 0;               // byte offset (inside this group's span slots) of this lane's fragment-0 row of the coming step
+            f32x4 acc[FM][4];
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+            for (int ic = 0; ic < nchunks; ++ic) {
+                bcur = __builtin_amdgcn_readfirstlane(bcur);
+                acur = __builtin_amdgcn_readfirstlane(acur);
+                const unsigned a_rd = (unsigned)(acur * aslot_bytes);
+                auto step = [&](auto Tc) {
+                    constexpr int T = decltype(Tc)::value;
+                    // ---- read tick: this step's slice and span are in LDS
+                    VT_TBAR(cwait);
+                    if (T == 0 && ic == 0) {
+                        if (wave == 0 && k < 4) VT_S6_STAMP(4 + 3 * k);
+#pragma unroll
+                        for (int i = 0; i < (FM + 2) / 3; ++i) mw[i] = 0u;
+#pragma unroll
+                        for (int i = 0; i < FM; ++i) mw[i / 3] |= (sMask[tbl + wrow + i * 16] & 0x1ffu) << ((i % 3) * 9);
+                        const int srow = wrow + fresh_args()->dtap[0];
+                        a_off = a_rd + (unsigned)((srow * 4 + (q4 ^ swz4(srow >> 2))) * 16);
+                    }
+                    if (VT_DBG(2)) {
+                        VT_TBAR(cwait);
+                        bcur = (bcur + 1) & 3;
+                        return;
+                    }
+                    const unsigned long long tR0 = VT_DBG(16) ? clock64() : 0;
+                    const char* A = sAg + a_off;  // computed during the previous MFMA tick (or at the tile's start)
+                    const char* Bt = sBb + ((bcur << 13) + b_lane);
+                    // three filter fragments are read in the read tick, the fourth during the MFMA tick into the
+                    // first one's registers (168 registers per lane): its latency hides behind 2*FM MFMAs
+                    uint4 af[FM], bf0, bf1, bf2;
+                    bf0 = *(const uint4*)(Bt);
+                    bf1 = *(const uint4*)(Bt + 256);
+                    bf2 = *(const uint4*)(Bt + 2048);
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+                        // a padded tap reads the zero strip at the same constant offset: ONE alternative address register
+                        const char* src = ((mw[i / 3] >> ((i % 3) * 9 + T)) & 1u) ? A : sZb;
+                        af[i] = *(const uint4*)(src + i * 1024);
+                    }
+                    // the next step's span row offset: a scalar load that returns during the MFMA tick
+                    const int dnext = fresh_args()->dtap[(T + 1) % 9];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers
+                    if (VT_DBG(16)) cR += clock64() - tR0;
+                    // ---- MFMA tick (the other group reads meanwhile)
+                    VT_TBAR(cwait);
+                    const unsigned long long tM0 = VT_DBG(16) ? clock64() : 0;
+#define VT_MMA_COL(bfrag, j)                                                                              \
+    _Pragma("unroll") for (int i = 0; i < FM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(   \
+        __builtin_bit_cast(bf16x8, bfrag), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0)
+                    VT_MMA_COL(bf0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    bf0 = *(const uint4*)(Bt + 2304);
+                    VT_MMA_COL(bf1, 1);
+                    VT_MMA_COL(bf2, 2);
+                    {
+                        // address of the next step's span rows (same tile), under the MFMAs
+                        const int srow = wrow + dnext;
+                        const unsigned rd = T == 8 ? (unsigned)((acur ^ 1) * aslot_bytes) : a_rd;
+                        a_off = rd + (unsigned)((srow * 4 + (q4 ^ swz4(srow >> 2))) * 16);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    VT_MMA_COL(bf0, 3);
+#undef VT_MMA_COL
+                    if (VT_DBG(16)) {
+                        asm volatile("s_nop 0" ::"v"(acc[FM - 1][3][0]));  // (the last MFMA's result: its issue has happened)
+                        cM += clock64() - tM0;
+                    }
+                    bcur = (bcur + 1) & 3;
+                };
+                step(I_<0>{});
+                step(I_<1>{});
+                step(I_<2>{});
+                step(I_<3>{});
+                step(I_<4>{});
+                step(I_<5>{});
+                step(I_<6>{});
+                step(I_<7>{});
+                step(I_<8>{});
+                acur ^= 1;
+            }
+
+            if (wave == 0 && k < 4) VT_S6_STAMP(5 + 3 * k);
+            // ---- epilogue: two 16-byte stores per row fragment, straight from the accumulators ----------
+            ArgsPtr Q = fresh_args();
+            constexpr bool affine = MODE == 2, stats = MODE == 1;
+            const bool relu = MODE == 2 && (Q->p.flags & VT_CONV_RELU);
+            const bool has_res = MODE != 1 && (Q->p.flags & VT_CONV_RESIDUAL) != 0;
+            const int Cout_ = Q->p.Cout, M_ = Q->p.M, ldy_ = Q->p.ldy, ldr_ = Q->p.ldr;
+            const bool dense_ = Q->p.dense_out;
+            bf16_t* __restrict__ yg = (bf16_t*)Q->p.y;
+            const bf16_t* __restrict__ rg = (const bf16_t*)Q->p.res;
+            const float* scale_ = Q->p.scale;
+            const float* shift_ = Q->p.shift;
+            float* stats_ = Q->p.stats;
+            const int rep = (int)((m0_cur / 32) % VT_STAT_REPLICAS);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                // (opaque: keeps the per-lane 64-bit output / statistics addresses from being hoisted out of the tile
+                //  loop, where they would sit in scratch across the whole step loop)
+                int n = ch0 + h * 32;
+                asm volatile("" : "+v"(n));
+                float s1[8], s2[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s1[e] = 0.f, s2[e] = 0.f;
+                float sc[8], sf[8];
+                if (affine) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int ne = min(n + e, Cout_ - 1);
+                        sc[e] = scale_ ? scale_[ne] : 1.f;
+                        sf[e] = shift_[ne];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int tr = wrow + i * 16;       // row inside the tile
+                    const int mrow = (int)m0_cur + tr;  // < 2^31 (checked by the dispatcher)
+                    const bool row_ok = tr < rows_tile && mrow < M_;
+                    const long po = dense_ ? mrow : sPo[tbl + tr];
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float t = acc[i][2 * h + (e >> 2)][e & 3];
+                        if (affine) t = fmaf(t, sc[e], sf[e]);
+                        if (relu) t = fmaxf(t, 0.f);
+                        v[e] = t;
+                    }
+                    uint4 out = VecIO<bf16_t>::pack(v);
+                    if (row_ok && n < Cout_) {
+                        if (stats) {
+                            float r8[8];
+                            VecIO<bf16_t>::unpack(out, r8);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                s1[e] += r8[e];
+                                s2[e] = fmaf(r8[e], r8[e], s2[e]);
+                            }
+                        }
+                        if (has_res) {
+                            const uint4 rr = *(const uint4*)(rg + (po * ldr_ + n));
+                            float fv[8], fr[8];
+                            VecIO<bf16_t>::unpack(out, fv);
+                            VecIO<bf16_t>::unpack(rr, fr);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) fv[e] += fr[e];
+                            out = VecIO<bf16_t>::pack(fv);
+                        }
+                        *(uint4*)(yg + (po * ldy_ + n)) = out;
+                    }
+                }
+                if (stats) {
+                    // sum over the 16 pixel lanes (same q4): butterfly, then lanes c16 = 0..7 keep channel e = c16
+                    float u = 0.f, v = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float x1 = s1[e], x2 = s2[e];
+#pragma unroll
+                        for (int o = 1; o < 16; o <<= 1) {
+                            x1 += __shfl_xor(x1, o, 64);
+                            x2 += __shfl_xor(x2, o, 64);
+                        }
+                        u = c16 == e ? x1 : u;
+                        v = c16 == e ? x2 : v;
+                    }
+                    const int nn = n + c16;
+                    if (c16 < 8 && nn < Cout_) {
+                        atomicAdd(&stats_[((long)rep * 2 + 0) * Cout_ + nn], u);
+                        atomicAdd(&stats_[((long)rep * 2 + 1) * Cout_ + nn], v);
+                    }
+                }
+            }
+            if (wave == 0 && k < 4) VT_S6_STAMP(6 + 3 * k);
+        };
+        switch (fm) {
+            case 4: run(I_<4>{}); break;
+            case 5:
+                if constexpr (kFMX > 5) {
+                    run(I_<5>{});
+                    break;
+                }
+            case 6:
+                if constexpr (kFMX > 6) {
+                    run(I_<6>{});
+                    break;
+                }
+            default: run(I_<kFMX>{}); break;
+        }
+    }
+    if (grp == 0) wg_barrier();  // tick 2S: group 1's last MFMA tick
+    if (VT_DBG(16) && wave == 0 && lane == 0 && blockIdx.x < 512) {
+        vt_span6_stamps[blockIdx.x * 16 + 15] = cwait;
+        vt_span6_stamps[blockIdx.x * 16 + 3] = cR;
+        vt_span6_stamps[blockIdx.x * 16 + 12] = cM;
+    }
+#undef VT_G_NUN
+#undef VT_G_U0
+#undef VT_TILE_U0
+#undef VT_TILE_F
+}
+
+}  // namespace
+
+// returns -1 when this kernel does not apply (the caller then tries the other span kernels)
+int vt_span6_dispatch(IgemmArgs& a0, int dtype, void* stream) {
+    const int enabled = getenv("VT_SPAN6") ? atoi(getenv("VT_SPAN6")) : 0;  // TODO static once settled
+    if (!enabled || dtype != VT_BF16) return -1;
+    if (a0.sh != 1 || a0.sw != 1 || a0.Ho != a0.Hi || a0.Wo != a0.Wi) return -1;
+    if (a0.Cin % 32 != 0 || a0.ntaps != 9 || a0.Cout < 64) return -1;
+    if ((long)a0.M + 2L * a0.Wi * VT_MAX_TAPS > 0x7fffffffL) return -1;
+    if ((long)a0.B * a0.oH * a0.oW > 0x7fffffffL) return -1;
+    if ((unsigned long)a0.M * a0.ldx * 2 >= 0xffff0000ul) return -1;
+    if ((unsigned long)a0.Cout * a0.ldw * 2 >= 0xffff0000ul) return -1;
+    int dmin = 1 << 30, dmax = -(1 << 30);
+    for (int t = 0; t < a0.ntaps; ++t) {
+        const int d = (a0.h0 + a0.dh[t]) * a0.Wi + (a0.w0 + a0.dw[t]);
+        dmin = d < dmin ? d : dmin;
+        dmax = d > dmax ? d : dmax;
+    }
+    S6Args a;
+    a.p = a0;
+    IgemmArgs& p = a.p;
+    a.dmin = dmin;
+    a.halo = dmax - dmin;
+    a.debug = getenv("VT_SPAN6_ABL") ? atoi(getenv("VT_SPAN6_ABL")) : 0;
+    for (int t = 0; t < 9; ++t) {
+        a.eh[t] = a0.h0 + a0.dh[t];
+        a.ew[t] = a0.w0 + a0.dw[t];
+        a.dtap[t] = a.eh[t] * a0.Wi + a.ew[t] - dmin;
+    }
+    p.tiles_n = (p.Cout + 127) / 128;
+    const int g8 = 32;  // workgroups per XCD: one per CU
+    if (g8 % p.tiles_n != 0) return -1;
+    // MFMA-bound layers only: enough rows to give every compute group at least 4 units
+    if ((long)p.M * p.tiles_n < 512L * 32 * 4) return -1;
+    a.rslots = g8 / p.tiles_n;
+    a.units = (p.M + 31) / 32;
+    a.upx = (a.units + 7) / 8;
+    a.npc = ((32 * kFMX + a.halo + 15) / 16 + 3) / 4 * 4;  // a multiple of 4: every loader issues one piece per tap 0..npc/4-1
+    a.ppt = (a.npc + 5) / 6;
+    if (a.npc < 16 || a.npc > 24) return -1;
+    const int smem = L6::bytes(a.npc);
+    if (smem > 160 * 1024) return -1;
+    const unsigned HW = (unsigned)(p.Hi * p.Wi), W = (unsigned)p.Wi;
+    if (HW == 1 || W == 1) return -1;
+    a.hw_magic = (unsigned)((0x100000000ull + HW - 1) / HW);
+    a.w_magic = (unsigned)((0x100000000ull + W - 1) / W);
+    const int mode = (p.flags & VT_CONV_STATS) ? 1 : ((p.flags & VT_CONV_AFFINE) ? 2 : 0);
+    if (mode == 1 && (p.flags & (VT_CONV_AFFINE | VT_CONV_RELU | VT_CONV_RESIDUAL))) return -1;
+    if (mode == 0 && (p.flags & VT_CONV_RELU)) return -1;
+    auto kern = mode == 1 ? span6_kernel<1> : (mode == 2 ? span6_kernel<2> : span6_kernel<0>);
+    {
+        const int rc = vt_raise_dynamic_lds((const void*)kern, 160 * 1024, "vt_conv_igemm(span6)");
+        if (rc != VT_OK) return rc;
+    }
+    vt_note_kernel("span6_kernel<bf16,2x4+4 waves,FM%d>", kFMX);
+    hipLaunchKernelGGL(kern, dim3(8 * g8), dim3(768), smem, (hipStream_t)stream, a);
+    VT_CHECK_LAUNCH("vt_conv_igemm(span6)");
+    if (kDiag && (a.debug & 16)) {
+        static int calls = 0;
+        if (++calls == 12) {  // a warm launch
+            (void)hipStreamSynchronize((hipStream_t)stream);
+            static unsigned long long h[512 * 16];
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(vt_span6_stamps), sizeof(h));
+            const int nb = 8 * g8 < 512 ? 8 * g8 : 512;
+            unsigned long long t0 = ~0ull;
+            for (int b = 0; b < nb; ++b) t0 = h[b * 16] < t0 ? h[b * 16] : t0;
+            double avg[16] = {0};
+            for (int b = 0; b < nb; ++b)
+                for (int k = 0; k < 16; ++k) avg[k] += ((k >= 12 || k == 3) ? (double)h[b * 16 + k] : (double)(h[b * 16 + k] - t0) * 0.01) / nb;
+            fprintf(stderr, "[span6 stamps, us from the first workgroup's start, mean over %d WGs] loader start %.1f prologue done %.1f loop done %.1f |"
+                            " tile0: first tick %.1f loop end %.1f epilogue end %.1f | tile1: %.1f %.1f %.1f | tile2: %.1f %.1f %.1f\n",
+                    nb, avg[0], avg[1], avg[2], avg[4], avg[5], avg[6], avg[7], avg[8], avg[9], avg[10], avg[11], avg[12]);
+            std::vector<double> st, en;
+            for (int b = 0; b < nb; ++b) st.push_back((h[b * 16] - t0) * 0.01), en.push_back((h[b * 16 + 2] - t0) * 0.01);
+            std::sort(st.begin(), st.end());
+            std::sort(en.begin(), en.end());
+            fprintf(stderr, "[span6 stamps] shader cycles, mean per WG: loader 0 waiting in barriers %.0f of %.0f in its loop; compute wave 0 waiting in barriers %.0f, read-tick work %.0f, MFMA-tick work %.0f\n",
+                    avg[13], avg[14], avg[15], avg[3], avg[12]);
+            fprintf(stderr, "[span6 stamps] start times (us), sorted, every 32nd WG:");
+            for (int b = 0; b < nb; b += 32) fprintf(stderr, " %.1f", st[b]);
+            fprintf(stderr, "\n[span6 stamps] loader end times (us), sorted, every 32nd WG:");
+            for (int b = 0; b < nb; b += 32) fprintf(stderr, " %.1f", en[b]);
+            fprintf(stderr, "\n");
+        }
+    }
+    return VT_OK;
+}
