@@ -57,7 +57,14 @@ __device__ unsigned long long vt_span_loop[8192 * 4];
 #define VT_SPAN_ABLATE 0
 #endif
 
-__device__ __forceinline__ int swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
+// chunk ^= 2 * ((row >> 2) & 1): the one 4-entry swizzle family (found by enumeration) under which a ds_read_b128 of
+// 16 consecutive 64-byte rows is conflict free for EVERY starting row -- a tap shifts the fragment rows by an
+// arbitrary offset; the table 0x1320 used before is conflict free only for offsets that are multiples of 4.
+// VT_SPAN_SWZ_TABLE: 0x2020 (this), 0x1320 (the old table, for A/B timing).
+#ifndef VT_SPAN_SWZ_TABLE
+#define VT_SPAN_SWZ_TABLE 0x2020
+#endif
+__device__ __forceinline__ int swz(int row) { return (VT_SPAN_SWZ_TABLE >> (((row >> 2) & 3) * 4)) & 3; }
 
 __device__ __forceinline__ void glds16(unsigned long gsrc, unsigned lds_base) {
     unsigned keep;
@@ -198,7 +205,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
 
     // ---- DMA geometry ---------------------------------------------------------------------
     // an instruction fills 16 rows x 64 B; lane l owns row 16j + (l>>2), chunk (l&3)^swz(row)
-    const int cj = (lane & 3) ^ ((0x1320 >> (((lane >> 4) & 3) * 4)) & 3);
+    const int cj = (lane & 3) ^ ((VT_SPAN_SWZ_TABLE >> (((lane >> 4) & 3) * 4)) & 3);
     // span row r = 16*(wave + NW*i) + (lane>>2) holds input pixel m0 + dmin + r (zero page outside)
     const long pix0 = m0 + dmin + 16 * wave + (lane >> 2);
     const unsigned long a_src0 = (unsigned long)(xg + (pix0 * p.ldx + cj * EPC));

@@ -78,7 +78,12 @@ struct S6Args {
     int debug;       // dev ablations (VT_SPAN6_ABL): 1 no DMA in the loop, 2 no MFMA / reads, 4 no vmcnt wait, 16 stamps
 };
 
-__device__ __forceinline__ int swz4(int g) { return (0x1320 >> ((g & 3) * 4)) & 3; }
+__device__ __forceinline__ int swz4(int g) { return (0x1320 >> ((g & 3) * 4)) & 3; }  // filter-slice image
+// Span image: chunk ^= 2 * ((row >> 2) & 1).  A tap shifts the fragment's 16 rows by an arbitrary offset; this is the
+// swizzle (found by enumeration over all 4-entry tables) under which the four 16-lane groups of a ds_read_b128 hit 16
+// distinct 16-byte slots for EVERY row offset -- the 0x1320 table is conflict free only for offsets that are
+// multiples of 4 (2-way on half of the taps).
+__device__ __forceinline__ int swzA(int g) { return (g & 1) << 1; }
 
 __device__ __forceinline__ const void* uniform_ptr(const void* p) {
     const unsigned long v = (unsigned long)p;
@@ -221,8 +226,8 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
         // row i is the one left of row i+1, the zero row below an image the one above the next) and the compute
         // waves need no masks at all.  The loaders build the span from the unpadded tensor: LDS row r of a piece is
         // padded position mp; its source is pixel (b, i, j) or the zero page.
-        // span piece = 16 rows x 64 B: lane owns row (lane>>2), source chunk (lane&3)^swz4(lane>>4)
-        const int cjA = (lane & 3) ^ swz4(lane >> 4);
+        // span piece = 16 rows x 64 B: lane owns row (lane>>2), source chunk (lane&3)^swzA(lane>>4)
+        const int cjA = (lane & 3) ^ swzA(lane >> 4);
         // (b, i, j) of padded position mp (0 <= mp < Mp); false for a padding position
         auto unpad = [&](int mp, int& b_, int& i_, int& j_) -> bool {
             int q = (int)__umulhi((unsigned)mp, wp_magic);
@@ -234,13 +239,28 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
             b_ = b, i_ = i, j_ = j;
             return j < W_ && i < H_;
         };
-        // global source of this lane's 16 bytes of the span row at padded position mp, chunk byte offset cb
-        auto span_src = [&](int mp, int cb) -> unsigned long {
+        // global source (channel chunk 0) of this lane's 16 bytes of the span row at padded position mp; `ok`: a real
+        // pixel (the chunk's byte offset applies), else the zero page
+        auto span_src = [&](int mp, bool& ok) -> unsigned long {
             const bool inr = (unsigned)mp < (unsigned)Mp;
             int b, i, j;
-            const bool ok = unpad(inr ? mp : 0, b, i, j) && inr;
+            ok = unpad(inr ? mp : 0, b, i, j) && inr;
             const long pix = ((long)b * H_ + i) * W_ + j;
-            return ok ? (unsigned long)xg + (unsigned long)(pix * ldx2 + cb + cjA * 16) : zero_src;
+            return ok ? (unsigned long)xg + (unsigned long)(pix * ldx2 + cjA * 16) : zero_src;
+        };
+        // The padded -> pixel mapping of this wave's pieces (piece T of group g = span rows 16*(lj + 4T) ..) depends on
+        // the tile only, not on the channel chunk: it is computed once per tile (behind taps 6 / 7 of the previous
+        // tile's first chunk) and a piece in the step loop costs one add.
+        unsigned long ab_cur[2][6], ab_nxt[2][6];
+        unsigned vm_cur[2] = {0, 0}, vm_nxt[2] = {0, 0};  // bit T: piece T's row of this lane is a real pixel
+        auto tile_bases = [&](int m0t, unsigned long (&ab)[6], unsigned& vm) {
+            vm = 0;
+#pragma unroll
+            for (int T = 0; T < 6; ++T) {
+                bool ok;
+                ab[T] = span_src(m0t + a.dmin + (lj + 4 * T) * 16 + (lane >> 2), ok);
+                vm |= (ok ? 1u : 0u) << T;
+            }
         };
         // filter slice = 8 pieces of 16 rows, this loader's are q = 2*lj, 2*lj+1; row n = 16q + (lane>>2); the
         // fragment reads address row n with chunk position kq ^ swz4(n>>3), so the source chunk is
@@ -264,16 +284,6 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
             }
             issued += 2;
         };
-        // this loader's pieces (pc = lj mod 4) among [p0, p1) of the span of group g that starts at padded position
-        // prow, channel chunk byte offset cb, into span slot sl
-        auto issue_pieces = [&](int g, int sl, int prow, int cb, int p0, int p1) {
-            int pc = p0 + ((lj - p0) & 3);
-            for (; pc < p1; pc += 4) {
-                set_m0(a_base + (unsigned)((g * 2 + sl) * aslot_bytes + pc * 1024));
-                glds_v(span_src(prow + pc * 16 + (lane >> 2), cb));
-                ++issued;
-            }
-        };
         // this loader's quarter of the table of group g's tile that starts at padded position m0t (table half par):
         // where each row is stored, -1 for a padding position
         auto row_tables = [&](int g, int par, int m0t) {
@@ -296,8 +306,18 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
         // ---- prologue: both groups' first span chunk, slices 0..2, the first tiles' row tables -----------
         const long S = (long)ntile * nsteps;  // steps of each group
         int m0c[2] = {VT_TILE_U0(0, 0) * 32, VT_TILE_U0(1, 0) * 32};
-        issue_pieces(0, 0, m0c[0] + a.dmin, 0, 0, a.npc);
-        issue_pieces(1, 0, m0c[1] + a.dmin, 0, 0, a.npc);
+        // the first tile's piece sources, then every LDS-DMA of the prologue, then the row tables under their flight
+        tile_bases(m0c[0], ab_cur[0], vm_cur[0]);
+        tile_bases(m0c[1], ab_cur[1], vm_cur[1]);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int T = 0; T < 6; ++T)
+                if (lj + 4 * T < a.npc) {
+                    set_m0(a_base + (unsigned)((g * 2) * aslot_bytes + (lj + 4 * T) * 1024));
+                    glds_v(ab_cur[g][T]);
+                    ++issued;
+                }
         int h0 = 0, h1 = 0, h2 = 0;  // `issued` right after this wave's share of slices s, s+1, s+2 went out
         int sic = 0, sT = 0;         // (chunk, tap) of the next slice to issue; slices repeat per tile
         long sg = 0;                 // its step
@@ -315,10 +335,10 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
         next_slice();
         next_slice();
         next_slice();
+        (void)h0;
         row_tables(0, 0, m0c[0]);
         row_tables(1, 0, m0c[1]);
         VT_S6_STAMP(1);
-
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // zero block and first tables written before barrier 0
 
         // Tick t starts with barrier t.  Group 0 reads step s in tick 2s, group 1 in tick 2s+1 (and both re-read the
@@ -344,21 +364,14 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                     const bool lastc = ic + 1 == nchunks;
                     const bool nextc = !lastc || has_next;  // a chunk follows this one (else: this one is re-loaded, unused)
                     const int cb_t = !nextc ? ic * 64 : (lastc ? 0 : (ic + 1) * 64);
-                    int r0g[2];  // padded position of the first row of this wave's next piece, per group
+                    const bool nx = lastc && nextc;  // the chunk being loaded belongs to the next tile
                     unsigned m0g[2];
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        r0g[g] = ((lastc && nextc) ? m0n[g] : m0c[g]) + a.dmin + lj * 16;
+                    for (int g = 0; g < 2; ++g)
                         m0g[g] = a_base + (unsigned)((g * 2 + (acur ^ 1)) * aslot_bytes + lj * 1024);
-                    }
                     const char* wb_cur = wg + (long)ic * 64;
                     const char* wb_nxt = wg + (long)(lastc ? 0 : ic + 1) * 64;
-                    auto piece = [&](int g) {
-                        set_m0(m0g[g]);
-                        glds_v(span_src(r0g[g] + (lane >> 2), cb_t));
-                        r0g[g] += 64;
-                        m0g[g] += 4096;
-                    };
+                    const unsigned long cb64 = (unsigned long)cb_t;
                     auto step = [&](auto Tc) {
                         constexpr int T = decltype(Tc)::value;
                         constexpr auto P = [](int t) { return (t >= 0 && t < NTP) ? 1 : 0; };
@@ -369,11 +382,19 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                             else vmw<0>();
                         }
                         VT_TBAR(lwait);
-                        if (dma && T < NTP) piece(0);
+                        if constexpr (T < NTP) if (dma) {
+                            const unsigned long base = nx ? ab_nxt[0][T] : ab_cur[0][T];
+                            const unsigned v = ((nx ? vm_nxt[0] : vm_cur[0]) >> T) & 1u;
+                            set_m0(m0g[0] + T * 4096);
+                            glds_v(base + (v ? cb64 : 0ul));
+                        }
                         // the next tiles' row tables, behind taps 6 (group 0) and 7 (group 1) of this tile's first chunk:
                         // the halves they go to were last read by the previous tiles' epilogues, which every compute
                         // wave left before this tile's first ticks
-                        if (T == 6 && ic == 0 && has_next) row_tables(0, (k + 1) & 1, m0n[0]);
+                        if (T == 6 && ic == 0 && has_next) {
+                            row_tables(0, (k + 1) & 1, m0n[0]);
+                            tile_bases(m0n[0], ab_nxt[0], vm_nxt[0]);
+                        }
                         // ---- odd tick 2s+1: group 1 reads step s
                         VT_TBAR(lwait);
                         // group 1 has left its MFMA tick of step s-1 (whose second pair of filter fragments it read
@@ -387,8 +408,16 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                             set_m0(m0b + 1024);
                             glds_s(b_voff[1], sb);
                         }
-                        if (dma && T < NTP) piece(1);
-                        if (T == 7 && ic == 0 && has_next) row_tables(1, (k + 1) & 1, m0n[1]);
+                        if constexpr (T < NTP) if (dma) {
+                            const unsigned long base = nx ? ab_nxt[1][T] : ab_cur[1][T];
+                            const unsigned v = ((nx ? vm_nxt[1] : vm_cur[1]) >> T) & 1u;
+                            set_m0(m0g[1] + T * 4096);
+                            glds_v(base + (v ? cb64 : 0ul));
+                        }
+                        if (T == 7 && ic == 0 && has_next) {
+                            row_tables(1, (k + 1) & 1, m0n[1]);
+                            tile_bases(m0n[1], ab_nxt[1], vm_nxt[1]);
+                        }
                         bnext = (bnext + 1) & 3;
                         --sleft;
                     };
@@ -404,6 +433,12 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                     acur ^= 1;
                 }
                 m0c[0] = m0n[0], m0c[1] = m0n[1];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    vm_cur[g] = vm_nxt[g];
+#pragma unroll
+                    for (int T = 0; T < 6; ++T) ab_cur[g][T] = ab_nxt[g][T];
+                }
             }
         };
         switch (a.npc >> 2) {
@@ -470,7 +505,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                     if (T == 0 && ic == 0) {
                         if (wave == 0 && k < 4) VT_S6_STAMP(4 + 3 * k);
                         const int srow = wrow + fresh_args()->dtap[0];
-                        a_off = a_rd + (unsigned)((srow * 4 + (q4 ^ swz4(srow >> 2))) * 16);
+                        a_off = a_rd + (unsigned)((srow * 4 + (q4 ^ swzA(srow >> 2))) * 16);
                     }
                     if (VT_DBG(2)) {
                         VT_TBAR(cwait);
@@ -515,7 +550,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                         // address of the next step's span rows (same tile), under the MFMAs
                         const int srow = wrow + dnext;
                         const unsigned rd = T == 8 ? (unsigned)((acur ^ 1) * aslot_bytes) : a_rd;
-                        a_off = rd + (unsigned)((srow * 4 + (q4 ^ swz4(srow >> 2))) * 16);
+                        a_off = rd + (unsigned)((srow * 4 + (q4 ^ swzA(srow >> 2))) * 16);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     VT_MMA_COL(bf0, 3);
