@@ -187,6 +187,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
 
     // ---- this workgroup's share: a contiguous range of 32-row units of one XCD, one filter column tile ----
     const int bid = blockIdx.x, xcd = bid & 7, l = bid >> 3;
+    if (l >= a.rslots * p.tiles_n) return;  // (tiles_n does not divide 32)
     const int tn = l % p.tiles_n, rs = l / p.tiles_n;
     const int ux0 = xcd * a.upx, ux1 = min(a.units, ux0 + a.upx);
     const int nx = max(0, ux1 - ux0);
@@ -251,12 +252,12 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
         // The padded -> pixel mapping of this wave's pieces (piece T of group g = span rows 16*(lj + 4T) ..) depends on
         // the tile only, not on the channel chunk: it is computed once per tile (behind taps 6 / 7 of the previous
         // tile's first chunk) and a piece in the step loop costs one add.
-        unsigned long ab_cur[2][6], ab_nxt[2][6];
+        unsigned long ab_cur[2][7], ab_nxt[2][7];
         unsigned vm_cur[2] = {0, 0}, vm_nxt[2] = {0, 0};  // bit T: piece T's row of this lane is a real pixel
-        auto tile_bases = [&](int m0t, unsigned long (&ab)[6], unsigned& vm) {
+        auto tile_bases = [&](int m0t, unsigned long (&ab)[7], unsigned& vm) {
             vm = 0;
 #pragma unroll
-            for (int T = 0; T < 6; ++T) {
+            for (int T = 0; T < 7; ++T) {
                 bool ok;
                 ab[T] = span_src(m0t + a.dmin + (lj + 4 * T) * 16 + (lane >> 2), ok);
                 vm |= (ok ? 1u : 0u) << T;
@@ -312,7 +313,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int T = 0; T < 6; ++T)
+            for (int T = 0; T < 7; ++T)
                 if (lj + 4 * T < a.npc) {
                     set_m0(a_base + (unsigned)((g * 2) * aslot_bytes + (lj + 4 * T) * 1024));
                     glds_v(ab_cur[g][T]);
@@ -345,9 +346,9 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
         // slice during their MFMA ticks 2s+1 / 2s+2), so a slice's ring slot is free from barrier 2s+3 on; group g's
         // span slot of chunk c-1 is free from its first read tick of chunk c.  Per step this wave issues, in order:
         //   even tick: [its piece of group 0's next span]      (taps 0..NTP-1: piece 4T + lj)
-        //   odd tick:  [its two pieces of slice s+3] [its piece of group 1's next span]
-        // so before the even tick of tap T exactly 4 + P(T-1) + P(T-2) + P(T-3) [group 1] + P(T-1) + P(T-2) [group 0]
-        // of its instructions are younger than slice s (P(t) = 1 for 0 <= t < NTP): compile-time counts.
+        //   odd tick:  [its piece of group 1's next span] [its two pieces of slice s+3]
+        // so before the even tick of tap T exactly 4 + 2 * (P(T-1) + P(T-2)) of its instructions are younger than
+        // slice s (P(t) = 1 for 0 <= t < NTP): compile-time counts.
         unsigned long long lwait = 0;
         const unsigned long long lc0 = clock64();
         int acur = 0;                    // span slot (both groups) of the chunk being read
@@ -375,7 +376,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                     auto step = [&](auto Tc) {
                         constexpr int T = decltype(Tc)::value;
                         constexpr auto P = [](int t) { return (t >= 0 && t < NTP) ? 1 : 0; };
-                        constexpr int kYounger = 4 + P(T - 1) + P(T - 2) + P(T - 3) + P(T - 1) + P(T - 2);
+                        constexpr int kYounger = 4 + 2 * (P(T - 1) + P(T - 2));
                         // ---- even tick 2s: slice s (and everything older: both groups' spans of its chunk) has landed
                         if (!VT_DBG(4)) {
                             if (sleft > 2) vmw<kYounger>();
@@ -397,6 +398,13 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                         }
                         // ---- odd tick 2s+1: group 1 reads step s
                         VT_TBAR(lwait);
+                        // (the piece goes first: at tap NTP-1 = 6 it must be older than the slice whose wait retires it)
+                        if constexpr (T < NTP) if (dma) {
+                            const unsigned long base = nx ? ab_nxt[1][T] : ab_cur[1][T];
+                            const unsigned v = ((nx ? vm_nxt[1] : vm_cur[1]) >> T) & 1u;
+                            set_m0(m0g[1] + T * 4096);
+                            glds_v(base + (v ? cb64 : 0ul));
+                        }
                         // group 1 has left its MFMA tick of step s-1 (whose second pair of filter fragments it read
                         // during that tick): the ring slot of slice s-1 takes slice s+3
                         if (dma && sleft > 3) {
@@ -407,12 +415,6 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                             glds_s(b_voff[0], sb);
                             set_m0(m0b + 1024);
                             glds_s(b_voff[1], sb);
-                        }
-                        if constexpr (T < NTP) if (dma) {
-                            const unsigned long base = nx ? ab_nxt[1][T] : ab_cur[1][T];
-                            const unsigned v = ((nx ? vm_nxt[1] : vm_cur[1]) >> T) & 1u;
-                            set_m0(m0g[1] + T * 4096);
-                            glds_v(base + (v ? cb64 : 0ul));
                         }
                         if (T == 7 && ic == 0 && has_next) {
                             row_tables(1, (k + 1) & 1, m0n[1]);
@@ -437,14 +439,15 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                 for (int g = 0; g < 2; ++g) {
                     vm_cur[g] = vm_nxt[g];
 #pragma unroll
-                    for (int T = 0; T < 6; ++T) ab_cur[g][T] = ab_nxt[g][T];
+                    for (int T = 0; T < 7; ++T) ab_cur[g][T] = ab_nxt[g][T];
                 }
             }
         };
         switch (a.npc >> 2) {
             case 4: chunks(I_<4>{}); break;
             case 5: chunks(I_<5>{}); break;
-            default: chunks(I_<6>{}); break;
+            case 6: chunks(I_<6>{}); break;
+            default: chunks(I_<7>{}); break;
         }
         wg_barrier();  // tick 2S: group 1's last MFMA tick
         VT_S6_STAMP(2);
@@ -722,8 +725,8 @@ int vt_span6_dispatch(IgemmArgs& a0, int dtype, void* stream) {
     a.dmin = -a.Wp - 1;
     a.halo = 2 * a.Wp + 2;
     p.tiles_n = (p.Cout + 127) / 128;
-    const int g8 = 32;  // workgroups per XCD: one per CU
-    if (g8 % p.tiles_n != 0) return -1;
+    if (p.tiles_n > 8) return -1;
+    const int g8 = 32 - 32 % p.tiles_n;  // working workgroups per XCD (one per CU; 32 % tiles_n CUs per XCD sit out)
     // MFMA-bound layers only: enough rows to give every compute group at least 4 units
     if ((long)p.M * p.tiles_n < 512L * 32 * 4) return -1;
     a.rslots = g8 / p.tiles_n;
@@ -731,7 +734,7 @@ int vt_span6_dispatch(IgemmArgs& a0, int dtype, void* stream) {
     a.upx = (a.units + 7) / 8;
     a.npc = ((32 * kFMX + a.halo + 15) / 16 + 3) / 4 * 4;  // a multiple of 4: every loader issues one piece per tap 0..npc/4-1
     a.ppt = (a.npc + 5) / 6;
-    if (a.npc < 16 || a.npc > 24) return -1;
+    if (a.npc < 16 || a.npc > 28) return -1;  // 4..7 taps carry one piece per loader and group
     const int smem = L6::bytes(a.npc);
     if (smem > 160 * 1024) return -1;
     a.hp_magic = (unsigned)((0x100000000ull + a.Hp - 1) / a.Hp);
@@ -745,7 +748,7 @@ int vt_span6_dispatch(IgemmArgs& a0, int dtype, void* stream) {
         if (rc != VT_OK) return rc;
     }
     vt_note_kernel("span6_kernel<bf16,2x4+4 waves,FM%d>", kFMX);
-    hipLaunchKernelGGL(kern, dim3(8 * g8), dim3(768), smem, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kern, dim3(8 * 32), dim3(768), smem, (hipStream_t)stream, a);
     VT_CHECK_LAUNCH("vt_conv_igemm(span6)");
     if (kDiag && (a.debug & 16)) {
         static int calls = 0;
@@ -753,7 +756,7 @@ int vt_span6_dispatch(IgemmArgs& a0, int dtype, void* stream) {
             (void)hipStreamSynchronize((hipStream_t)stream);
             static unsigned long long h[512 * 16];
             (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(vt_span6_stamps), sizeof(h));
-            const int nb = 8 * g8 < 512 ? 8 * g8 : 512;
+            const int nb = 256;
             unsigned long long t0 = ~0ull;
             for (int b = 0; b < nb; ++b) t0 = h[b * 16] < t0 ? h[b * 16] : t0;
             double avg[16] = {0};
