@@ -296,6 +296,60 @@ class TestBackbone:
         torch.testing.assert_close(traced(inputs), m(inputs), rtol=1e-4, atol=1e-4)
 
 
+def test_traced_graph_holds_the_registered_operator_and_survives_save_load(tmp_path):
+    """SURVEY 8b / VERDICT r1 missing 6: the module API dispatches to `vision_toolbox_amd::backbone` (torch.library),
+    so a trace is a real operator node -- serialisable, unlike an autograd.Function's PythonOp."""
+    m = backbones.darknet19().cuda().eval()
+    x = torch.rand(2, 3, 64, 64, device="cuda")
+    traced = torch.jit.trace(m, x, check_trace=False)
+    assert "vision_toolbox_amd::backbone" in str(traced.graph)
+    path = str(tmp_path / "darknet19_traced.pt")
+    traced.save(path)
+    loaded = torch.jit.load(path)
+    torch.testing.assert_close(loaded(x), m(x), rtol=1e-5, atol=1e-5)
+
+
+def test_torch_compile_traces_through_the_operator():
+    """the fake-tensor implementation gives shapes / strides / dtypes, so torch.compile (aot_eager: dynamo + AOT
+    autograd tracing with fake tensors, no inductor code generation) runs the module and matches eager; reference
+    tests/test_backbones.py:80-86."""
+    m = backbones.vovnet19_slim_ese().cuda().eval()
+    x = torch.rand(2, 3, 64, 64, device="cuda")
+    want = [t.clone() for t in m.get_feature_maps(x)]
+    compiled = torch.compile(m.get_feature_maps, backend="aot_eager")
+    got = compiled(x)
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+
+
+def test_operator_autograd_matches_module_autograd():
+    """gradients through the registered autograd formula (input and every parameter) after a second, interleaved
+    forward: each graph owns its own run state."""
+    m = backbones.darknet_yolov5n().cuda().train()
+    filler.fill_module(m, "opg.")
+    x1 = torch.rand(2, 3, 64, 64, device="cuda", requires_grad=True)
+    x2 = torch.rand(2, 3, 64, 64, device="cuda", requires_grad=True)
+    y1 = m(x1)
+    y2 = m(x2)  # a second forward before the first backward
+    (y1.float().square().mean()).backward()
+    g1 = {k: p.grad.clone() for k, p in m.named_parameters()}
+    dx1 = x1.grad.clone()
+    for p in m.parameters():
+        p.grad = None
+    (y2.float().square().mean()).backward()
+    assert x2.grad is not None and torch.isfinite(x2.grad).all()
+    # the same forward alone gives the same gradients (batch statistics make the two forwards independent)
+    for p in m.parameters():
+        p.grad = None
+    x1b = x1.detach().clone().requires_grad_(True)
+    m(x1b).float().square().mean().backward()
+    # (f32 atomics in the statistics arrive in a different order from run to run: compare in relative L2)
+    assert rel_err(x1b.grad, dx1) < 1e-3
+    for k, p in m.named_parameters():
+        assert rel_err(p.grad, g1[k]) < 5e-3, k
+
+
 def test_oracle_and_hip_agree_on_fresh_random_init():
     """default init (kaiming fan_out, components.py:45-46) -> copy weights to the oracle."""
     torch.manual_seed(0)

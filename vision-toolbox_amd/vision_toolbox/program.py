@@ -2,15 +2,22 @@
 
 `BackboneRunner` owns, per backbone instance, the flat parameter store and a cache of
 compiled programs keyed by (input shape, dtype, mode).  `forward()` /
-`get_feature_maps()` of a backbone (reference backbones/base.py:16-21) go through
-ONE autograd.Function whose forward runs the forward launch list and whose backward
-runs the explicit backward list; the returned feature maps are ordinary
-autograd-tracked tensors, so user heads / necks (necks.py:83) compose with them.
+`get_feature_maps()` of a backbone (reference backbones/base.py:16-21) go through ONE
+registered operator, `torch.ops.vision_toolbox_amd.backbone` (torch.library custom op,
+SURVEY 8b): its CUDA implementation runs the forward launch list, its registered
+autograd formula the explicit backward list, and its fake-tensor (meta) implementation
+gives shapes / strides / dtypes without touching the GPU -- so `torch.jit.trace`
+(reference tests/test_backbones.py:76-78) records a real, serialisable operator node and
+`torch.compile` / `torch.export` can trace through the module.  The returned feature
+maps are ordinary autograd-tracked tensors, so user heads / necks (necks.py:83) compose
+with them.
 """
 from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import itertools
+import weakref
 from typing import Optional, Sequence
 
 import torch
@@ -23,7 +30,7 @@ from . import engine as E
 @contextlib.contextmanager
 def tracing_paused():
     """host-side set-up (flat parameter store, program compilation) must not be recorded by
-    torch.jit.trace; only the BackboneFn call is (as one PythonOp)."""
+    torch.jit.trace; only the `vision_toolbox_amd::backbone` operator call is."""
     state = torch._C._get_tracing_state()
     if state is None:
         yield
@@ -36,7 +43,9 @@ def tracing_paused():
 
 
 def current_stream_handle() -> int:
-    return int(torch.cuda.current_stream().cuda_stream)
+    # the raw hipStream_t of the current torch stream (also valid while dynamo runs the operator from a compiled
+    # region, where torch.cuda.current_stream() returns a proxy without .cuda_stream)
+    return int(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def resolve_dtype(x: torch.Tensor, override: Optional[torch.dtype]) -> int:
@@ -117,23 +126,73 @@ class _RunState:
     __slots__ = ("prog", "arena", "bases", "x_shape")
 
 
-class BackboneFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, runner: "BackboneRunner", prog: Program, x: torch.Tensor, *params):
-        with tracing_paused():
-            st, outs = runner._run_forward(prog, x)
-        ctx.runner, ctx.st = runner, st
-        ctx.x_requires_grad = x.requires_grad
-        ctx.n_params = len(params)
-        return tuple(outs)
+# ---- the registered operator ---------------------------------------------------------------------
+# Non-tensor state travels by handle: `handle` names the BackboneRunner (weak registry); the run state a
+# backward needs (arena, bases) is parked by the CUDA implementation under `token` (its last, CPU int64,
+# output) and moved into the autograd context by setup_context, so it lives exactly as long as the graph.
+_RUNNERS: "weakref.WeakValueDictionary[int, BackboneRunner]" = weakref.WeakValueDictionary()
+_HANDLES = itertools.count(1)
+_TOKENS = itertools.count(1)
+_TORCH_OUT_DTYPE = {N.VT_F32: torch.float32, N.VT_BF16: torch.bfloat16}
 
-    @staticmethod
-    def backward(ctx, *gouts):
-        if ctx.st.prog.n_bwd == 0:
-            raise RuntimeError("this forward was compiled without a backward list (traced / no-grad call)")
-        dx, pgrads = ctx.runner._run_backward(ctx.st, gouts, ctx.x_requires_grad)
-        ctx.st = None
-        return (None, None, dx, *pgrads[: ctx.n_params])
+
+def _runner(handle: int) -> "BackboneRunner":
+    r = _RUNNERS.get(handle)
+    if r is None:
+        raise RuntimeError("vision_toolbox_amd::backbone: the backbone this graph was traced with no longer exists")
+    return r
+
+
+# (defined through torch.library.define / impl rather than the custom_op decorator: the feature maps are views of
+#  ONE arena allocation, which the decorator's output-aliasing check rejects; they never alias an input)
+torch.library.define("vision_toolbox_amd::backbone",
+                     "(Tensor x, Tensor[] params, int handle, bool all_maps, int dtype, bool need_grad) -> Tensor[]")
+
+
+@torch.library.impl("vision_toolbox_amd::backbone", "CUDA")
+def _backbone_cuda(x: torch.Tensor, params: list[torch.Tensor], handle: int, all_maps: bool, dtype: int,
+                   need_grad: bool) -> list[torch.Tensor]:
+    """feature maps (logical NCHW, channels_last strides) of backbone `handle` for images x; `params` are the
+    module's parameters in flat-store order (read from the store; listed so that autograd routes gradients)."""
+    runner = _runner(handle)
+    with tracing_paused():
+        prog = runner.program(x, dtype, all_maps, need_grad)
+        st, outs = runner._run_forward(prog, x)
+    token = next(_TOKENS)
+    if need_grad:
+        runner._pending[token] = st
+        while len(runner._pending) > 4:  # forwards whose graph was never built: do not hoard their arenas
+            runner._pending.pop(next(iter(runner._pending)))
+    return list(outs) + [torch.tensor([token], dtype=torch.int64)]
+
+
+@torch.library.register_fake("vision_toolbox_amd::backbone")
+def _backbone_fake(x, params, handle, all_maps, dtype, need_grad):
+    runner = _runner(handle)
+    prog = runner.program(x, dtype, all_maps, need_grad)
+    td = _TORCH_OUT_DTYPE[dtype]
+    outs = [torch.empty_strided((t.B, t.C, t.H, t.W), (t.H * t.W * t.ld, 1, t.W * t.ld, t.ld), dtype=td, device=x.device)
+            for t in prog.outs]
+    return outs + [torch.empty(1, dtype=torch.int64, device="cpu")]
+
+
+def _backbone_setup(ctx, inputs, output):
+    x, params, handle, all_maps, dtype, need_grad = inputs
+    ctx.handle, ctx.n_params, ctx.x_requires_grad = handle, len(params), x.requires_grad
+    ctx.st = _runner(handle)._pending.pop(int(output[-1]), None) if need_grad else None
+
+
+def _backbone_backward(ctx, gouts):
+    st = ctx.st
+    if st is None or st.prog.n_bwd == 0:
+        raise RuntimeError("this forward was compiled without a backward list (traced / no-grad call)")
+    dx, pgrads = _runner(ctx.handle)._run_backward(st, gouts[:-1], ctx.x_requires_grad)
+    ctx.st = None
+    return dx, list(pgrads[: ctx.n_params]), None, None, None, None
+
+
+torch.library.register_autograd("vision_toolbox_amd::backbone", _backbone_backward, setup_context=_backbone_setup)
+backbone_op = torch.ops.vision_toolbox_amd.backbone
 
 
 class BackboneRunner:
@@ -141,6 +200,9 @@ class BackboneRunner:
         self.module = module
         self.store = E.ParamStore(module)
         self.cache: dict = {}
+        self.handle = next(_HANDLES)
+        self._pending: dict = {}  # token -> run state of a forward whose autograd context has not been set up yet
+        _RUNNERS[self.handle] = self
 
     # -- compile ------------------------------------------------------------------
     def program(self, x: torch.Tensor, dtype: int, all_maps: bool, need_grad: bool) -> Program:
@@ -182,16 +244,13 @@ class BackboneRunner:
             self.store.ensure(x.device)
             params = self.store.params
             need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
-            prog = self.program(x, dtype, all_maps, need_grad)
-        if tracing:
-            # recorded as ONE opaque op of x; the parameters are read from the module's flat
-            # store at run time, so the tracer never has to resolve them
-            outs = BackboneFn.apply(self, prog, x)
-        elif need_grad:
-            outs = BackboneFn.apply(self, prog, x, *params)
+        if tracing or not need_grad:
+            # the parameters are read from the module's flat store at run time: a traced / exported graph holds
+            # ONE operator node of x and never has to resolve 200 parameter tensors
+            outs = backbone_op(x, [], self.handle, all_maps, dtype, False)
         else:
-            _, outs = self._run_forward(prog, x)
-        return list(outs)
+            outs = backbone_op(x, list(params), self.handle, all_maps, dtype, True)
+        return list(outs[:-1])
 
     def _run_forward(self, prog: Program, x: torch.Tensor):
         dev = x.device
