@@ -303,6 +303,15 @@ int vt_run_ops(const vt_op* ops, int32_t n, void* const* bases, int32_t nbases, 
  * side == NULL or side == stream runs everything in line. */
 int vt_run_ops_streams(const vt_op* ops, int32_t n, void* const* bases, int32_t nbases, void* stream,
                        void* side);
+/* same, for a list that is run in SEGMENTS (the data-parallel trainer issues a gradient bucket's collective between
+ * two segments, reference configs/base.yaml:17-19 = DDP's per-bucket hooks): with VT_RUN_LEAVE_SIDE_OPEN the call
+ * does not order `stream` behind the side stream on return -- the caller joins them itself (a later segment's JOIN
+ * op, or vt_stream_wait) -- so cutting a list does not serialise the filter-gradient stream. */
+#define VT_RUN_LEAVE_SIDE_OPEN 1
+int vt_run_ops_streams_ex(const vt_op* ops, int32_t n, void* const* bases, int32_t nbases, void* stream,
+                          void* side, int32_t flags);
+/* order `waiter` behind everything enqueued on `signaller` so far (a pooled event; no host synchronisation) */
+int vt_stream_wait(void* waiter, void* signaller);
 
 /* hipGraph capture of an op list (side-stream ops become parallel graph branches): capture
  * once, replay with one launch. */

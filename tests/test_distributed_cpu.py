@@ -85,9 +85,22 @@ def _worker(rank, world, port, q):
         ok_bcast = torch.equal(ref, ts.store.pflat)
         # averaging is folded into SGD: grad_scale = 1 / world
         ok_scale = abs(ts.opt_ops[0].f[4] - 1.0 / world) < 1e-12
-        q.put((rank, ok_sum, ok_plan, ok_order, ok_bcast, ok_scale))
+        q.put((rank, ok_sum, ok_plan, ok_order, ok_bcast, ok_scale, _launch_list_digest(ts)))
     finally:
         dist.destroy_process_group()
+
+
+def _launch_list_digest(ts):
+    """digest of the forward and backward launch lists (every op: kind, operands, integer / float arguments)"""
+    import ctypes
+    import hashlib
+
+    from vision_toolbox import _native as N
+
+    h = hashlib.sha256()
+    for ops, n in ((ts.prog.fwd_ops, ts.prog.n_fwd), (ts.prog.bwd_ops, ts.prog.n_bwd)):
+        h.update(ctypes.string_at(ctypes.addressof(ops), n * ctypes.sizeof(N.Op)))
+    return h.hexdigest()
 
 
 def test_two_rank_gloo_bucketed_allreduce_and_train_plan():
@@ -104,6 +117,14 @@ def test_two_rank_gloo_bucketed_allreduce_and_train_plan():
     assert sorted(r[0] for r in results) == [0, 1]
     for r in results:
         assert all(r[1:]), r
+    # a rank of the data-parallel job runs EXACTLY the single-GPU launch lists -- the collectives
+    # are issued between segments of the same list (and from the filter-gradient stream), nothing is re-planned
+    from vision_toolbox import backbones
+    from vision_toolbox.trainer import TrainStep
+
+    solo = TrainStep(backbones.darknet_yolov5n(), 16, 2, 64, torch.bfloat16, device="cpu", plan_only=True, bucket_mb=0.5)
+    assert solo.world == 1 and solo.bucketer is None
+    assert {r[6] for r in results} == {_launch_list_digest(solo)}
 
 
 def test_bench_launches_its_own_ranks_from_one_command():

@@ -172,8 +172,9 @@ def test_lr_schedule_follows_device_scalar():
     assert not torch.equal(w0, ts.store.pflat)
 
 
-@pytest.mark.parametrize("sync_bn", ["0", "1"], ids=["ddp", "ddp_syncbn"])
-def test_two_ranks_on_one_gpu_match_ddp_semantics(sync_bn):
+@pytest.mark.parametrize("sync_bn,model", [("0", "vovnet19_slim_ese"), ("1", "vovnet19_slim_ese"), ("0", "cspdarknet53")],
+                         ids=["ddp", "ddp_syncbn", "ddp_cspdarknet53"])
+def test_two_ranks_on_one_gpu_match_ddp_semantics(sync_bn, model):
     """bench.py --gpus N path minus RCCL itself: two ranks share this GPU and exchange the gradient
     buckets over gloo (tools/ddp_check.py); updates must equal the oracle's DDP replay and the ranks
     must stay bit-identical.  sync_bn=1: SyncBatchNorm mode against one process on the joint batch."""
@@ -189,7 +190,8 @@ def test_two_ranks_on_one_gpu_match_ddp_semantics(sync_bn):
         port = sk.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), str(root / "tools" / "ddp_check.py")],
-                       capture_output=True, text=True, timeout=900, env=dict(os.environ, DDP_CHECK_SYNCBN=sync_bn))
+                       capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, DDP_CHECK_SYNCBN=sync_bn, DDP_CHECK_MODEL=model))
     assert r.returncode == 0 and "DDP_CHECK_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     buf = torch.zeros(16, device="cuda")  # the launch-count guard of this module wants a launch here too
     N.check(N.lib().vt_memset(buf.data_ptr(), 0, 64, int(torch.cuda.current_stream().cuda_stream)))

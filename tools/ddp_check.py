@@ -31,7 +31,12 @@ from vision_toolbox.trainer import TrainStep
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    name, ncls, B, S, steps, lr, wd = "vovnet19_slim_ese", 16, 4, 64, 2, 2e-3, 1e-3
+    # DDP_CHECK_MODEL=cspdarknet53: BASELINE configs[2]'s model (53 train-mode BatchNorm layers at 8 x 96 px per rank are
+    # ill-conditioned in f32 -- tests/test_trainer_gpu.py -- so its update bound is wider; the ranks must still end
+    # bit-identical, which is what the bucket / segment / stream plumbing can break)
+    name = os.environ.get("DDP_CHECK_MODEL", "vovnet19_slim_ese")
+    deep = name == "cspdarknet53"
+    ncls, B, S, steps, lr, wd = (16, 8, 96, 2, 2e-4, 1e-3) if deep else (16, 4, 64, 2, 2e-3, 1e-3)
     sync_bn = os.environ.get("DDP_CHECK_SYNCBN", "0") == "1"
     torch.cuda.set_device(0)
     xs = [filler.images(B, S, seed=1000 + r) for r in range(world)]
@@ -39,7 +44,7 @@ def main():
 
     torch.manual_seed(rank)  # ranks start from DIFFERENT weights; the broadcast must fix that
     ts = TrainStep(getattr(backbones, name)(), ncls, B, S, torch.float32, lr=lr, momentum=0.9, weight_decay=wd,
-                   label_smoothing=0.1, device="cuda:0", bucket_mb=0.25, use_graphs=False, sync_bn=sync_bn)
+                   label_smoothing=0.1, device="cuda:0", bucket_mb=8.0 if deep else 0.25, use_graphs=False, sync_bn=sync_bn)
     if rank == 0:
         filler.fill_module(ts.model, "ddp.")
         ts.weights_changed()
@@ -87,11 +92,13 @@ def main():
                        lambda k: R.weight_decay_group(k, wd, 0.0, 0.0))
         got = ts.model.state_dict()
         worst = 0.0
-        for k in ("0.stem.0.conv.weight", "0.stages.3.module_0.out_conv.conv.weight", "3.weight", "3.bias"):
+        keys = ("0.stages.4.out_conv.conv.weight", "3.weight", "3.bias") if deep else \
+            ("0.stem.0.conv.weight", "0.stages.3.module_0.out_conv.conv.weight", "3.weight", "3.bias")
+        for k in keys:
             d_got, d_ref = got[k].cpu() - init[k], sd[k].detach() - init[k]
             err = ((d_got - d_ref).norm() / d_ref.norm()).item()
             worst = max(worst, err)
-            assert d_ref.norm() > 0 and err < 0.1, (k, err)
+            assert d_ref.norm() > 0 and err < (0.25 if deep else 0.1), (k, err)
         if sync_bn:
             rv = [k for k in got if k.endswith("running_var")]
             for k in (rv[0], rv[-1]):

@@ -187,14 +187,35 @@ int vt_run_ops(const vt_op* ops, int32_t n, void* const* bases, int32_t nbases, 
     return vt_run_ops_streams(ops, n, bases, nbases, stream, nullptr);
 }
 
-// order stream `waiter` behind everything enqueued on `signaller` so far
-static int stream_wait(hipStream_t waiter, hipStream_t signaller, std::vector<hipEvent_t>& bag) {
-    hipEvent_t ev;
-    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-    if (e == hipSuccess) {
-        bag.push_back(ev);  // released by the caller once the whole list is enqueued / captured
-        e = hipEventRecord(ev, signaller);
+// order stream `waiter` behind everything enqueued on `signaller` so far.  Eager execution takes the event from a
+// per-thread ring (a wait captures the record it was issued against, so an event may be re-recorded while an earlier
+// wait on it is still pending; 140 create/destroy pairs per step were measurable); stream capture gets fresh events,
+// released by the caller once the capture has ended (`bag`).
+static int stream_wait(hipStream_t waiter, hipStream_t signaller, std::vector<hipEvent_t>* bag) {
+    hipEvent_t ev = nullptr;
+    hipError_t e = hipSuccess;
+    if (bag) {
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e == hipSuccess) bag->push_back(ev);
+    } else {
+        constexpr int kRing = 64;
+        static thread_local hipEvent_t ring[kRing] = {};
+        static thread_local int ring_dev[kRing];
+        static thread_local unsigned next = 0;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned k = next++ % kRing;
+        if (ring[k] != nullptr && ring_dev[k] != dev) {
+            (void)hipEventDestroy(ring[k]);
+            ring[k] = nullptr;
+        }
+        if (ring[k] == nullptr) {
+            e = hipEventCreateWithFlags(&ring[k], hipEventDisableTiming);
+            ring_dev[k] = dev;
+        }
+        ev = ring[k];
     }
+    if (e == hipSuccess) e = hipEventRecord(ev, signaller);
     if (e == hipSuccess) e = hipStreamWaitEvent(waiter, ev, 0);
     if (e != hipSuccess) {
         vt_set_error("stream fork/join: %s", hipGetErrorString(e));
@@ -204,7 +225,7 @@ static int stream_wait(hipStream_t waiter, hipStream_t signaller, std::vector<hi
 }
 
 static int run_ops_impl(const vt_op* ops, int32_t n, void* const* bases, int32_t nbases, void* stream,
-                        void* side, std::vector<hipEvent_t>& bag) {
+                        void* side, std::vector<hipEvent_t>* bag, int32_t flags) {
     VT_REQUIRE(ops && n >= 0 && nbases >= 0 && nbases <= VT_MAX_BASES && (bases || nbases == 0),
                VT_ERR_INVALID, "vt_run_ops: bad argument");
     const bool two = side != nullptr && side != stream;
@@ -217,7 +238,8 @@ static int run_ops_impl(const vt_op* ops, int32_t n, void* const* bases, int32_t
         if (op.kind == VT_OP_FORK) {
             if (two) rc = stream_wait((hipStream_t)side, (hipStream_t)stream, bag);
         } else if (op.kind == VT_OP_JOIN) {
-            if (two && side_dirty) rc = stream_wait((hipStream_t)stream, (hipStream_t)side, bag);
+            // (unconditional: an earlier SEGMENT of the same list may have left side work open, VT_RUN_LEAVE_SIDE_OPEN)
+            if (two) rc = stream_wait((hipStream_t)stream, (hipStream_t)side, bag);
             side_dirty = false;
         } else {
             rc = run_one(op, bases, nbases, (two && on_side) ? side : stream);
@@ -230,17 +252,24 @@ static int run_ops_impl(const vt_op* ops, int32_t n, void* const* bases, int32_t
             return rc;
         }
     }
-    // never return with unjoined side work: the caller only knows about `stream`
-    if (two && side_dirty) return stream_wait((hipStream_t)stream, (hipStream_t)side, bag);
+    // never return with unjoined side work (the caller only knows about `stream`) unless it asked to keep it open
+    if (two && side_dirty && !(flags & VT_RUN_LEAVE_SIDE_OPEN)) return stream_wait((hipStream_t)stream, (hipStream_t)side, bag);
     return VT_OK;
 }
 
 int vt_run_ops_streams(const vt_op* ops, int32_t n, void* const* bases, int32_t nbases, void* stream,
                        void* side) {
-    std::vector<hipEvent_t> bag;
-    const int rc = run_ops_impl(ops, n, bases, nbases, stream, side, bag);
-    for (hipEvent_t ev : bag) (void)hipEventDestroy(ev);  // the runtime defers the release to completion
-    return rc;
+    return run_ops_impl(ops, n, bases, nbases, stream, side, nullptr, 0);
+}
+
+int vt_run_ops_streams_ex(const vt_op* ops, int32_t n, void* const* bases, int32_t nbases, void* stream,
+                          void* side, int32_t flags) {
+    return run_ops_impl(ops, n, bases, nbases, stream, side, nullptr, flags);
+}
+
+int vt_stream_wait(void* waiter, void* signaller) {
+    VT_REQUIRE(waiter != signaller, VT_ERR_INVALID, "vt_stream_wait: a stream cannot wait for itself");
+    return stream_wait((hipStream_t)waiter, (hipStream_t)signaller, nullptr);
 }
 
 int vt_graph_create(const vt_op* ops, int32_t n, void* const* bases, int32_t nbases, void** graph_out) {
@@ -264,7 +293,7 @@ int vt_graph_create(const vt_op* ops, int32_t n, void* const* bases, int32_t nba
         return VT_ERR_HIP;
     }
     std::vector<hipEvent_t> bag;
-    const int rc = run_ops_impl(ops, n, bases, nbases, cs, ss, bag);
+    const int rc = run_ops_impl(ops, n, bases, nbases, cs, ss, &bag, 0);
     hipGraph_t g = nullptr;
     e = hipStreamEndCapture(cs, &g);
     for (hipEvent_t ev : bag) (void)hipEventDestroy(ev);  // only after the capture has ended

@@ -154,6 +154,8 @@ SYMBOLS = {
     "vt_nhwc_to_nchw": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vt_run_ops": (_i32, [C.POINTER(Op), _i32, C.POINTER(_vp), _i32, _vp]),
     "vt_run_ops_streams": (_i32, [C.POINTER(Op), _i32, C.POINTER(_vp), _i32, _vp, _vp]),
+    "vt_run_ops_streams_ex": (_i32, [C.POINTER(Op), _i32, C.POINTER(_vp), _i32, _vp, _vp, _i32]),
+    "vt_stream_wait": (_i32, [_vp, _vp]),
     "vt_graph_create": (_i32, [C.POINTER(Op), _i32, C.POINTER(_vp), _i32, C.POINTER(_vp)]),
     "vt_graph_launch": (_i32, [_vp, _vp]),
     "vt_graph_destroy": (_i32, [_vp]),
@@ -208,11 +210,21 @@ def launch_count() -> int:
     return int(lib().vt_launch_count())
 
 
-def run_ops(ops, n: int, bases, stream: int, side: int = 0) -> None:
+VT_RUN_LEAVE_SIDE_OPEN = 1
+
+
+def run_ops(ops, n: int, bases, stream: int, side: int = 0, leave_side_open: bool = False) -> None:
     """ops: (Op * n) array; bases: list of device addresses (ints or None); `side` is the
-    stream handle for ops flagged OP_SIDE_STREAM (0: run them in line)."""
+    stream handle for ops flagged OP_SIDE_STREAM (0: run them in line).  `leave_side_open`: do not
+    order `stream` behind the side stream on return (a list run in segments; the caller joins later)."""
     arr = (C.c_void_p * len(bases))(*[C.c_void_p(b) if b else None for b in bases])
-    check(lib().vt_run_ops_streams(ops, n, arr, len(bases), C.c_void_p(stream), C.c_void_p(side) if side else None))
+    check(lib().vt_run_ops_streams_ex(ops, n, arr, len(bases), C.c_void_p(stream), C.c_void_p(side) if side else None,
+                                      VT_RUN_LEAVE_SIDE_OPEN if (leave_side_open and side) else 0))
+
+
+def stream_wait(waiter: int, signaller: int) -> None:
+    """order stream `waiter` behind everything enqueued on `signaller` so far (no host synchronisation)."""
+    check(lib().vt_stream_wait(C.c_void_p(waiter), C.c_void_p(signaller)))
 
 
 class Graph:

@@ -264,19 +264,31 @@ class TrainStep:
 
     def _run_list(self, ops, n, sync, cuts, cut_buckets, s, side):
         """run a launch list in segments: a segment ends before every finalize kernel whose statistics
-        must be all-reduced first (SyncBatchNorm) and after every op that completes a gradient bucket."""
+        must be all-reduced first (SyncBatchNorm) and after every op that completes a gradient bucket.
+
+        Cutting the list must not cost the N = 1 schedule: an intermediate segment leaves the filter-gradient
+        (side) stream open instead of joining it, and a bucket's collective is issued with the SIDE stream current,
+        after ordering that stream behind the main stream's position (BatchNorm / bias gradients are written
+        there).  RCCL's stream then waits for exactly the producers of the bucket, the main stream for nothing;
+        the list's own JOIN op (last segment) and `bucketer.finish()` close both before the optimiser."""
         marks = {idx: ("sync", (base, off, nb)) for idx, base, off, nb in sync}
         ends = sorted(set(marks) | set(cuts) | {n})
         lo = 0
         for hi in ends:
             if hi > lo:
                 sub = (N.Op * (hi - lo)).from_address(ctypes.addressof(ops) + lo * ctypes.sizeof(N.Op))
-                N.run_ops(sub, hi - lo, self.bases, s, side=side)
+                N.run_ops(sub, hi - lo, self.bases, s, side=side, leave_side_open=hi != n)
             if hi in marks:  # stream-ordered: NCCL makes the launch stream wait, no host sync
                 torch.distributed.all_reduce(self._sync_view(*marks[hi][1]), group=self.pg)
-            if hi in cut_buckets:
-                for bi in cut_buckets[hi]:
-                    self.bucketer.reduce_bucket(bi)
+            if hi in cut_buckets and cut_buckets[hi]:
+                if side and self._side is not None:
+                    N.stream_wait(side, s)
+                    with torch.cuda.stream(self._side):
+                        for bi in cut_buckets[hi]:
+                            self.bucketer.reduce_bucket(bi)
+                else:
+                    for bi in cut_buckets[hi]:
+                        self.bucketer.reduce_bucket(bi)
             lo = hi
 
     def _dev_ctx(self):
@@ -288,8 +300,12 @@ class TrainStep:
     def broadcast_parameters(self, src: int = 0) -> None:
         """initial weights + buffers from rank `src` (what DDP's constructor does)."""
         if self.world > 1:
+            # parameters, BatchNorm buffers (running statistics AND the int64 batch counters) and the optimiser's
+            # momentum: a resumed run starts identical on every rank
             torch.distributed.broadcast(self.store.pflat, src, group=self.pg)
             torch.distributed.broadcast(self.store.sflat, src, group=self.pg)
+            torch.distributed.broadcast(self.store.nflat, src, group=self.pg)
+            torch.distributed.broadcast(self.mflat, src, group=self.pg)
             if self.dtype == N.VT_BF16:
                 self.store.mirror.copy_(self.store.pflat)
 
