@@ -437,7 +437,8 @@ def main():
                          "flops": layers[0]["flops"], "shape": layers[0]["shape"]}
         traffic = None
         if world == 1 and not args.no_pmc:
-            traffic = pmc_traffic_live("128,128,3,1,28", "span_kernel")
+            # (the rocprof rows are matched by the name the dispatcher reported for this layer, e.g. "span6_kernel")
+            traffic = pmc_traffic_live("128,128,3,1,28", (standalone_name or dom["kernel"]).split("<")[0])
         # HBM-bound layers of stages 0-2 (HBM fraction on the 1x1 and early-stage convs)
         hbm_layers = [conv_roofline(args.batch, 64, 112, N.VT_BF16, k=1), conv_roofline(args.batch, 128, 56, N.VT_BF16, k=1),
                       conv_roofline(args.batch, 8, 224, N.VT_BF16, k=3, Cout=32)]

@@ -256,6 +256,20 @@ def test_softmax_cross_entropy_label_smoothing(dtype):
     assert rel_err(dl.float().cpu(), logits.grad) < tol(dtype, 1e-5)
 
 
+def test_softmax_cross_entropy_out_of_range_label_poisons_the_loss():
+    """torch raises on a label outside [0, N); the kernel cannot, so it must neither read out of bounds
+    nor train silently: the loss becomes NaN, the gradients of the valid samples stay finite."""
+    B, Ncls = 4, 10
+    ld = filler.tensor("xo", (B, Ncls)).cuda()
+    loss = torch.zeros(1, device="cuda")
+    dl = torch.empty_like(ld)
+    yd = torch.tensor([1, 12345678, 3, -5], dtype=torch.int64, device="cuda")
+    N.check(N.lib().vt_softmax_xent(vp(ld), Ncls, vp(yd), 0.1, 1.0 / B, vp(loss), vp(dl), Ncls, B, Ncls,
+                                    N.VT_F32, stream()))
+    assert torch.isnan(loss).all()
+    assert torch.isfinite(dl).all()
+
+
 def test_sgd_momentum_matches_torch_optim():
     n = 100_003
     p0, g = filler.tensor("sp", (n,)), filler.tensor("sg", (n,))

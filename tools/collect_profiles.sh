@@ -34,7 +34,7 @@ out, tag = sys.argv[1], sys.argv[2]
 SHAPES = [("conv3x3 s1 128->128 @28x28 B=256", 200704, 128, 1152), ("conv3x3 s1 256->256 @14x14 B=256", 50176, 256, 2304),
           ("conv3x3 s1 512->512 @7x7 B=256", 12544, 512, 4608)]
 def conv_rows(path):
-    rows = [r for r in csv.DictReader(open(path)) if "span_kernel" in r["Kernel_Name"] or "igemm_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path)) if "span_kernel" in r["Kernel_Name"] or "span6_kernel" in r["Kernel_Name"] or "igemm_kernel" in r["Kernel_Name"]]
     return rows
 def per_shape(d, counter=None):
     """{shape index: [values]} for a counter (or durations in us when counter is None)"""

@@ -732,8 +732,11 @@ xent_kernel(const T* __restrict__ logits, int ldl, const int64_t* __restrict__ l
     const bool mixed = mix && mix[0] != 0.f;
     const float lam = mixed ? mix[1] : 1.f;
     const int64_t yp = mixed ? labels[(b + B - 1) % B] : yb;
+    // a label outside [0, N) (torch raises there; a kernel cannot): no out-of-bounds read, and the loss becomes NaN
+    // so that the bad batch is noticed instead of silently training on garbage
+    const bool bad = yb < 0 || yb >= (int64_t)N || yp < 0 || yp >= (int64_t)N;
     if (t == 0) {
-        const float zy = lam * ldf(lp + yb) + (1.f - lam) * ldf(lp + yp);
+        const float zy = bad ? __builtin_nanf("") : lam * ldf(lp + yb) + (1.f - lam) * ldf(lp + yp);
         const float l = lse - (1.f - eps) * zy - (eps / (float)N) * tsz;
         atomicAdd(loss, l / (float)B);
     }

@@ -143,6 +143,18 @@ struct L6 {
     __host__ __device__ static constexpr int bytes(int npc) { return kA + 4 * npc * 1024; }
 };
 
+// sum of a value over the 16 lanes of its DPP row (lanes 16k .. 16k+15), returned in every lane of the row
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_sum16(float x) {
+    x = dpp_add<0x128>(x);  // row_ror:8
+    x = dpp_add<0x124>(x);  // row_ror:4
+    x = dpp_add<0x122>(x);  // row_ror:2
+    return dpp_add<0x121>(x);  // row_ror:1
+}
+
 template <int T>
 using I_ = std::integral_constant<int, T>;
 
@@ -644,16 +656,12 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                     }
                 }
                 if (stats) {
-                    // sum over the 16 pixel lanes (same q4): butterfly, then lanes c16 = 0..7 keep channel e = c16
+                    // sum over the 16 pixel lanes (same q4 = one DPP row): four row rotations on the vector ALU (no LDS
+                    // crossbar round trips), then lanes c16 = 0..7 keep channel e = c16
                     float u = 0.f, v = 0.f;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        float x1 = s1[e], x2 = s2[e];
-#pragma unroll
-                        for (int o = 1; o < 16; o <<= 1) {
-                            x1 += __shfl_xor(x1, o, 64);
-                            x2 += __shfl_xor(x2, o, 64);
-                        }
+                        const float x1 = row_sum16(s1[e]), x2 = row_sum16(s2[e]);
                         u = c16 == e ? x1 : u;
                         v = c16 == e ? x2 : v;
                     }
