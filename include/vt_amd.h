@@ -274,6 +274,9 @@ enum vt_op_kind {
     VT_OP_JOIN, /* main stream waits for everything enqueued on the side stream so far */
     VT_OP_RESAMPLE_FWD,
     VT_OP_RESAMPLE_BWD,
+    VT_OP_FORK_MARK, /* remember the main stream's position (an event record), nothing waits yet */
+    VT_OP_FORK_WAIT, /* side stream waits for the last FORK_MARK: FORK split in two, so that the host can enqueue main-stream
+                        work between the mark and the side-stream ops that depend on it */
     VT_OP_KIND_END
 };
 

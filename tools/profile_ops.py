@@ -43,7 +43,7 @@ def main():
         for idx in range(n):
             op = ops[idx]
             kind = op.kind & 0xFFFF
-            if kind in (N.OP_FORK, N.OP_JOIN):
+            if kind in (N.OP_FORK, N.OP_JOIN, N.OP_FORK_MARK, N.OP_FORK_WAIT):
                 continue
             one = (N.Op * 1).from_address(ctypes.addressof(ops) + idx * ctypes.sizeof(N.Op))
             N.run_ops(one, 1, ts.bases, s)

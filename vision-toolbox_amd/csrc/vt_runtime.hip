@@ -187,11 +187,10 @@ int vt_run_ops(const vt_op* ops, int32_t n, void* const* bases, int32_t nbases, 
     return vt_run_ops_streams(ops, n, bases, nbases, stream, nullptr);
 }
 
-// order stream `waiter` behind everything enqueued on `signaller` so far.  Eager execution takes the event from a
-// per-thread ring (a wait captures the record it was issued against, so an event may be re-recorded while an earlier
-// wait on it is still pending; 140 create/destroy pairs per step were measurable); stream capture gets fresh events,
-// released by the caller once the capture has ended (`bag`).
-static int stream_wait(hipStream_t waiter, hipStream_t signaller, std::vector<hipEvent_t>* bag) {
+// Events: eager execution takes them from a per-thread ring (a wait captures the record it was issued against, so an
+// event may be re-recorded while an earlier wait on it is still pending; 140 create/destroy pairs per step were
+// measurable); stream capture gets fresh events, released by the caller once the capture has ended (`bag`).
+static hipEvent_t take_event(std::vector<hipEvent_t>* bag, hipError_t* err) {
     hipEvent_t ev = nullptr;
     hipError_t e = hipSuccess;
     if (bag) {
@@ -215,6 +214,14 @@ static int stream_wait(hipStream_t waiter, hipStream_t signaller, std::vector<hi
         }
         ev = ring[k];
     }
+    *err = e;
+    return ev;
+}
+
+// order stream `waiter` behind everything enqueued on `signaller` so far
+static int stream_wait(hipStream_t waiter, hipStream_t signaller, std::vector<hipEvent_t>* bag) {
+    hipError_t e;
+    hipEvent_t ev = take_event(bag, &e);
     if (e == hipSuccess) e = hipEventRecord(ev, signaller);
     if (e == hipSuccess) e = hipStreamWaitEvent(waiter, ev, 0);
     if (e != hipSuccess) {
@@ -230,6 +237,11 @@ static int run_ops_impl(const vt_op* ops, int32_t n, void* const* bases, int32_t
                VT_ERR_INVALID, "vt_run_ops: bad argument");
     const bool two = side != nullptr && side != stream;
     bool side_dirty = false;  // side stream has work the main stream has not been ordered behind
+    // last FORK_MARK: per thread in eager execution, so that a list run in segments may be cut between a mark and its
+    // wait; per call while capturing (the events of a capture die with it)
+    static thread_local hipEvent_t eager_mark = nullptr;
+    hipEvent_t capture_mark = nullptr;
+    hipEvent_t& mark = bag ? capture_mark : eager_mark;
     for (int i = 0; i < n; ++i) {
         vt_op op = ops[i];
         const bool on_side = (op.kind & VT_OP_SIDE_STREAM) != 0;
@@ -237,6 +249,26 @@ static int run_ops_impl(const vt_op* ops, int32_t n, void* const* bases, int32_t
         int rc = VT_OK;
         if (op.kind == VT_OP_FORK) {
             if (two) rc = stream_wait((hipStream_t)side, (hipStream_t)stream, bag);
+        } else if (op.kind == VT_OP_FORK_MARK) {
+            if (two) {
+                hipError_t e;
+                mark = take_event(bag, &e);
+                if (e == hipSuccess) e = hipEventRecord(mark, (hipStream_t)stream);
+                if (e != hipSuccess) {
+                    vt_set_error("fork mark: %s", hipGetErrorString(e));
+                    rc = VT_ERR_HIP;
+                }
+            }
+        } else if (op.kind == VT_OP_FORK_WAIT) {
+            if (two) {
+                if (mark == nullptr) {
+                    vt_set_error("fork wait without a preceding mark");
+                    rc = VT_ERR_INVALID;
+                } else if (hipStreamWaitEvent((hipStream_t)side, mark, 0) != hipSuccess) {
+                    vt_set_error("fork wait failed");
+                    rc = VT_ERR_HIP;
+                }
+            }
         } else if (op.kind == VT_OP_JOIN) {
             // (unconditional: an earlier SEGMENT of the same list may have left side work open, VT_RUN_LEAVE_SIDE_OPEN)
             if (two) rc = stream_wait((hipStream_t)stream, (hipStream_t)side, bag);

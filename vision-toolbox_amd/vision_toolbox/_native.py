@@ -48,7 +48,9 @@ VT_OP_MAX_PTR, VT_OP_MAX_INT, VT_OP_MAX_FLT, VT_MAX_BASES = 12, 110, 8, 16
     OP_JOIN,
     OP_RESAMPLE_FWD,
     OP_RESAMPLE_BWD,
-) = range(1, 27)
+    OP_FORK_MARK,
+    OP_FORK_WAIT,
+) = range(1, 29)
 OP_SIDE_STREAM = 0x10000  # OR-ed into Op.kind: enqueue on the side stream
 
 OP_NAMES = {
@@ -76,6 +78,8 @@ OP_NAMES = {
     OP_NHWC_TO_NCHW: "nhwc_to_nchw",
     OP_FORK: "fork",
     OP_JOIN: "join",
+    OP_FORK_MARK: "fork_mark",
+    OP_FORK_WAIT: "fork_wait",
     OP_RESAMPLE_FWD: "resample_fwd",
     OP_RESAMPLE_BWD: "resample_bwd",
 }

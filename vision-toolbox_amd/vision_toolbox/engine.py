@@ -238,6 +238,10 @@ class Builder:
         self.hoist_dgrad_packs = False
         # release each filter gradient to the side stream after (True) or before (False) the unit's data gradient
         self.wgrad_late = os.environ.get("VT_WGRAD_LATE", "0") != "0"
+        # FORK split into MARK (before the data gradient) and WAIT (before the filter gradient): measured equal to the
+        # plain FORK (24.65 vs 24.66 ms: the 7 us per unit on the main stream are the event record itself, not the
+        # host's issue order), so off
+        self.fork_split = os.environ.get("VT_FORK_SPLIT", "0") != "0"
         self._hoisted: list[N.Op] = []
         # SyncBatchNorm (configs/base.yaml:22): the trainer all-reduces every layer's statistics
         # between the kernel that accumulates them and the finalize kernel; the finalize kernels
@@ -604,11 +608,11 @@ class Builder:
                 # side stream.  It is released AFTER this unit's data gradient (wgrad_late): both are MFMA-bound
                 # and only slow each other down, whereas the HBM-bound BatchNorm passes of the next unit in
                 # backward order leave the matrix pipes to it.
-                def emit_wgrad():
+                def emit_wgrad(wait_only=False):
                     if not w.requires_grad:
                         return
                     dfwd = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, dz.ld, ldw, 0)
-                    self.emit(N.OP_FORK)
+                    self.emit(N.OP_FORK_WAIT if wait_only else N.OP_FORK)
                     if padded:
                         ws = self.zeroed_f32(Cout * ntaps * x.C, "dwpad", bwd=True)
                         self.emit(N.OP_CONV_WGRAD, [x.addr(), dz.addr(), self.bp(ws)], desc=dfwd, extra_ints=[ldw],
@@ -619,13 +623,21 @@ class Builder:
                         self.emit(N.OP_CONV_WGRAD, [x.addr(), dz.addr(), self.pgrad(w)], desc=dfwd,
                                   extra_ints=[ldw], side=True)
 
-                if not self.wgrad_late:
+                # Host issue order: [mark the main stream's position: dz is complete] [data gradient, main stream]
+                # [side stream waits for the MARK] [filter gradient].  The filter gradient still depends on dz only,
+                # but the main stream does not sit idle while the host enqueues it (7 us x 66 units in the trace).
+                split = self.fork_split and w.requires_grad and x.needs_grad and not self.wgrad_late
+                if split:
+                    self.emit(N.OP_FORK_MARK)
+                elif not self.wgrad_late:
                     emit_wgrad()
                 # data gradient
                 if x.needs_grad:
                     self._dgrad(x, dz, wptr if not padded else self.bp(wpack), dt if (padded or dt != N.VT_F32) else N.VT_F32,
                                 ldw, Cout, k, s, pad, Ho, Wo)
-                if self.wgrad_late:
+                if split:
+                    emit_wgrad(wait_only=True)
+                elif self.wgrad_late:
                     emit_wgrad()
 
             self.nodes.append(bwd)
