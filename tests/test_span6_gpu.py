@@ -1,0 +1,101 @@
+"""vt_igemm_span6.hip (the two-group + loader-wave kernel of the MFMA-bound 3x3 stride-1 layers: ConvNormAct
+`components.py:26-35` inside DarknetBlock / CSP / OSA stages, forward and stride-1 data gradient) against
+the kernel the dispatcher would otherwise take, on identical operands.  Against vt_igemm_span.hip the comparison is
+BIT-EXACT (same products, same order); where the alternative is the general kernel (few output pixels) the two
+differ by summation order only and are compared at one bf16 rounding.  Those kernels are pinned to the float64
+oracle in test_kernels_gpu.py / test_fullsize_gpu.py.
+
+The model-level GPU tests run toy sizes that never reach this kernel (it needs >= 65,536 output pixels x filter
+tiles), so the dispatch is forced here (VT_SPAN6=2) over a matrix chosen for its edge cases: pixel counts that are
+not multiples of the 32-row unit, odd map sizes (padded coordinates (H+1) x (W+1)), 6 / 7 piece taps (map widths 29
+.. 80), filter-tile counts that do not divide 32 (3 tiles), a partial last filter tile (Cout = 160), channel-slice
+operands (ldx > Cin, ldy > Cout: the concat-elided buffers of CSP / OSA blocks), every epilogue mode."""
+import ctypes as C
+import os
+
+import pytest
+import torch
+
+from vision_toolbox import _native as N
+
+from gpu_util import stream, vp
+
+pytestmark = pytest.mark.gpu
+
+# B, Cin, Cout, H, W
+SHAPES = [
+    (8, 64, 128, 96, 96),     # 7 piece taps (Wp = 97, the widest map whose span fits the LDS), 4..5-unit tiles
+    (40, 64, 128, 45, 37),    # odd sizes, M = 66,600 (not a multiple of 32)
+    (16, 96, 160, 64, 80),    # 7 piece taps (Wp = 81), partial second filter tile, three channel chunks
+    (96, 128, 128, 28, 28),   # the dominant layer's geometry at 3/8 of the batch
+    (12, 64, 384, 41, 52),    # three filter tiles (do not divide the 32 workgroups of an XCD)
+    (128, 160, 160, 28, 28),  # VoVNet-39 stage 2
+    (33, 64, 256, 29, 71),    # odd batch, two filter tiles
+    (256, 32, 128, 28, 28),   # a single channel chunk: NOT taken by span6 (must fall through unharmed)
+]
+MODES = [("stats", N.VT_CONV_STATS), ("plain", 0), ("residual", N.VT_CONV_RESIDUAL),
+         ("affine_relu", N.VT_CONV_AFFINE | N.VT_CONV_RELU),
+         ("affine_relu_residual", N.VT_CONV_AFFINE | N.VT_CONV_RELU | N.VT_CONV_RESIDUAL)]
+
+
+def _desc(B, Cin, Cout, H, W, ldx, ldy, ldr, flags, flip):
+    d = N.ConvDesc()
+    d.dtype = N.VT_BF16
+    d.B, d.Hi, d.Wi, d.Cin, d.ldx = B, H, W, Cin, ldx
+    d.Ho, d.Wo, d.sh, d.sw, d.h0, d.w0 = H, W, 1, 1, -1, -1
+    d.Cout, d.ldy, d.oH, d.oW, d.oHs, d.oWs = Cout, ldy, H, W, 1, 1
+    d.ldw, d.ldr, d.flags, d.ntaps = 9 * Cin, ldr, flags, 9
+    for i in range(9):
+        # flip: the tap order of a stride-1 data gradient (filter rotated by 180 degrees)
+        t = 8 - i if flip else i
+        d.dh[i], d.dw[i] = t // 3, t % 3
+    return d
+
+
+def _run(env, d, x, w, y, scale, shift, res, stats):
+    os.environ["VT_SPAN6"] = env
+    try:
+        N.check(N.lib().vt_conv_igemm(C.byref(d), vp(x), vp(w), vp(y), vp(scale) if scale is not None else None,
+                                      vp(shift) if shift is not None else None, vp(res) if res is not None else None,
+                                      vp(stats) if stats is not None else None, stream()))
+        torch.cuda.synchronize()
+        return N.last_kernel_name()
+    finally:
+        os.environ.pop("VT_SPAN6", None)
+
+
+@pytest.mark.parametrize("mode", MODES, ids=[m[0] for m in MODES])
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_span6_is_bit_identical_to_the_span_kernel(shape, mode):
+    B, Cin, Cout, H, W = shape
+    flags = mode[1]
+    torch.manual_seed(hash(shape) % 1000)
+    slices = shape[0] % 2 == 0  # half of the shapes: operands are channel slices of wider buffers
+    ldx, ldy = (Cin + 32, Cout + 64) if slices else (Cin, Cout)
+    xb = torch.randn(B, H, W, ldx, device="cuda").to(torch.bfloat16)
+    x = xb[..., 16:16 + Cin] if slices else xb
+    w = (torch.randn(Cout, 9, Cin, device="cuda") * (2.0 / (9 * Cin)) ** 0.5).to(torch.bfloat16)
+    res = torch.randn(B, H, W, Cout, device="cuda").to(torch.bfloat16) if flags & N.VT_CONV_RESIDUAL else None
+    scale = torch.rand(Cout, device="cuda") + 0.5 if flags & N.VT_CONV_AFFINE else None
+    shift = torch.randn(Cout, device="cuda") if flags & N.VT_CONV_AFFINE else None
+    d = _desc(B, Cin, Cout, H, W, ldx, ldy, Cout if res is not None else 0, flags, flip=mode[0] == "residual")
+    outs = {}
+    for env in ("0", "2"):
+        yb = torch.full((B, H, W, ldy), float("nan"), device="cuda", dtype=torch.bfloat16)
+        y = yb[..., 32:32 + Cout] if slices else yb
+        st = torch.zeros(N.VT_STAT_REPLICAS, 2, Cout, device="cuda") if flags & N.VT_CONV_STATS else None
+        name = _run(env, d, x, w, y, scale, shift, res, st)
+        outs[env] = (yb, st.double().sum(0) if st is not None else None, name)
+    (y0, s0, n0), (y1, s1, n1) = outs["0"], outs["2"]
+    assert "span6" not in n0
+    assert ("span6" in n1) == (Cin >= 64), n1  # the forced dispatch really took the kernel under test
+    assert torch.equal(torch.isnan(y0.float()), torch.isnan(y1.float()))  # nothing outside the slice was written
+    a, b = torch.nan_to_num(y0.float()), torch.nan_to_num(y1.float())
+    if "span_kernel" in n0 or "span6" not in n1:
+        assert torch.equal(a, b)
+    else:  # reference = the general kernel: another summation order, one bf16 rounding apart at most
+        assert ((a - b).norm() / a.norm()).item() < 1e-3
+        torch.testing.assert_close(b, a, rtol=2.0 ** -6, atol=2e-2)  # two roundings (epilogue, residual add): 2 ulp
+    if s0 is not None:
+        # the statistics are sums of the (same) stored values in a different order
+        torch.testing.assert_close(s1, s0, rtol=2e-3 if "span_kernel" not in n0 else 1e-5, atol=0.5)

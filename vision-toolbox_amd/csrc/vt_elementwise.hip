@@ -159,7 +159,8 @@ __global__ void __launch_bounds__(kThreads)
 bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z, int ldz,
                      const float* __restrict__ scale, const float* __restrict__ shift,
                      const float* __restrict__ mean, const float* __restrict__ invstd, long M, int C,
-                     RowMap rm, int relu, float* __restrict__ sums) {
+                     RowMap rm, int relu_flags, float* __restrict__ sums) {
+    const int relu = relu_flags & 1;  // bit 1: dev switch, LDS staging of every row lane (the pre-round-2 fold)
     constexpr int EPC = VecIO<T>::EPC;
     // [RT][2][CT*EPC] partial sums: each thread parks its 2*EPC partials, then the first
     // 2*CT*EPC threads fold the RT row lanes (no LDS atomics: with RT rows per column they
@@ -213,9 +214,29 @@ bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z
                 }
             }
         }
-        if (r < rm.RT) {
-            float4* d1 = (float4*)(sred + ((long)(r * 2 + 0) * W + tc * EPC));
-            float4* d2 = (float4*)(sred + ((long)(r * 2 + 1) * W + tc * EPC));
+        // Rows of the fold: with CT a power of two below 64 a wave holds 64 / CT row lanes of every column it
+        // touches; those are folded in registers first (xor shuffles), so the LDS staging shrinks from RT to
+        // kThreads / 64 rows -- 4 KiB instead of 16 KiB at C = 128.  (This kernel runs beside the filter gradients
+        // of the side stream, whose workgroups hold most of a CU's LDS: at 16 KiB per block its occupancy, not HBM,
+        // set its in-step time.)
+        const bool inwave = rm.CT < 64 && (rm.CT & (rm.CT - 1)) == 0 && !(relu_flags & 2);
+        int rows_l = rm.RT, r_l = r;
+        if (inwave) {
+            for (int off = rm.CT; off < 64; off <<= 1) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    s1[e] += __shfl_xor(s1[e], off, 64);
+                    s2[e] += __shfl_xor(s2[e], off, 64);
+                }
+            }
+            rows_l = kThreads / 64;
+            r_l = (t & 63) < rm.CT ? (t >> 6) : -1;  // one writer per (wave, column)
+        } else if (r >= rm.RT) {
+            r_l = -1;
+        }
+        if (r_l >= 0) {
+            float4* d1 = (float4*)(sred + ((long)(r_l * 2 + 0) * W + tc * EPC));
+            float4* d2 = (float4*)(sred + ((long)(r_l * 2 + 1) * W + tc * EPC));
 #pragma unroll
             for (int q = 0; q < EPC / 4; ++q) {
                 d1[q] = make_float4(s1[4 * q], s1[4 * q + 1], s1[4 * q + 2], s1[4 * q + 3]);
@@ -228,7 +249,7 @@ bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z
             const int c = cbase * EPC + lc;
             if (c < C) {
                 float acc = 0.f;
-                for (int rr = 0; rr < rm.RT; ++rr) acc += sred[(long)(rr * 2 + which) * W + lc];
+                for (int rr = 0; rr < rows_l; ++rr) acc += sred[(long)(rr * 2 + which) * W + lc];
                 if (which) acc *= invstd[c];
                 atomicAdd(&sums[((long)rep * 2 + which) * C + c], acc);
             }
@@ -980,11 +1001,13 @@ int vt_bn_act_bwd_reduce(const void* dy, int32_t lddy, const void* z, int32_t ld
     const int epc = vt_epc(dtype);
     static const int target = getenv("VT_REDUCE_BLOCKS") ? atoi(getenv("VT_REDUCE_BLOCKS")) : 1024;
     const RowMap rm = RowMap::make(C, epc, M, target);
-    const int smem = rm.RT * 2 * rm.CT * epc * (int)sizeof(float);
+    static const int inwave_env = getenv("VT_REDUCE_INWAVE") ? atoi(getenv("VT_REDUCE_INWAVE")) : 1;
+    const bool inwave = inwave_env && rm.CT < 64 && (rm.CT & (rm.CT - 1)) == 0;  // (as in the kernel)
+    const int smem = (inwave ? kThreads / 64 : rm.RT) * 2 * rm.CT * epc * (int)sizeof(float);
     VT_DISPATCH_T(dtype, "vt_bn_act_bwd_reduce",
                   hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(rm.blocks(M)), dim3(kThreads), smem,
                                      (hipStream_t)stream, (const T*)dy, lddy, (const T*)z, ldz, scale, shift,
-                                     mean, invstd, (long)M, C, rm, relu, sums));
+                                     mean, invstd, (long)M, C, rm, (relu ? 1 : 0) | (inwave_env ? 0 : 2), sums));
     VT_CHECK_LAUNCH("vt_bn_act_bwd_reduce");
     return VT_OK;
 }

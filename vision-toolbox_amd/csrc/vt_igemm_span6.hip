@@ -712,7 +712,8 @@ int vt_span6_dispatch(IgemmArgs& a0, int dtype, void* stream) {
     if (!enabled || dtype != VT_BF16) return -1;
     if (enabled < 2 && (a0.Cout < 128 || a0.Wi < 20 || a0.Hi < 20)) return -1;
     if (a0.sh != 1 || a0.sw != 1 || a0.Ho != a0.Hi || a0.Wo != a0.Wi) return -1;
-    if (a0.Cin % 32 != 0 || a0.ntaps != 9 || a0.Cout < 64) return -1;
+    // (Cin >= 64: with a single channel chunk the next tile's piece sources would be needed before they are computed)
+    if (a0.Cin % 32 != 0 || a0.Cin < 64 || a0.ntaps != 9 || a0.Cout < 64) return -1;
     if ((long)a0.M + 2L * a0.Wi * VT_MAX_TAPS > 0x7fffffffL) return -1;
     if ((long)a0.B * a0.oH * a0.oW > 0x7fffffffL) return -1;
     if ((unsigned long)a0.M * a0.ldx * 2 >= 0xffff0000ul) return -1;
