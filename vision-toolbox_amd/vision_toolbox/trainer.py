@@ -10,9 +10,13 @@ program per rank:
               as the backward segment that completes it has been enqueued
            -> SGD(momentum) over the flat buffers, which also refreshes the bf16 weights
 
-Every segment is a captured hipGraph (vt_graph_*), so a step costs a handful of host calls.
-BatchNorm uses per-rank batch statistics (SyncBN, configs/base.yaml:22, is not enabled: its
-134 latency-bound collectives per step would dominate a ~10 ms step).
+The step is one launch list cut into segments at the bucket boundaries; every segment runs
+through the native executor on two streams (main + filter-gradient side stream, left open
+across segments so N > 1 keeps the N = 1 schedule; the bucket all-reduce is issued with the
+side stream current).  hipGraph replay of the same segments is available (graphs=True) but
+measured slower than eager two-stream execution.  BatchNorm uses per-rank batch statistics by
+default; sync_bn=True gives the reference recipe's SyncBatchNorm (configs/base.yaml:22) at the
+cost of 134 small collectives per step.
 """
 from __future__ import annotations
 
