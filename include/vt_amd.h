@@ -146,6 +146,23 @@ int vt_bn_act_bwd_apply(const void* dy, int32_t lddy, const void* z, int32_t ldz
                         void* dz, int32_t lddz, int64_t M, int32_t C, int32_t relu,
                         int32_t dtype, void* stream);
 
+/* Backward of the stem unit Conv3x3(3 -> C, s1, pad 1) -> BatchNorm2d -> ReLU in one streaming pass
+ * (darknet.py:75 `ConvNormAct(3, 32, 3, 1)`; autograd backward of components.py:26-44 with respect to the
+ * conv weight and the BatchNorm parameters -- the unit's input is the image, no data gradient exists).
+ * vt_stem_bn_bwd_reduce reads x [B*H*W][8] (3 real channels), dy and z ONCE and accumulates
+ *   sums  float[VT_STAT_REPLICAS][2][C]  as vt_bn_act_bwd_reduce, and
+ *   gzx   float[vt_stem_bn_bwd_scratch_bytes(C) / 4]: the correlations of g, z and 1 with the tap-shifted x
+ * (both zeroed by the caller); after vt_bn_bwd_finalize, vt_stem_bn_bwd_combine adds
+ *   dw[n][t][c] += coef0[n]*G - coef1[n]*Z + coef2[n]*X,  dw float[C][9][cin]
+ * i.e. the filter gradient of dz = coef0*g - coef1*z + coef2 without forming dz.  bf16, C = 32 (the stems of the reference's models). */
+int64_t vt_stem_bn_bwd_scratch_bytes(int32_t C);
+int vt_stem_bn_bwd_reduce(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, const void* x,
+                          const void* dy, int32_t lddy, const void* z, int32_t ldz, const float* scale,
+                          const float* shift, const float* mean, const float* invstd, int32_t relu,
+                          float* sums, float* gzx, void* stream);
+int vt_stem_bn_bwd_combine(int32_t C, int32_t cin, const float* gzx, const float* coef, float* dw,
+                           void* stream);
+
 /* ---- pooling ------------------------------------------------------------ */
 /* nn.MaxPool2d(3, 2, 1) at the head of every VoVNet stage (vovnet.py:94). */
 int vt_maxpool3x3s2_fwd(const void* x, int32_t ldx, void* y, int32_t ldy, uint8_t* argmax,
@@ -277,6 +294,8 @@ enum vt_op_kind {
     VT_OP_FORK_MARK, /* remember the main stream's position (an event record), nothing waits yet */
     VT_OP_FORK_WAIT, /* side stream waits for the last FORK_MARK: FORK split in two, so that the host can enqueue main-stream
                         work between the mark and the side-stream ops that depend on it */
+    VT_OP_STEM_BWD_REDUCE,  /* vt_stem_bn_bwd_reduce */
+    VT_OP_STEM_BWD_COMBINE, /* vt_stem_bn_bwd_combine */
     VT_OP_KIND_END
 };
 

@@ -153,12 +153,16 @@ def test_cspdarknet53_program_structure():
     p = _dry_program("cspdarknet53", N.VT_BF16, True, True)
     h = p.kind_histogram
     assert p.n_units == 67
-    assert h["conv_wgrad"] == 67 and h["bn_finalize"] == 67 and h["bn_bwd_apply"] == 67
+    # the stem unit's backward is ONE streaming pass (BatchNorm reduction + filter-gradient correlations) and a
+    # combine kernel: no dz, no bn_bwd_reduce / bn_bwd_apply / conv_wgrad for it (vt_stem_bwd.hip)
+    assert h["stem_bwd_reduce"] == 1 and h["stem_bwd_combine"] == 1
+    assert h["conv_wgrad"] == 66 and h["bn_finalize"] == 67 and h["bn_bwd_apply"] == 66 and h["bn_bwd_reduce"] == 66
+    assert h["bn_bwd_finalize"] == 67
     # residual adds are folded into the normalise pass and torch.cat is elided: the ONLY
     # elementwise launches are one bn_act_apply per unit; the only copies are the bf16 weight
-    # mirror and the 3->8 channel stem filter pad (+ its gradient un-pad)
+    # mirror and the 3->8 channel stem filter pad
     assert h["bn_act_apply"] == 67
-    assert h["copy2d"] == 3
+    assert h["copy2d"] == 2
     # forward convs + one data-gradient launch per conv (4 parity classes for the 5 stride-2 convs)
     assert h["conv_igemm"] == 67 + (66 - 5) + 5 * 4
     assert "maxpool_fwd" not in h

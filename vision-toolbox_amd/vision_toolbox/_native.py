@@ -50,7 +50,9 @@ VT_OP_MAX_PTR, VT_OP_MAX_INT, VT_OP_MAX_FLT, VT_MAX_BASES = 12, 110, 8, 16
     OP_RESAMPLE_BWD,
     OP_FORK_MARK,
     OP_FORK_WAIT,
-) = range(1, 29)
+    OP_STEM_BWD_REDUCE,
+    OP_STEM_BWD_COMBINE,
+) = range(1, 31)
 OP_SIDE_STREAM = 0x10000  # OR-ed into Op.kind: enqueue on the side stream
 
 OP_NAMES = {
@@ -80,6 +82,8 @@ OP_NAMES = {
     OP_JOIN: "join",
     OP_FORK_MARK: "fork_mark",
     OP_FORK_WAIT: "fork_wait",
+    OP_STEM_BWD_REDUCE: "stem_bwd_reduce",
+    OP_STEM_BWD_COMBINE: "stem_bwd_combine",
     OP_RESAMPLE_FWD: "resample_fwd",
     OP_RESAMPLE_BWD: "resample_bwd",
 }
@@ -139,6 +143,9 @@ SYMBOLS = {
     "vt_bn_act_apply": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "vt_bn_act_bwd_reduce": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "vt_bn_bwd_finalize": (_i32, [_vp, _i32, _f64, _f64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "vt_stem_bn_bwd_scratch_bytes": (_i64, [_i32]),
+    "vt_stem_bn_bwd_reduce": (_i32, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "vt_stem_bn_bwd_combine": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp]),
     "vt_bn_act_bwd_apply": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "vt_maxpool3x3s2_fwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vt_maxpool3x3s2_bwd": (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -242,6 +242,8 @@ class Builder:
         # plain FORK (24.65 vs 24.66 ms: the 7 us per unit on the main stream are the event record itself, not the
         # host's issue order), so off
         self.fork_split = os.environ.get("VT_FORK_SPLIT", "0") != "0"
+        # stem unit (3 -> 32, s1): BatchNorm-backward reduction and filter gradient in one pass, dz never formed
+        self.stem_fused_bwd = os.environ.get("VT_STEM_FUSED_BWD", "1") != "0"
         self._hoisted: list[N.Op] = []
         # SyncBatchNorm (configs/base.yaml:22): the trainer all-reduces every layer's statistics
         # between the kernel that accumulates them and the finalize kernel; the finalize kernels
@@ -576,6 +578,9 @@ class Builder:
                       [x.addr(), wptr, y.addr(), None, self.pref(conv.bias) if conv.bias is not None else None,
                        residual.addr() if residual else None, None], desc=d)
 
+        stem_fused = (self.stem_fused_bwd and track and padded and has_bn and not fused and residual is None and
+                      not x.needs_grad and w.requires_grad and dt == N.VT_BF16 and Cout == 32 and k == 3 and s == 1 and
+                      pad == 1 and x.C == 8 and x.ld == 8)
         if track:
             tag = self.tag
             training = unit_training
@@ -587,6 +592,21 @@ class Builder:
                     return
                 if residual is not None:
                     self.grad_add(residual, dy)
+                if stem_fused:
+                    # dz = a*g - b*z + d feeds nothing but the filter gradient (the unit's input is the image): the
+                    # pass that reduces (sum g, sum g*xhat) also correlates g, z and 1 with the tap-shifted x, and a
+                    # small kernel finishes dW = a*G - b*Z + d*X once (a, b, d) exist (vt_stem_bwd.hip)
+                    sums = self.zeroed_f32(N.VT_STAT_REPLICAS * 2 * Cout, "bwdsums")
+                    gzx = self.zeroed_f32(N.lib().vt_stem_bn_bwd_scratch_bytes(Cout) // 4, "stem_gzx")
+                    self.emit(N.OP_STEM_BWD_REDUCE,
+                              [x.addr(), dy.addr(), z.addr(), cp[0], cp[1], cp[2], cp[3], self.bp(sums), self.bp(gzx)],
+                              [dt, B, x.H, x.W, Cout, dy.ld, z.ld, int(relu)])
+                    bcoef = self.f32(3 * Cout, "bwdcoef")
+                    self.emit(N.OP_BN_BWD_FINALIZE,
+                              [self.bp(sums), cp[0], cp[2], cp[3], self.pgrad(norm.weight), self.pgrad(norm.bias),
+                               self.bp(bcoef)], [Cout, int(training)], [M * self.bn_world, 1.0 / self.bn_world])
+                    self.emit(N.OP_STEM_BWD_COMBINE, [self.bp(gzx), self.bp(bcoef), self.pgrad(w)], [Cout, Cin_w])
+                    return
                 if has_bn:
                     sums = self.zeroed_f32(N.VT_STAT_REPLICAS * 2 * Cout, "bwdsums")
                     self.emit(N.OP_BN_BWD_REDUCE,
