@@ -48,6 +48,11 @@ extern "C" {
 #define VT_CONV_STATS 2    /* accumulate per-channel sum / sum-of-squares       */
 #define VT_CONV_RESIDUAL 4 /* y += residual (after relu)                        */
 #define VT_CONV_AFFINE 8   /* y = y*scale[c] + shift[c]; scale==NULL means 1    */
+#define VT_CONV_D2S 16     /* depth-to-space 2x2: the Cout = 4*C' columns of grid pixel (i, j) are the output pixels
+                            * (2i+a, 2j+b) x C' channels, column = (2a+b)*C' + c; needs oHs = oWs = 2, oh0 = ow0 = 0,
+                            * oH = 2*Ho, oW = 2*Wo, no STATS / AFFINE / RELU.  One launch then forms the whole data
+                            * gradient of a 3x3 stride-2 convolution (the four parity classes as column blocks of a
+                            * 2x2-tap filter image, zero where a class has no tap) and reads dz once. */
 
 #define VT_STAT_REPLICAS 32 /* stats buffers are float[VT_STAT_REPLICAS][2][C]  */
 
@@ -107,7 +112,7 @@ int vt_conv_wgrad(const vt_conv_desc* d, const void* x, const void* dz, float* d
 
 /* Re-pack a [Cout][ntaps][Cin] filter (f32 master or dtype mirror) into the
  * [Cin][nsel][Cout] image the data-gradient launch reads; sel[i] is the source
- * tap of packed tap i. */
+ * tap of packed tap i (-1: a zero tap, for the column blocks of a VT_CONV_D2S filter image). */
 int vt_pack_dgrad_filter(const void* w, int32_t src_dtype, int32_t ldw, void* out,
                          int32_t dst_dtype, const int32_t* sel_host, int32_t nsel,
                          int32_t Cout, int32_t ntaps, int32_t Cin, void* stream);

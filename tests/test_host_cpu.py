@@ -163,8 +163,9 @@ def test_cspdarknet53_program_structure():
     # mirror and the 3->8 channel stem filter pad
     assert h["bn_act_apply"] == 67
     assert h["copy2d"] == 2
-    # forward convs + one data-gradient launch per conv (4 parity classes for the 5 stride-2 convs)
-    assert h["conv_igemm"] == 67 + (66 - 5) + 5 * 4
+    # forward convs + one data-gradient launch per conv; the 5 stride-2 convs take 4 parity-class launches, except the
+    # HBM-bound first one (32 -> 64 channels), whose classes are the column blocks of one depth-to-space launch
+    assert h["conv_igemm"] == 67 + (66 - 5) + 4 * 4 + 1
     assert "maxpool_fwd" not in h
 
 

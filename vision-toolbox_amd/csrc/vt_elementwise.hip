@@ -885,7 +885,7 @@ struct SelTable {
     int sel[VT_MAX_TAPS];
 };
 
-// out[c][i][n] = w[n][sel[i]][c]
+// out[c][i][n] = w[n][sel[i]][c]  (sel[i] < 0: zeros)
 template <typename S, typename D>
 __global__ void __launch_bounds__(kThreads)
 pack_dgrad_kernel(const S* __restrict__ w, int ldw, D* __restrict__ out, SelTable st, int nsel, int Cout,
@@ -895,7 +895,8 @@ pack_dgrad_kernel(const S* __restrict__ w, int ldw, D* __restrict__ out, SelTabl
         const long t2 = i / Cout;
         const int s = (int)(t2 % nsel);
         const int c = (int)(t2 / nsel);
-        out[i] = from_float<D>((float)w[(long)n * ldw + (long)st.sel[s] * Cin + c]);
+        const int src = st.sel[s];
+        out[i] = from_float<D>(src < 0 ? 0.f : (float)w[(long)n * ldw + (long)src * Cin + c]);
     }
 }
 
@@ -1314,8 +1315,8 @@ int vt_pack_dgrad_filter(const void* w, int32_t src_dtype, int32_t ldw, void* ou
                VT_ERR_INVALID, "vt_pack_dgrad_filter: bad argument");
     SelTable st;
     for (int i = 0; i < nsel; ++i) {
-        VT_REQUIRE(sel_host[i] >= 0 && sel_host[i] < ntaps, VT_ERR_INVALID,
-                   "vt_pack_dgrad_filter: sel[%d]=%d outside [0,%d)", i, sel_host[i], ntaps);
+        VT_REQUIRE(sel_host[i] >= -1 && sel_host[i] < ntaps, VT_ERR_INVALID,
+                   "vt_pack_dgrad_filter: sel[%d]=%d outside [-1,%d)", i, sel_host[i], ntaps);
         st.sel[i] = sel_host[i];
     }
     const long total = (long)Cin * nsel * Cout;

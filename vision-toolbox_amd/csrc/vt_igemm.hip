@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs p) {
             }
             uint4 v = sOut4[idx];
             if (has_res) {
-                const uint4 r = *(const uint4*)(rg + (po * p.ldr + n));
+                const uint4 r = *(const uint4*)(rg + (po * p.ldr + vt_out_col(p, n, p.ldr)));
                 float fv[EPC], fr[EPC];
                 VecIO<T>::unpack(v, fv);
                 VecIO<T>::unpack(r, fr);
@@ -402,7 +402,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs p) {
                 for (int e = 0; e < EPC; ++e) fv[e] += fr[e];
                 v = VecIO<T>::pack(fv);
             }
-            *(uint4*)(yg + (po * p.ldy + n)) = v;
+            *(uint4*)(yg + (po * p.ldy + vt_out_col(p, n, p.ldy))) = v;
         }
     }
 }
@@ -453,7 +453,14 @@ extern "C" int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w
                VT_ERR_UNSUPPORTED,
                "vt_conv_igemm: Cin=%d Cout=%d ldx=%d ldy=%d ldw=%d must be multiples of %d", d->Cin,
                d->Cout, d->ldx, d->ldy, d->ldw, epc);
-    VT_REQUIRE(d->ldx >= d->Cin && d->ldy >= d->Cout && d->ldw >= d->ntaps * d->Cin, VT_ERR_INVALID,
+    const bool d2s = (d->flags & VT_CONV_D2S) != 0;
+    if (d2s) {
+        VT_REQUIRE(d->Cout % (4 * epc) == 0 && d->oHs == 2 && d->oWs == 2 && d->oh0 == 0 && d->ow0 == 0 &&
+                       d->oH == 2 * d->Ho && d->oW == 2 * d->Wo &&
+                       !(d->flags & (VT_CONV_STATS | VT_CONV_AFFINE | VT_CONV_RELU)),
+                   VT_ERR_UNSUPPORTED, "vt_conv_igemm: D2S needs Cout = 4*C', a 2x2-strided output and a raw epilogue");
+    }
+    VT_REQUIRE(d->ldx >= d->Cin && d->ldy >= (d2s ? d->Cout / 4 : d->Cout) && d->ldw >= d->ntaps * d->Cin, VT_ERR_INVALID,
                "vt_conv_igemm: stride smaller than extent");
     VT_REQUIRE(vt_aligned16(x) && vt_aligned16(w) && vt_aligned16(y), VT_ERR_INVALID,
                "vt_conv_igemm: x/w/y must be 16-byte aligned");
@@ -465,7 +472,7 @@ extern "C" int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w
     VT_REQUIRE(in_elems < 0x7fffffffL && out_elems < 0x7fffffffL && (long)d->B * d->Ho * d->Wo < 0x7fffffffL,
                VT_ERR_UNSUPPORTED, "vt_conv_igemm: tensor exceeds 2^31 elements");
     if (d->flags & VT_CONV_RESIDUAL) {
-        VT_REQUIRE(residual && vt_aligned16(residual) && d->ldr % epc == 0 && d->ldr >= d->Cout,
+        VT_REQUIRE(residual && vt_aligned16(residual) && d->ldr % epc == 0 && d->ldr >= (d2s ? d->Cout / 4 : d->Cout),
                    VT_ERR_INVALID, "vt_conv_igemm: bad residual");
     }
     if (d->flags & VT_CONV_AFFINE) VT_REQUIRE(shift, VT_ERR_INVALID, "vt_conv_igemm: AFFINE needs shift");
@@ -496,19 +503,19 @@ extern "C" int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w
     memcpy(a.dw, d->dw, VT_MAX_TAPS);
 
     hipStream_t st = (hipStream_t)stream;
-    {
+    if (!d2s) {  // (these kernels write dense rows only)
         const int rc = vt_stem_dispatch(a, d->dtype, stream);  // RGB stem
         if (rc >= 0) return rc;
     }
-    {
+    if (!d2s) {  // (these kernels write dense rows only)
         const int rc = vt_span6_dispatch(a, d->dtype, stream);  // MFMA-bound 3x3 stride-1 layers: two-group + loader kernel
         if (rc >= 0) return rc;
     }
-    {
+    if (!d2s) {  // (these kernels write dense rows only)
         const int rc = vt_span5_dispatch(a, d->dtype, stream);  // MFMA-bound 3x3 stride-1 layers: loader-wave span kernel
         if (rc >= 0) return rc;
     }
-    {
+    if (!d2s) {  // (these kernels write dense rows only)
         const int rc = vt_span3_dispatch(a, d->dtype, stream);  // MFMA-bound 3x3 stride-1 layers: persistent span kernel
         if (rc >= 0) return rc;
     }

@@ -18,6 +18,15 @@ struct IgemmArgs {
     int8_t dw[VT_MAX_TAPS];
 };
 
+// element offset of output column n relative to the row's base pixel: n itself, or under VT_CONV_D2S the pixel
+// (a, b) = ((n / C') >> 1, (n / C') & 1) of the 2 x 2 block and channel n % C' (C' = Cout / 4)
+__device__ __forceinline__ long vt_out_col(const IgemmArgs& p, int n, int ld) {
+    if (!(p.flags & VT_CONV_D2S)) return n;
+    const int cq = p.Cout >> 2;
+    const int blk = n / cq;
+    return ((long)(blk >> 1) * p.oW + (blk & 1)) * ld + (n - blk * cq);
+}
+
 // vt_igemm_span.hip: input-span kernel for stride-1-grid convs; returns -1 when it does not
 // apply to `a` (the caller then launches the general kernel), else a VT_* status.
 int vt_span_dispatch(IgemmArgs& a, int dtype, void* stream);

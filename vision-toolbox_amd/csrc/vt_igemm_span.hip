@@ -591,6 +591,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
     }
     const int rrow = lane / CPRW, rch = lane % CPRW;
     const int ncol = tn * BN + wn * TN + rch * EPC;
+    const long ycol = vt_out_col(p, ncol, p.ldy), rcol = vt_out_col(p, ncol, p.ldr);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -618,7 +619,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
                     const long po = sPo[tr];
                     uint4 v = raw;
                     if (has_res) {
-                        const uint4 rr = *(const uint4*)(rg + (po * p.ldr + ncol));
+                        const uint4 rr = *(const uint4*)(rg + (po * p.ldr + rcol));
                         float fv[EPC], fr[EPC];
                         VecIO<T>::unpack(v, fv);
                         VecIO<T>::unpack(rr, fr);
@@ -626,7 +627,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
                         for (int e = 0; e < EPC; ++e) fv[e] += fr[e];
                         v = VecIO<T>::pack(fv);
                     }
-                    *(uint4*)(yg + (po * p.ldy + ncol)) = v;
+                    *(uint4*)(yg + (po * p.ldy + ycol)) = v;
                 }
             }
         }

@@ -17,7 +17,7 @@ LIB_PATH = Path(os.environ.get("VT_AMD_LIB", _HERE.parent / "csrc" / "libvt_amd.
 VT_OK, VT_ERR_INVALID, VT_ERR_UNSUPPORTED, VT_ERR_HIP = 0, 1, 2, 3
 VT_F32, VT_BF16 = 0, 1
 VT_MAX_TAPS = 36
-VT_CONV_RELU, VT_CONV_STATS, VT_CONV_RESIDUAL, VT_CONV_AFFINE = 1, 2, 4, 8
+VT_CONV_RELU, VT_CONV_STATS, VT_CONV_RESIDUAL, VT_CONV_AFFINE, VT_CONV_D2S = 1, 2, 4, 8, 16
 VT_STAT_REPLICAS = 32
 VT_OP_MAX_PTR, VT_OP_MAX_INT, VT_OP_MAX_FLT, VT_MAX_BASES = 12, 110, 8, 16
 

@@ -244,6 +244,9 @@ class Builder:
         self.fork_split = os.environ.get("VT_FORK_SPLIT", "0") != "0"
         # stem unit (3 -> 32, s1): BatchNorm-backward reduction and filter gradient in one pass, dz never formed
         self.stem_fused_bwd = os.environ.get("VT_STEM_FUSED_BWD", "1") != "0"
+        # 3x3 stride-2 data gradients whose dz has at most this many channels (the HBM-bound ones) run as ONE
+        # depth-to-space launch instead of four parity-class launches that each re-read dz
+        self.dgrad_d2s_maxc = int(os.environ.get("VT_DGRAD_D2S_MAXC", "64"))
         self._hoisted: list[N.Op] = []
         # SyncBatchNorm (configs/base.yaml:22): the trainer all-reduces every layer's statistics
         # between the kernel that accumulates them and the finalize kernel; the finalize kernels
@@ -668,6 +671,46 @@ class Builder:
         # the s*s parity classes tile d(x) disjointly, so they share one destination and
         # one folded addend: every pixel is produced exactly once
         gx, res = self.grad_target(x)
+        if (s == 2 and k == 3 and pad == 1 and x.H % 2 == 0 and x.W % 2 == 0 and Cout <= self.dgrad_d2s_maxc and
+                (4 * x.C) % (4 * _EPC[dt]) == 0 and dt == N.VT_BF16):
+            # Every parity class (ph, pw) of d(x) reads dz at offsets {0, 1}^2 of its own grid position, so the four
+            # are the column blocks of ONE 2x2-tap convolution over dz with 4*C output columns (zero taps where a
+            # class has fewer), written depth-to-space: dz is read once instead of four times.  16/9 of the MFMA work,
+            # which these layers (HBM-bound: few channels, large maps) do not notice.
+            taps = [(1, 1), (1, 0), (0, 1), (0, 0)]  # the order a parity class lists its own taps in (below)
+            wd = self.alloc(4 * x.C * 4 * Cout * _ESIZE[dt], "wd_d2s")
+            for ph in range(2):
+                for pw in range(2):
+                    r0, t0 = (ph + pad) % s, (pw + pad) % s
+                    rows, cols = list(range(r0, k, s)), list(range(t0, k, s))
+                    eh, ew = (ph + pad - r0) // s, (pw + pad - t0) // s
+                    sel = []
+                    for (a, b) in taps:  # class tap (u, v) sits at offset (eh - u, ew - v)
+                        u, v = eh - a, ew - b
+                        sel.append(rows[u] * k + cols[v] if 0 <= u < len(rows) and 0 <= v < len(cols) else -1)
+                    ints = [w_dtype, ldw, dt, 4, Cout, k * k, x.C, 0] + sel
+                    dst = self.bp(wd, (2 * ph + pw) * x.C * 4 * Cout * _ESIZE[dt])
+                    if self.hoist_dgrad_packs:
+                        keep, self._cur = self._cur, self._hoisted
+                        self.emit(N.OP_PACK_DGRAD, [wptr, dst], ints, side=True)
+                        self._cur = keep
+                    else:
+                        self.emit(N.OP_PACK_DGRAD, [wptr, dst], ints)
+            d = N.ConvDesc()
+            d.dtype = dt
+            d.B, d.Hi, d.Wi, d.Cin, d.ldx = dz.B, Ho, Wo, Cout, dz.ld
+            d.Ho, d.Wo, d.sh, d.sw, d.h0, d.w0 = x.H // 2, x.W // 2, 1, 1, 0, 0
+            d.Cout, d.ldy, d.oH, d.oW = 4 * x.C, gx.ld, x.H, x.W
+            d.oHs, d.oWs, d.oh0, d.ow0 = 2, 2, 0, 0
+            d.ldw, d.ldr = 4 * Cout, (res.ld if res is not None else 0)
+            d.flags = N.VT_CONV_D2S | (N.VT_CONV_RESIDUAL if res is not None else 0)
+            d.ntaps = 4
+            for i, (a, b) in enumerate(taps):
+                d.dh[i], d.dw[i] = a, b
+            self.emit(N.OP_CONV_IGEMM, [dz.addr(), self.bp(wd), gx.addr(), None, None,
+                                        res.addr() if res is not None else None, None], desc=d)
+            self.grad_written(x)
+            return
         for ph in range(s):
             for pw in range(s):
                 r0, t0 = (ph + pad) % s, (pw + pad) % s
