@@ -46,32 +46,45 @@ __device__ __forceinline__ void st16(T* p, const uint4& v) { *(uint4*)p = v; }
 // ---------------------------------------------------------------------------------
 // BatchNorm finalize (training): stats -> mean / invstd / scale / shift + running stats
 // ---------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, int C, double count,
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int C, double inv_count, double unbias,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float eps, float momentum, float* running_mean, float* running_var,
                                    int64_t* nbt, float* scale, float* shift, float* mean, float* invstd) {
+    // One single-block launch per BatchNorm, 134 of them on the critical path of a step: what it costs is latency,
+    // not work.  The replica sums are loaded as independent pairs (two partial chains), the divisions by `count` are
+    // multiplications by a host-computed reciprocal, and 1/sqrt runs in f32 on the double-precision variance
+    // (correctly rounded sqrt and division: within one ulp of the double evaluation) -- fp64 division and sqrt are
+    // long software sequences on this hardware.
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && nbt) nbt[0] += 1;
     if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int r = 0; r < VT_STAT_REPLICAS; ++r) {
-        s += (double)stats[((long)r * 2 + 0) * C + c];
-        ss += (double)stats[((long)r * 2 + 1) * C + c];
-    }
-    const double mu = s / count;
-    double var = ss / count - mu * mu;
-    if (var < 0.0) var = 0.0;
-    const float istd = (float)(1.0 / sqrt(var + (double)eps));
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    float rm = 0.f, rv = 0.f;
+    if (running_mean) rm = running_mean[c], rv = running_var[c];
+    float v1[VT_STAT_REPLICAS], v2[VT_STAT_REPLICAS];
+#pragma unroll
+    for (int r = 0; r < VT_STAT_REPLICAS; ++r) {
+        v1[r] = stats[((long)r * 2 + 0) * C + c];
+        v2[r] = stats[((long)r * 2 + 1) * C + c];
+    }
+    double s = 0.0, ss = 0.0, sb = 0.0, ssb = 0.0;
+#pragma unroll
+    for (int r = 0; r < VT_STAT_REPLICAS; r += 2) {
+        s += (double)v1[r], sb += (double)v1[r + 1];
+        ss += (double)v2[r], ssb += (double)v2[r + 1];
+    }
+    const double mu = (s + sb) * inv_count;
+    double var = (ss + ssb) * inv_count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float istd = 1.0f / sqrtf((float)(var + (double)eps));
     const float sc = g * istd;
     scale[c] = sc;
     shift[c] = b - (float)mu * sc;
     mean[c] = (float)mu;
     invstd[c] = istd;
     if (running_mean) {
-        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        running_mean[c] = (1.f - momentum) * rm + momentum * (float)mu;
+        running_var[c] = (1.f - momentum) * rv + momentum * (float)(var * unbias);
     }
 }
 
@@ -258,26 +271,37 @@ bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, double count, double pscale,
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, double inv_count, double pscale,
                                        const float* __restrict__ scale, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, int train, float* dgamma,
                                        float* dbeta, float* coef) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
+    const float a = scale[c], mu = mean[c], istd = invstd[c];
+    float dg = 0.f, db = 0.f;
+    if (dgamma) dg = dgamma[c];
+    if (dbeta) db = dbeta[c];
+    float v1[VT_STAT_REPLICAS], v2[VT_STAT_REPLICAS];
+#pragma unroll
     for (int r = 0; r < VT_STAT_REPLICAS; ++r) {
-        s1 += (double)sums[((long)r * 2 + 0) * C + c];
-        s2 += (double)sums[((long)r * 2 + 1) * C + c];
+        v1[r] = sums[((long)r * 2 + 0) * C + c];
+        v2[r] = sums[((long)r * 2 + 1) * C + c];
     }
-    if (dgamma) dgamma[c] += (float)(s2 * pscale);
-    if (dbeta) dbeta[c] += (float)(s1 * pscale);
-    const float a = scale[c];
+    double s1 = 0.0, s2 = 0.0, s1b = 0.0, s2b = 0.0;
+#pragma unroll
+    for (int r = 0; r < VT_STAT_REPLICAS; r += 2) {
+        s1 += (double)v1[r], s1b += (double)v1[r + 1];
+        s2 += (double)v2[r], s2b += (double)v2[r + 1];
+    }
+    s1 += s1b, s2 += s2b;
+    if (dgamma) dgamma[c] = dg + (float)(s2 * pscale);
+    if (dbeta) dbeta[c] = db + (float)(s1 * pscale);
     float b = 0.f, d = 0.f;
     if (train) {
-        const double c1 = s1 / count, c2 = s2 / count;
-        const double bb = (double)a * c2 * (double)invstd[c];
+        const double c1 = s1 * inv_count, c2 = s2 * inv_count;
+        const double bb = (double)a * c2 * (double)istd;
         b = (float)bb;
-        d = (float)(bb * (double)mean[c] - (double)a * c1);
+        d = (float)(bb * (double)mu - (double)a * c1);
     }
     coef[c] = a;
     coef[C + c] = b;
@@ -951,8 +975,9 @@ int vt_bn_finalize(const float* stats, int32_t C, double count, const float* gam
                "vt_bn_finalize: bad argument");
     VT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), VT_ERR_INVALID,
                "vt_bn_finalize: running_mean/var must both be given or both NULL");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, C,
-                       count, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked,
+    const double unbias = count > 1.0 ? count / (count - 1.0) : 1.0;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, C,
+                       1.0 / count, unbias, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked,
                        scale, shift, mean, invstd);
     VT_CHECK_LAUNCH("vt_bn_finalize");
     return VT_OK;
@@ -1018,8 +1043,8 @@ int vt_bn_bwd_finalize(const float* sums, int32_t C, double count, double pscale
                        void* stream) {
     VT_REQUIRE(sums && scale && mean && invstd && coef && C > 0 && count > 0, VT_ERR_INVALID,
                "vt_bn_bwd_finalize: bad argument");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums,
-                       C, count, pscale, scale, mean, invstd, train, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums,
+                       C, 1.0 / count, pscale, scale, mean, invstd, train, dgamma, dbeta, coef);
     VT_CHECK_LAUNCH("vt_bn_bwd_finalize");
     return VT_OK;
 }

@@ -139,8 +139,9 @@ __global__ void __launch_bounds__(256, 2) stem_bwd_kernel(const SbArgs p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
 
-    uint4 vg[2][NIT], vz[2][NIT], vx[2];
-    bool ok[2][NIT];
+    constexpr int NPF = 4;  // steps of loads in flight: 2 workgroups x 4 x 9.2 KB per CU against ~2.5 us of loaded HBM latency
+    uint4 vg[NPF][NIT], vz[NPF][NIT], vx[NPF];
+    bool ok[NPF][NIT];
     auto issue = [&](auto slot_c, int s) {
         constexpr int slot = decltype(slot_c)::value;
 #pragma unroll
@@ -187,8 +188,12 @@ __global__ void __launch_bounds__(256, 2) stem_bwd_kernel(const SbArgs p) {
 
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    using S3 = std::integral_constant<int, 3>;
     issue(S0{}, 0);
     issue(S1{}, 1);
+    issue(S2{}, 2);
+    issue(S3{}, 3);
     __syncthreads();  // tiles zeroed, ring prologue visible
 
     auto step = [&](auto slot_c, int s) {
@@ -234,7 +239,7 @@ __global__ void __launch_bounds__(256, 2) stem_bwd_kernel(const SbArgs p) {
             const long P = Pbeg + p.halo + 64l * s + lane;
             *(uint4*)(sX + (((unsigned)(int)P & xmask) << 4)) = vx[slot];
         }
-        issue(slot_c, s + 2);
+        issue(slot_c, s + NPF);
         __syncthreads();
 
         // ---- MFMA: [g | z | one]^T x [filter-row fragments] over this wave's 32 positions ------------------
@@ -260,9 +265,11 @@ __global__ void __launch_bounds__(256, 2) stem_bwd_kernel(const SbArgs p) {
         }
     };
 
-    for (int s = 0; s < nsteps; s += 2) {
+    for (int s = 0; s < nsteps; s += NPF) {
         step(S0{}, s);
         if (s + 1 < nsteps) step(S1{}, s + 1);
+        if (s + 2 < nsteps) step(S2{}, s + 2);
+        if (s + 3 < nsteps) step(S3{}, s + 3);
     }
 
     // ---- results --------------------------------------------------------------------------------------------
