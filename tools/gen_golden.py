@@ -29,22 +29,54 @@ REF = Path("/root/reference")
 GOLDEN = ROOT / "tests" / "golden"
 
 
+_REF_MODULES: dict = {}  # the reference's modules, kept out of sys.modules between uses
+
+
+class reference_namespace:
+    """Inside the block `vision_toolbox` IS the unmodified reference package (behind the torchvision shim); outside
+    it the name is whatever it was before (this repo's package, in a pytest run: tests/test_checkpoint.py imports this
+    module in the middle of one, and the two packages share their import name)."""
+
+    @staticmethod
+    def _mine(k):
+        return k == "vision_toolbox" or k.startswith("vision_toolbox.")
+
+    def __enter__(self):
+        tv = types.ModuleType("torchvision")
+        ops = types.ModuleType("torchvision.ops")
+        ops.DeformConv2d = type("DeformConv2d", (nn.Module,), {})
+        tv.ops = ops
+        sys.modules.setdefault("torchvision", tv)
+        sys.modules.setdefault("torchvision.ops", ops)
+        self.saved = {k: sys.modules.pop(k) for k in list(sys.modules) if self._mine(k)}
+        if not _REF_MODULES:
+            pkg = types.ModuleType("vision_toolbox")
+            pkg.__path__ = [str(REF / "vision_toolbox")]
+            sub = types.ModuleType("vision_toolbox.backbones")
+            sub.__path__ = [str(REF / "vision_toolbox" / "backbones")]
+            _REF_MODULES["vision_toolbox"] = pkg
+            _REF_MODULES["vision_toolbox.backbones"] = sub
+        sys.modules.update(_REF_MODULES)
+        return self
+
+    def __exit__(self, *exc):
+        for k in [k for k in sys.modules if self._mine(k)]:
+            _REF_MODULES[k] = sys.modules.pop(k)
+        sys.modules.update(self.saved)
+        return False
+
+
+def ref_import(name: str):
+    """import a module of the unmodified reference, e.g. ref_import("vision_toolbox.necks")"""
+    with reference_namespace():
+        return importlib.import_module(name)
+
+
 def import_reference():
-    tv = types.ModuleType("torchvision")
-    ops = types.ModuleType("torchvision.ops")
-    ops.DeformConv2d = type("DeformConv2d", (nn.Module,), {})
-    tv.ops = ops
-    sys.modules.setdefault("torchvision", tv)
-    sys.modules.setdefault("torchvision.ops", ops)
-    pkg = types.ModuleType("vision_toolbox")
-    pkg.__path__ = [str(REF / "vision_toolbox")]
-    sub = types.ModuleType("vision_toolbox.backbones")
-    sub.__path__ = [str(REF / "vision_toolbox" / "backbones")]
-    sys.modules["vision_toolbox"] = pkg
-    sys.modules["vision_toolbox.backbones"] = sub
-    comp = importlib.import_module("vision_toolbox.components")
-    dk = importlib.import_module("vision_toolbox.backbones.darknet")
-    vv = importlib.import_module("vision_toolbox.backbones.vovnet")
+    with reference_namespace():
+        comp = importlib.import_module("vision_toolbox.components")
+        dk = importlib.import_module("vision_toolbox.backbones.darknet")
+        vv = importlib.import_module("vision_toolbox.backbones.vovnet")
     return comp, dk, vv
 
 

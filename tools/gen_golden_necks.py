@@ -15,10 +15,10 @@ import torch
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tools"))
-import gen_golden  # noqa: E402,F401  (installs the import shim for vision_toolbox.*)
+import gen_golden  # noqa: E402  (the import shim for the reference's vision_toolbox.*)
 from oracle import filler  # noqa: E402
 
-necks = importlib.import_module("vision_toolbox.necks")
+necks = gen_golden.ref_import("vision_toolbox.necks")
 GOLDEN = ROOT / "tests" / "golden"
 
 CASES = {  # name -> (kind, in_channels, out_channels, top_down, sizes(bottom first), batch)
