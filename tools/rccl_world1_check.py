@@ -1,0 +1,69 @@
+"""One rank, RCCL: the data-parallel schedule of TrainStep (cut launch lists, bucket all-reduces issued from the
+filter-gradient stream, SyncBatchNorm collectives between segments, broadcasts) run over a ONE-rank `nccl` process
+group on a one-GPU box, against the plain single-GPU schedule on the same data.  A one-rank all-reduce is the
+identity, so what this proves is that torch's RCCL process group accepts the calls where and how the trainer issues
+them (streams, async work handles, in-place views of the flat buffers) and that the cut schedule leaves the numbers
+alone -- not the exchange itself (gloo world-2: tests/test_distributed_cpu.py, tools/ddp_check.py).
+
+    python tools/rccl_world1_check.py [sync_bn=0|1]        (GPU box)"""
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path[:0] = [str(ROOT / "vision-toolbox_amd"), str(ROOT)]
+
+import torch
+import torch.distributed as dist
+
+from vision_toolbox import backbones
+from vision_toolbox.trainer import TrainStep
+
+
+def run(dp: bool, sync_bn: bool):
+    torch.manual_seed(0)
+    ts = TrainStep(backbones.darknet_yolov5n(), 16, 8, 64, torch.float32, lr=0.01, bucket_mb=0.25, sync_bn=sync_bn,
+                   use_graphs=os.environ.get("RCCL_CHECK_GRAPHS", "0") != "0")  # bench.py runs without graphs
+    if dp:
+        assert ts.bucketer is not None and len(ts.bucketer.buckets) > 2 and len(ts.bwd_cuts) > 2
+        ts.broadcast_parameters(0)
+    else:
+        assert ts.bucketer is None
+    g = torch.Generator().manual_seed(1)
+    losses = []
+    for _ in range(2):  # the toy problem amplifies run-to-run noise (atomics) quickly: compare early
+        x = torch.randn(8, 3, 64, 64, generator=g).cuda()
+        y = torch.randint(0, 16, (8,), generator=g).cuda()
+        ts.step(x, y)
+        losses.append(float(ts.loss()))
+    torch.cuda.synchronize()
+    return losses, ts.store.pflat.double().clone()
+
+
+def main():
+    sync_bn = len(sys.argv) > 1 and sys.argv[1] == "1"
+    ref_losses, ref_p = run(False, False)
+    again_losses, again_p = run(False, False)
+    nl = max(abs(a - b) for a, b in zip(again_losses, ref_losses))
+    npar = float((again_p - ref_p).norm() / ref_p.norm())
+    print(f"plain vs plain (run-to-run noise of the atomics): losses {nl:.2e}, params {npar:.2e}")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29633")
+    os.environ["VT_DP_WORLD1"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    losses, p = run(True, sync_bn)
+    dist.barrier()
+    dist.destroy_process_group()
+    dl = max(abs(a - b) for a, b in zip(losses, ref_losses))
+    dp = float((p - ref_p).norm() / ref_p.norm())
+    print(f"losses {losses} vs {ref_losses}: max diff {dl:.2e}; params rel diff {dp:.2e}")
+    # f32 on purpose: in bf16 the atomics' summation order flips a few roundings per run and the toy network (BatchNorm
+    # over 2x2 maps at batch 8) turns that into discrete 1e-4-sized classes of gradients; in f32 the run-to-run spread
+    # is ~3e-6, so 1e-4 separates "same numbers" from a stale or early collective
+    assert dl < 1e-4 and dp < 1e-4, "the one-rank RCCL schedule changed the numbers"
+    print("RCCL_WORLD1_OK")
+
+
+if __name__ == "__main__":
+    main()

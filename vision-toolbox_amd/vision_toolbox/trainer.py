@@ -21,6 +21,7 @@ cost of 134 small collectives per step.
 from __future__ import annotations
 
 import ctypes
+import os
 import math
 from typing import Optional
 
@@ -143,6 +144,10 @@ class TrainStep:
         self.world = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(process_group)
+        # a one-rank process group still takes the data-parallel schedule (cut lists, bucket collectives on the
+        # filter-gradient stream, broadcasts): how the RCCL path is exercised on a one-GPU box (tests)
+        self.dp = self.world > 1 or (os.environ.get("VT_DP_WORLD1", "0") != "0" and torch.distributed.is_available()
+                                     and torch.distributed.is_initialized())
         head = nn.Linear(backbone.get_last_out_channels(), num_classes)
         self.model = nn.Sequential(backbone, nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten(), head)
         self.model.train()
@@ -173,7 +178,7 @@ class TrainStep:
         # SyncBatchNorm, the reference recipe's setting (configs/base.yaml:22): batch statistics over
         # ALL ranks.  Off by default for the throughput metric: it adds two small,
         # strictly sequential collectives per unit (67 + 67 for CSPDarknet-53).
-        self.sync_bn = bool(sync_bn) and self.world > 1
+        self.sync_bn = bool(sync_bn) and self.dp
         b.bn_world = self.world if self.sync_bn else 1
         self.mix = bool(mix)  # MixUp / CutMix applied on device from a per-step parameter block
         x = b.input_images(batch_size, 3, image_size, image_size, mix=self.mix)
@@ -214,7 +219,7 @@ class TrainStep:
         self.bucketer = None
         self.bwd_cuts = [self.prog.n_bwd]  # op index after which each segment ends
         self.cut_buckets: list[list[int]] = [[]]
-        if self.world > 1:
+        if self.dp:
             buckets = plan_buckets(total, int(bucket_mb * (1 << 20)) // 4)
             self.bucketer = GradBucketer(self.gflat, buckets, self.pg)
             ready = [0] * len(buckets)  # last bwd op that writes into each bucket
@@ -303,7 +308,7 @@ class TrainStep:
     # -- data-parallel plumbing ----------------------------------------------------------------
     def broadcast_parameters(self, src: int = 0) -> None:
         """initial weights + buffers from rank `src` (what DDP's constructor does)."""
-        if self.world > 1:
+        if self.dp:
             # parameters, BatchNorm buffers (running statistics AND the int64 batch counters) and the optimiser's
             # momentum: a resumed run starts identical on every rank
             torch.distributed.broadcast(self.store.pflat, src, group=self.pg)
