@@ -325,6 +325,9 @@ def main():
                     help="run the step on a torch stream of this priority (-1 = high): the filter-gradient side "
                          "stream then only fills what the critical path leaves")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 child runs that measure `traffic`")
+    ap.add_argument("--steps-only", action="store_true",
+                    help="(profiling) run warm-up + timed steps and print their time; no roofline / baseline launches, so a "
+                         "rocprofv3 pass over this command counts the step's kernels and nothing else")
     ap.add_argument("--plan-only", action="store_true",
                     help="(tests) build the launch lists and the bucket plan on the CPU, run the first collectives "
                          "over the given backend and exit: exercises the N>1 launch path without a GPU")
@@ -411,6 +414,13 @@ def main():
     loss = ts.loss()
     assert N.launch_count() > launches0 and loss == loss, "HIP path did not run / loss is NaN"
 
+    if args.steps_only:
+        if rank == 0:
+            print(json.dumps({"steps_only": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(elapsed / args.steps * 1e3, 3), "final_loss": round(loss, 4)}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = args.batch * world * args.steps / elapsed

@@ -26,6 +26,42 @@ for grp in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAV
     echo "pmc $name exit $?"
 done
 
+# 4. HBM bytes of the WHOLE step: FETCH_SIZE and WRITE_SIZE over every kernel of `bench.py --steps-only` (1 warm-up + 3
+#    timed steps, nothing else launched), each counter in its own pass
+for grp in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/${TAG}_step_pmc_$grp" -- \
+        python3 "$ROOT/bench.py" --steps 3 --warmup 1 --steps-only --no-cpu-baseline --no-pmc > "$OUT/${TAG}_step_pmc_$grp.log" 2>&1
+    echo "step pmc $grp exit $?"
+done
+python3 - "$OUT" "$TAG" <<'EOF2'
+import csv, glob, json, sys
+from collections import defaultdict
+out, tag = sys.argv[1], sys.argv[2]
+res = {"steps_counted": 4, "note": "1 warm-up + 3 timed steps of bench.py --steps-only; FETCH_SIZE x2 (gfx950 reports half the bytes of wide reads), KB -> bytes"}
+per_kernel = defaultdict(lambda: [0.0, 0.0, 0])
+for grp, slot in (("FETCH_SIZE", 0), ("WRITE_SIZE", 1)):
+    try:
+        f = glob.glob(f"{out}/{tag}_step_pmc_{grp}/*/*counter_collection.csv")[0]
+    except IndexError:
+        res["error"] = f"no counter file for {grp}"
+        continue
+    tot = 0.0
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != grp:
+            continue
+        v = float(r["Counter_Value"]) * 1024 * (2 if grp == "FETCH_SIZE" else 1)
+        tot += v
+        k = r["Kernel_Name"].split("(")[0].split("<")[0][-60:]
+        per_kernel[k][slot] += v
+        per_kernel[k][2] += 1 if slot == 0 else 0
+    res[grp + "_bytes_per_step"] = tot / 4
+res["hbm_bytes_per_step"] = res.get("FETCH_SIZE_bytes_per_step", 0) + res.get("WRITE_SIZE_bytes_per_step", 0)
+res["by_kernel_GB_per_step"] = {k: [round(v[0] / 4e9, 3), round(v[1] / 4e9, 3), v[2] // 4] for k, v in
+                                sorted(per_kernel.items(), key=lambda kv: -(kv[1][0] + kv[1][1]))[:25]}
+json.dump(res, open(f"{out}/{tag}_step_hbm_bytes.json", "w"), indent=1)
+print(json.dumps({k: v for k, v in res.items() if k != "by_kernel_GB_per_step"}, indent=1))
+EOF2
+
 python3 - "$OUT" "$TAG" <<'EOF'
 import csv, glob, json, sys
 from collections import defaultdict

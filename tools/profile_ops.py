@@ -38,6 +38,7 @@ def main():
     p = ts.prog
     rows = []
     excess = []
+    algo_bytes = defaultdict(float)
     reps = 5
     for phase, ops, n in (("fwd", p.fwd_ops, p.n_fwd), ("bwd", p.bwd_ops, p.n_bwd)):
         for idx in range(n):
@@ -66,8 +67,17 @@ def main():
                 ideal = max(fl / 1.0e15, nb / 5.0e12) * 1e3  # ms: 1.0 PF/s practical MFMA, 5 TB/s HBM
                 work = f"{fl / ms / 1e9:7.1f} TF/s {nb / ms / 1e9:6.2f} TB/s ideal {ideal:6.3f} excess {ms - ideal:6.3f}"
                 excess.append((ms - ideal, phase, name, desc, ms, ideal))
-            elif kind == N.OP_BN_ACT_APPLY:
-                pass
+            # bytes this decomposition moves when every operand is read / written exactly once (bf16 activations)
+            if kind in (N.OP_CONV_IGEMM, N.OP_CONV_WGRAD):
+                algo_bytes[name] += nb
+            elif kind == N.OP_BN_ACT_APPLY:  # i: ldz ldr ldy C relu dtype | f: M ; ptr 3 = residual
+                algo_bytes[name] += 2.0 * op.f[0] * op.i[3] * (2 + (1 if op.ptr[3].base >= 0 else 0))
+            elif kind == N.OP_BN_BWD_REDUCE:  # i: lddy ldz C relu dtype | f: M
+                algo_bytes[name] += 2.0 * op.f[0] * op.i[2] * 2
+            elif kind == N.OP_BN_BWD_APPLY:  # i: lddy ldz lddz C relu dtype | f: M
+                algo_bytes[name] += 2.0 * op.f[0] * op.i[3] * 3
+            elif kind == N.OP_STEM_BWD_REDUCE:  # i: dtype B H W C ...
+                algo_bytes[name] += 2.0 * op.i[1] * op.i[2] * op.i[3] * (8 + 2 * op.i[4])
             rows.append((ms, phase, idx, name, desc, work))
     tot = defaultdict(float)
     for ms, phase, idx, name, desc, work in rows:
@@ -75,6 +85,8 @@ def main():
     print(f"{model} B={B}: {len(rows)} ops, sum {sum(r[0] for r in rows):.3f} ms (isolated, serial)")
     for (phase, name), v in sorted(tot.items(), key=lambda kv: -kv[1]):
         print(f"  {phase} {name:16s} {v:8.3f} ms")
+    print(f"-- bytes per step when every operand of this decomposition moves once: {sum(algo_bytes.values()) / 1e9:.2f} GB "
+          + ", ".join(f"{k} {v / 1e9:.2f}" for k, v in sorted(algo_bytes.items(), key=lambda kv: -kv[1])))
     print("-- conv ops by time")
     conv = [r for r in rows if r[3].startswith("conv")]
     for ms, phase, idx, name, desc, work in sorted(conv, key=lambda r: -r[0])[:top]:
