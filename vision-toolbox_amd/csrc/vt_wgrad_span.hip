@@ -96,10 +96,15 @@ constexpr int kDzSlot = 32 * 128;  // bytes: 32 positions x 64 channels
 // waves as the CU holds instead of giving each 4-wave group its own copy.
 // The four waves of tap group 0 bring in dz, those of group 1 the new x rows: one LDS-DMA
 // instruction and one position counter per wave and step.
-template <int FI, int FJ, int PD>
+// WIDE (64 x 64 tiles only): a wave owns ALL 64 output channels x 16 input channels (4 x 1 fragments) instead of
+// 32 x 32 (2 x 2).  Same accumulators, but 8 + 2*taps transposing reads per step instead of 4 + 4*taps: the 2 x 2
+// grid is LDS-read bound (8 waves x 24 reads x 4 cycles = 768 LDS cycles per step against 640 MFMA cycles per SIMD).
+template <int FI, int FJ, int PD, bool WIDE = false>
 __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
+    static_assert(!WIDE || (FI == 2 && FJ == 2), "WIDE is the 64 x 64 tile");
     constexpr int NS = PD + 1;
     constexpr int NI = 32 * FI, NC = 32 * FJ;
+    constexpr int WI = WIDE ? 2 * FI : FI, WJ = WIDE ? FJ / 2 : FJ;  // fragments per wave
     constexpr int TG = 5;  // taps per group (the second group owns 4)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sDz = smem;                  // [NS][32 rows][128 B]
@@ -109,6 +114,8 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tg = wave8 >> 2, wave = wave8 & 3;
     const int wn = wave >> 1, wc = wave & 1;
+    const int rbase = WIDE ? 0 : wn * 16 * FI;        // first output channel of this wave inside the tile
+    const int cbase = WIDE ? wave * 16 : wc * 16 * FJ;  // first input channel
     const int ntl = tg ? 9 - TG : TG;  // taps this wave owns
     const int tile_n = blockIdx.x % p.tiles_n, tile_c = blockIdx.x / p.tiles_n;
     const int n0 = tile_n * NI, c0 = tile_c * NC;
@@ -159,10 +166,10 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
     // 4g+e, e>=4 <-> 16+4g+(e-4), for BOTH operands.
     const int g = lane >> 4, u = lane & 15, q = u >> 2, pp = u & 3;
     const int rowlo = 4 * g + q;
-    unsigned a_off[FI];  // dz slot-relative byte offsets
+    unsigned a_off[WI];  // dz slot-relative byte offsets
 #pragma unroll
-    for (int i = 0; i < FI; ++i) {
-        const int ch = ((wn * 16 * FI + 16 * i) >> 3) + (pp >> 1);
+    for (int i = 0; i < WI; ++i) {
+        const int ch = ((rbase + 16 * i) >> 3) + (pp >> 1);
         a_off[i] = (unsigned)(rowlo * 128 + ((ch ^ (2 * ((rowlo >> 1) & 3))) << 4) + 8 * (pp & 1));
     }
     unsigned b_off[TG];  // ring-relative byte offsets of the j = 0 fragment at step 0, per owned tap
@@ -170,17 +177,17 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
     for (int tt = 0; tt < TG; ++tt) {
         const int t = min(tg * TG + tt, 8);
         const int row = rowlo + p.o[t];
-        const int ch = ((wc * 16 * FJ) >> 3) + (pp >> 1);
+        const int ch = (cbase >> 3) + (pp >> 1);
         b_off[tt] = (unsigned)(row * 128 + ((ch ^ (2 * ((row >> 1) & 3))) << 4) + 8 * (pp & 1));
     }
 
-    f32x4 acc[TG][FI][FJ];
+    f32x4 acc[TG][WI][WJ];
 #pragma unroll
     for (int t = 0; t < TG; ++t)
 #pragma unroll
-        for (int i = 0; i < FI; ++i)
+        for (int i = 0; i < WI; ++i)
 #pragma unroll
-            for (int j = 0; j < FJ; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < WJ; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- prologue: halo chunks (x waves), then PD steps ahead -----------------------------------
     if (tg)
@@ -205,9 +212,9 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
         if (s + PD < nsteps) VT_WS_ISSUE_STEP(nxt);
 
         const char* dzs = sDz + cur * kDzSlot;
-        bf16x8 af[FI];
+        bf16x8 af[WI];
 #pragma unroll
-        for (int i = 0; i < FI; ++i) {
+        for (int i = 0; i < WI; ++i) {
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(dzs + a_off[i]));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(dzs + a_off[i] + 16 * 128));
             af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -218,18 +225,18 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
             if (tt < ntl) {
                 const unsigned lo_o = (sb + b_off[tt]) & xmask;
                 const unsigned hi_o = (lo_o + 16u * 128u) & xmask;
-                bf16x8 bf[FJ];
+                bf16x8 bf[WJ];
 #pragma unroll
-                for (int j = 0; j < FJ; ++j) {
+                for (int j = 0; j < WJ; ++j) {
                     // the next 16 input channels sit one 32-byte group over: chunk index ^ 2
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sX + (lo_o ^ (32u * j))));
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sX + (hi_o ^ (32u * j))));
                     bf[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                 }
 #pragma unroll
-                for (int i = 0; i < FI; ++i)
+                for (int i = 0; i < WI; ++i)
 #pragma unroll
-                    for (int j = 0; j < FJ; ++j)
+                    for (int j = 0; j < WJ; ++j)
                         acc[tt][i][j] =
                             __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[tt][i][j], 0, 0, 0);
             }
@@ -250,13 +257,12 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
         __syncthreads();
         if (tt < ntl) {
 #pragma unroll
-            for (int i = 0; i < FI; ++i)
+            for (int i = 0; i < WI; ++i)
 #pragma unroll
-                for (int j = 0; j < FJ; ++j)
+                for (int j = 0; j < WJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        sAcc[tg * IMG + (wn * 16 * FI + 16 * i + 4 * g + r) * PITCH + wc * 16 * FJ + 16 * j + u] =
-                            acc[tt][i][j][r];
+                        sAcc[tg * IMG + (rbase + 16 * i + 4 * g + r) * PITCH + cbase + 16 * j + u] = acc[tt][i][j][r];
         }
         __syncthreads();
         const int nimg = (TG + tt < 9) ? 2 : 1;
@@ -270,18 +276,18 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
     }
 }
 
-template <int FI, int FJ>
+template <int FI, int FJ, bool WIDE = false>
 int launch_ws(const WsArgs& a, long split, hipStream_t st) {
     constexpr int PD = 2;
     const int rings = (PD + 1) * kDzSlot + a.RX * 128;
     const int image = 2 * 32 * FI * (32 * FJ + 4) * 4;
     const int smem = rings > image ? rings : image;
-    auto kern = wgrad_span_kernel<FI, FJ, PD>;
+    auto kern = wgrad_span_kernel<FI, FJ, PD, WIDE>;
     {
         const int rc = vt_raise_dynamic_lds((const void*)kern, 96 * 1024, "vt_conv_wgrad(span)");
         if (rc != VT_OK) return rc;
     }
-    vt_note_kernel("wgrad_span_kernel<%d,%d,%d>", FI, FJ, PD);
+    vt_note_kernel("wgrad_span_kernel<%d,%d,%d%s>", FI, FJ, PD, WIDE ? ",wide" : "");
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_n * a.tiles_c), (unsigned)split), dim3(512), smem, st, a);
     VT_CHECK_LAUNCH("vt_conv_wgrad(span)");
     return VT_OK;
@@ -348,7 +354,8 @@ int vt_wgrad_span_dispatch(const vt_conv_desc* d, const void* x, const void* dz,
     static const int ablate = getenv("VT_WGRAD_ABLATE") ? atoi(getenv("VT_WGRAD_ABLATE")) : 0;  // timing experiments
     a.ablate = ablate;
     hipStream_t st = (hipStream_t)stream;
-    if (FI == 2 && FJ == 2) return launch_ws<2, 2>(a, split, st);
+    static const int wide = getenv("VT_WGRAD_SPAN_WIDE") ? atoi(getenv("VT_WGRAD_SPAN_WIDE")) : 1;
+    if (FI == 2 && FJ == 2) return wide ? launch_ws<2, 2, true>(a, split, st) : launch_ws<2, 2>(a, split, st);
     if (FI == 2) return launch_ws<2, 1>(a, split, st);
     if (FJ == 2) return launch_ws<1, 2>(a, split, st);
     return launch_ws<1, 1>(a, split, st);

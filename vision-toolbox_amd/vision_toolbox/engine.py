@@ -583,7 +583,7 @@ class Builder:
 
         stem_fused = (self.stem_fused_bwd and track and padded and has_bn and not fused and residual is None and
                       not x.needs_grad and w.requires_grad and dt == N.VT_BF16 and Cout == 32 and k == 3 and s == 1 and
-                      pad == 1 and x.C == 8 and x.ld == 8)
+                      pad == 1 and x.C == 8 and x.ld == 8 and x.W <= 896 and B * (x.H + 1) * (x.W + 1) < 0x7fff0000)  # (ring in LDS)
         if track:
             tag = self.tag
             training = unit_training
