@@ -92,7 +92,7 @@ def test_forward_conv_at_batch_256_spot_checked_in_float64(layer):
     assert ((got - ref).abs() <= 1e-2 * ref.abs() + 2e-2).all()
 
 
-@pytest.mark.parametrize("layer", [(128, 128, 3, 1, 28), (32, 32, 3, 1, 112), (64, 128, 3, 2, 112)],
+@pytest.mark.parametrize("layer", [(128, 128, 3, 1, 28), (32, 32, 3, 1, 112), (64, 128, 3, 2, 112), (32, 64, 3, 2, 224)],
                          ids=lambda l: "x".join(map(str, l)))
 def test_filter_gradient_at_batch_256_linear_and_equal_to_cpu_autograd(layer):
     Cin, Cout, k, s, H = layer

@@ -45,6 +45,13 @@ CONV_CASES = [
     (2, 8, 32, 3, 1, 20, 13),  # RGB-stem shape class (one 16-byte pixel): vt_stem.hip in bf16
     (1, 8, 64, 3, 1, 9, 40),
     (3, 8, 24, 3, 1, 17, 17),
+    # 3x3 stride 2 on even maps, Wo = 28 / 36 / 29 / 32, one and two channel tiles: with lowered thresholds (see
+    # test_stride2_all_taps_filter_gradient_in_subprocess) the bf16 filter gradient runs as two all-taps launches over
+    # the row-parity views of x (vt_wgrad_span_s2_dispatch)
+    (2, 32, 64, 3, 2, 56, 56),
+    (2, 64, 128, 3, 2, 64, 72),
+    (1, 16, 24, 3, 2, 60, 58),
+    (3, 8, 16, 3, 2, 56, 64),
 ]
 
 
@@ -378,5 +385,23 @@ def test_conv_kernel_variants_in_subprocess(mode):
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     # the autouse fixture wants a launch from THIS process too
+    buf = torch.zeros(16, device="cuda")
+    N.check(N.lib().vt_memset(vp(buf), 0, 64, stream()))
+
+
+def test_stride2_all_taps_filter_gradient_in_subprocess():
+    """the stride-2 filter gradient as two all-taps launches over the row-parity views of x (vt_wgrad_span_s2_dispatch)
+    is taken from 100 output columns and 32 input channels up (the first stride-2 conv of the Darknets at 224 px:
+    test_fullsize_gpu.py covers that shape at batch 256).  VT_WGRAD_S2_MINW / _MINC are read once per process, so the
+    filter-gradient cases above (28 .. 36 output columns, 8 .. 64 channels, one and two channel tiles) are re-run in a
+    child process with the thresholds lowered."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, VT_WGRAD_S2_MINW="28", VT_WGRAD_S2_MINC="8")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, "-k", "test_conv_filter_gradient"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     buf = torch.zeros(16, device="cuda")
     N.check(N.lib().vt_memset(vp(buf), 0, 64, stream()))

@@ -51,7 +51,8 @@ for grp, slot in (("FETCH_SIZE", 0), ("WRITE_SIZE", 1)):
             continue
         v = float(r["Counter_Value"]) * 1024 * (2 if grp == "FETCH_SIZE" else 1)
         tot += v
-        k = r["Kernel_Name"].split("(")[0].split("<")[0][-60:]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        k = k.split("(")[0].split("<")[0][-48:]
         per_kernel[k][slot] += v
         per_kernel[k][2] += 1 if slot == 0 else 0
     res[grp + "_bytes_per_step"] = tot / 4

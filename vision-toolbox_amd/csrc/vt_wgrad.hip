@@ -314,6 +314,9 @@ __global__ void __launch_bounds__(256 * G) wgrad_kernel(const WgradArgs p) {
 // vt_wgrad_span.hip: stride-1 3x3 bf16 layers; -1 when it does not apply
 int vt_wgrad_span_dispatch(const vt_conv_desc* d, const void* x, const void* dz, float* dw, int32_t ldgw,
                            void* stream);
+// vt_wgrad_span.hip: stride-2 3x3 bf16 layers on even maps as two stride-1 launches over row-parity views
+int vt_wgrad_span_s2_dispatch(const vt_conv_desc* d, const void* x, const void* dz, float* dw, int32_t ldgw,
+                              void* stream);
 
 extern "C" int vt_conv_wgrad(const vt_conv_desc* d, const void* x, const void* dz, float* dw,
                              int32_t ldgw, void* stream) {
@@ -337,6 +340,10 @@ extern "C" int vt_conv_wgrad(const vt_conv_desc* d, const void* x, const void* d
                "vt_conv_wgrad: tensor exceeds 2^31 elements");
     {
         const int rc = vt_wgrad_span_dispatch(d, x, dz, dw, ldgw, stream);
+        if (rc >= 0) return rc;
+    }
+    {
+        const int rc = vt_wgrad_span_s2_dispatch(d, x, dz, dw, ldgw, stream);
         if (rc >= 0) return rc;
     }
 

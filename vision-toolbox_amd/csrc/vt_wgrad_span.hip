@@ -41,6 +41,10 @@ struct WsArgs {
     int tiles_n, tiles_c, chunk, ablate;
     unsigned magic_pw, magic_ph;  // ceil(2^32 / PW), ceil(2^32 / PH)  (PW, PH >= 2)
     short o[9];              // d_t - dmin
+    int ntaps, tgn;          // taps (<= 9) and how many of them the first tap group owns (<= 5)
+    long rowx;               // elements between image rows of x (W*ldx for a dense tensor; larger for a row-parity view)
+    int cblk, cin_dst;       // flush map (cblk > 0): input channel c -> destination tap map[t][c / cblk], channel c % cblk
+    signed char map[9][4];   // (-1: the column is dropped)
 };
 
 __device__ __attribute__((aligned(16))) unsigned int vt_ws_zero16[4];
@@ -116,7 +120,7 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
     const int wn = wave >> 1, wc = wave & 1;
     const int rbase = WIDE ? 0 : wn * 16 * FI;        // first output channel of this wave inside the tile
     const int cbase = WIDE ? wave * 16 : wc * 16 * FJ;  // first input channel
-    const int ntl = tg ? 9 - TG : TG;  // taps this wave owns
+    const int ntl = tg ? p.ntaps - p.tgn : p.tgn;  // taps this wave owns
     const int tile_n = blockIdx.x % p.tiles_n, tile_c = blockIdx.x / p.tiles_n;
     const int n0 = tile_n * NI, c0 = tile_c * NC;
     const long Pbeg = (long)blockIdx.y * p.chunk;
@@ -137,6 +141,7 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
     const bool col_ok = tg ? (srcc * 8 < NC && c0 + srcc * 8 < p.Cin) : (srcc * 8 < NI && n0 + srcc * 8 < p.Cout);
     const bf16_t* __restrict__ src_base = tg ? p.x + (c0 + srcc * 8) : p.dz + (n0 + srcc * 8);
     const int src_ld = tg ? p.ldx : p.ldy;
+    const long src_row = tg ? p.rowx : (long)p.W * p.ldy;
     Pos ps;
     long Ps = Pbeg + (tg ? p.dmin : 0) + 8 * wave + r8;  // this lane's stream position
     ps.init(Ps, p.S, p.PW);
@@ -146,8 +151,8 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
 #define VT_WS_ISSUE(dst)                                                                          \
     do {                                                                                          \
         const bool ok = col_ok && (tg || Ps < Pend) && (unsigned)ps.b < (unsigned)p.B && ps.i < p.H && ps.j < p.W; \
-        const long pix = ((long)ps.b * p.H + ps.i) * p.W + ps.j;                                  \
-        glds16(ok ? (unsigned long)(src_base + pix * src_ld) : zero_src, (dst) + (unsigned)wave * 1024u); \
+        const long eoff = ((long)ps.b * p.H + ps.i) * src_row + (long)ps.j * src_ld;             \
+        glds16(ok ? (unsigned long)(src_base + eoff) : zero_src, (dst) + (unsigned)wave * 1024u); \
         ++nissued;                                                                                \
         Ps += 32;                                                                                 \
         ps.advance32(p.PH, p.PW, p.magic_pw, p.magic_ph);                                         \
@@ -175,7 +180,7 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
     unsigned b_off[TG];  // ring-relative byte offsets of the j = 0 fragment at step 0, per owned tap
 #pragma unroll
     for (int tt = 0; tt < TG; ++tt) {
-        const int t = min(tg * TG + tt, 8);
+        const int t = min(tg * p.tgn + tt, p.ntaps - 1);
         const int row = rowlo + p.o[t];
         const int ch = (cbase >> 3) + (pp >> 1);
         b_off[tt] = (unsigned)(row * 128 + ((ch ^ (2 * ((row >> 1) & 3))) << 4) + 8 * (pp & 1));
@@ -265,13 +270,22 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
                         sAcc[tg * IMG + (rbase + 16 * i + 4 * g + r) * PITCH + cbase + 16 * j + u] = acc[tt][i][j][r];
         }
         __syncthreads();
-        const int nimg = (TG + tt < 9) ? 2 : 1;
+        const int nimg = (tt < p.tgn ? 1 : 0) + (p.tgn + tt < p.ntaps ? 1 : 0);  // (tt >= tgn: nothing; group 1 never owns more)
+        if (tt >= p.tgn) continue;
         for (int idx = tid; idx < nimg * NI * NC; idx += 512) {
             const int img = idx / (NI * NC), e = idx % (NI * NC);
             const int n = e / NC, c = e % NC;
-            const int t = img * TG + tt;
-            if (n0 + n < p.Cout && c0 + c < p.Cin && !p.ablate)
-                atomicAdd(p.dw + ((long)(n0 + n) * p.ldgw + (long)t * p.Cin + c0 + c), sAcc[img * IMG + n * PITCH + c]);
+            const int t = img * p.tgn + tt;
+            if (n0 + n < p.Cout && c0 + c < p.Cin && !p.ablate) {
+                long col = (long)t * p.Cin + c0 + c;
+                if (p.cblk) {
+                    const int blk = (c0 + c) / p.cblk;
+                    const int td = p.map[t][blk];
+                    if (td < 0) continue;
+                    col = (long)td * p.cin_dst + (c0 + c - blk * p.cblk);
+                }
+                atomicAdd(p.dw + ((long)(n0 + n) * p.ldgw + col), sAcc[img * IMG + n * PITCH + c]);
+            }
         }
     }
 }
@@ -293,53 +307,33 @@ int launch_ws(const WsArgs& a, long split, hipStream_t st) {
     return VT_OK;
 }
 
-}  // namespace
-
-// returns -1 when this kernel does not apply (the caller then uses the general kernel)
-int vt_wgrad_span_dispatch(const vt_conv_desc* d, const void* x, const void* dz, float* dw, int32_t ldgw,
-                           void* stream) {
-    static const int enabled = getenv("VT_WGRAD_SPAN") ? atoi(getenv("VT_WGRAD_SPAN")) : 1;
-    if (!enabled) return -1;
-    if (d->dtype != VT_BF16 || d->ntaps != 9 || d->sh != 1 || d->sw != 1 || d->Ho != d->Hi || d->Wo != d->Wi)
-        return -1;
-    // 14x14 and 7x7 maps with wide layers: the padded enumeration costs 15-30 % extra MFMA work and
-    // the general kernel's operands stay L2 resident there (measured 97 vs 115 us at 256ch 14x14)
-    if (enabled < 2 && d->Wi < 20 && d->Cin > 64 && d->Cout > 64) return -1;
-    int ph = 0, pw = 0;
-    for (int t = 0; t < 9; ++t) {
-        const int eh = d->h0 + d->dh[t], ew = d->w0 + d->dw[t];
-        ph = abs(eh) > ph ? abs(eh) : ph;
-        pw = abs(ew) > pw ? abs(ew) : pw;
-    }
-    WsArgs a;
-    memset(&a, 0, sizeof(a));
-    a.x = (const bf16_t*)x, a.dz = (const bf16_t*)dz, a.dw = dw;
-    a.B = d->B, a.H = d->Hi, a.W = d->Wi, a.Cin = d->Cin, a.ldx = d->ldx, a.Cout = d->Cout, a.ldy = d->ldy;
-    a.ldgw = ldgw;
-    a.PH = d->Hi + ph, a.PW = d->Wi + pw;
+// ring geometry, pixel split and launch for a filled-in WsArgs (x, dz, dw, B, H, W, Cin, ldx, Cout, ldy, ldgw, rowx, PH, PW
+// and the flush map are set); eh/ew = tap offsets in the position grid.  -1 when the ring would not fit.
+int launch_ws_taps(WsArgs& a, int ntaps, const int* eh, const int* ew, hipStream_t st) {
     a.S = a.PH * a.PW;
     a.magic_pw = (unsigned)((0x100000000ull + a.PW - 1) / a.PW);
     a.magic_ph = (unsigned)((0x100000000ull + a.PH - 1) / a.PH);
-    const long NP = (long)d->B * a.S;
-    if (NP > 0x7ffffff0L) return -1;
+    const long NP = (long)a.B * a.S;
+    if (NP > 0x7ffffff0L || a.PW < 2 || a.PH < 2) return -1;
     a.NP = (int)NP;
+    a.ntaps = ntaps, a.tgn = (ntaps + 1) / 2;
     int dmin = 1 << 30, dmax = -(1 << 30), off[9];
-    for (int t = 0; t < 9; ++t) {
-        off[t] = (d->h0 + d->dh[t]) * a.PW + (d->w0 + d->dw[t]);
+    for (int t = 0; t < ntaps; ++t) {
+        off[t] = eh[t] * a.PW + ew[t];
         dmin = off[t] < dmin ? off[t] : dmin;
         dmax = off[t] > dmax ? off[t] : dmax;
     }
     a.dmin = dmin;
-    for (int t = 0; t < 9; ++t) a.o[t] = (short)(off[t] - dmin);
+    for (int t = 0; t < 9; ++t) a.o[t] = (short)(off[t < ntaps ? t : ntaps - 1] - dmin);
     constexpr int PD = 2;
     a.NH = (31 + dmax - dmin) / 32;
     int rx = 64;
     while (rx < 32 * (a.NH + PD + 1)) rx *= 2;
     if (rx > 512) return -1;  // wide maps: the ring would not leave room for two workgroups per CU
     a.RX = rx;
-    const int FI = d->Cout > 32 ? 2 : 1, FJ = d->Cin > 32 ? 2 : 1;
-    a.tiles_n = (d->Cout + 32 * FI - 1) / (32 * FI);
-    a.tiles_c = (d->Cin + 32 * FJ - 1) / (32 * FJ);
+    const int FI = a.Cout > 32 ? 2 : 1, FJ = a.Cin > 32 ? 2 : 1;
+    a.tiles_n = (a.Cout + 32 * FI - 1) / (32 * FI);
+    a.tiles_c = (a.Cin + 32 * FJ - 1) / (32 * FJ);
     // pixel split: one 8-wave workgroup per CU, at least 16 steps each (the halo warm-up is NH chunks)
     static const int target = getenv("VT_WGRAD_SPAN_TARGET") ? atoi(getenv("VT_WGRAD_SPAN_TARGET")) : 256;
     const long tiles = (long)a.tiles_n * a.tiles_c;
@@ -353,10 +347,93 @@ int vt_wgrad_span_dispatch(const vt_conv_desc* d, const void* x, const void* dz,
     a.chunk = (int)chunk;
     static const int ablate = getenv("VT_WGRAD_ABLATE") ? atoi(getenv("VT_WGRAD_ABLATE")) : 0;  // timing experiments
     a.ablate = ablate;
-    hipStream_t st = (hipStream_t)stream;
     static const int wide = getenv("VT_WGRAD_SPAN_WIDE") ? atoi(getenv("VT_WGRAD_SPAN_WIDE")) : 1;
     if (FI == 2 && FJ == 2) return wide ? launch_ws<2, 2, true>(a, split, st) : launch_ws<2, 2>(a, split, st);
     if (FI == 2) return launch_ws<2, 1>(a, split, st);
     if (FJ == 2) return launch_ws<1, 2>(a, split, st);
     return launch_ws<1, 1>(a, split, st);
+}
+
+}  // namespace
+
+// returns -1 when this kernel does not apply (the caller then uses the general kernel)
+int vt_wgrad_span_dispatch(const vt_conv_desc* d, const void* x, const void* dz, float* dw, int32_t ldgw,
+                           void* stream) {
+    static const int enabled = getenv("VT_WGRAD_SPAN") ? atoi(getenv("VT_WGRAD_SPAN")) : 1;
+    if (!enabled) return -1;
+    if (d->dtype != VT_BF16 || d->ntaps != 9 || d->sh != 1 || d->sw != 1 || d->Ho != d->Hi || d->Wo != d->Wi)
+        return -1;
+    // 14x14 and 7x7 maps with wide layers: the padded enumeration costs 15-30 % extra MFMA work and
+    // the general kernel's operands stay L2 resident there (measured 97 vs 115 us at 256ch 14x14)
+    if (enabled < 2 && d->Wi < 20 && d->Cin > 64 && d->Cout > 64) return -1;
+    int ph = 0, pw = 0, eh[9], ew[9];
+    for (int t = 0; t < 9; ++t) {
+        eh[t] = d->h0 + d->dh[t], ew[t] = d->w0 + d->dw[t];
+        ph = abs(eh[t]) > ph ? abs(eh[t]) : ph;
+        pw = abs(ew[t]) > pw ? abs(ew[t]) : pw;
+    }
+    WsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = (const bf16_t*)x, a.dz = (const bf16_t*)dz, a.dw = dw;
+    a.B = d->B, a.H = d->Hi, a.W = d->Wi, a.Cin = d->Cin, a.ldx = d->ldx, a.Cout = d->Cout, a.ldy = d->ldy;
+    a.ldgw = ldgw;
+    a.rowx = (long)d->Wi * d->ldx;
+    a.PH = d->Hi + ph, a.PW = d->Wi + pw;
+    return launch_ws_taps(a, 9, eh, ew, (hipStream_t)stream);
+}
+
+// Filter gradient of a 3x3 STRIDE-2 convolution (the first conv of every Darknet / CSPDarknet stage,
+// darknet.py:33 / :43) on the all-taps kernel.  With an even map the input is, without moving a byte,
+//   X_even[b][i][j][(b', c)] = x[b][2i  ][2j + b'][c]      X_odd[b][i][j][(b', c)] = x[b][2i+1][2j + b'][c]
+// (pixel pairs = 2*Cin contiguous channels; rows two image rows apart), and output pixel (i, j) reads
+//   filter row 1 from X_even(i, j-1 .. j),   rows 0 / 2 from X_odd(i-1, j-1 .. j) / X_odd(i, j-1 .. j):
+// two stride-1 launches (2 and 4 taps over 2*Cin channels) whose columns are scattered to the 9 x Cin
+// filter taps by the flush map; of the (tap, pixel-half) pairs those that fall on pixel 2j-2 are dropped
+// (25 % of the MFMA work).  The general kernel gives each 128-column slice of the 9*Cin columns its own
+// workgroups and 128 output channels per tile: at 32 -> 64 channels it fetched 2.6 GB for 1.2 GB of operands.
+int vt_wgrad_span_s2_dispatch(const vt_conv_desc* d, const void* x, const void* dz, float* dw, int32_t ldgw,
+                              void* stream) {
+    // Measured (CSPDarknet-53 / VoVNet-39 steps): per 32-position step the all-taps kernel costs ~0.55 us whatever the
+    // tap count, so two launches of 2 and 4 taps only match the general kernel's time where that one is at its worst
+    // (32 -> 64 @224->112: 0.49 vs 0.47 ms alone, but 1.6 instead of 2.6 GB fetched: -0.1 ms per step beside the
+    // HBM-bound BatchNorm passes); at 64 -> 128 @112->56 it is 0.44 vs 0.29 ms, on the 8-channel VoVNet stem slower too.
+    static const int minw = getenv("VT_WGRAD_S2_MINW") ? atoi(getenv("VT_WGRAD_S2_MINW")) : 100;
+    static const int minc = getenv("VT_WGRAD_S2_MINC") ? atoi(getenv("VT_WGRAD_S2_MINC")) : 32;
+    if (d->Cin < minc) return -1;
+    if (minw <= 0 || d->dtype != VT_BF16 || d->ntaps != 9 || d->sh != 2 || d->sw != 2 || d->h0 != -1 || d->w0 != -1)
+        return -1;
+    if (d->Hi % 2 || d->Wi % 2 || d->Ho != d->Hi / 2 || d->Wo != d->Wi / 2 || d->Wo < minw) return -1;
+    if (d->ldx != d->Cin || d->Cin % 8 || d->Cin > 127) return -1;  // pixel pairs must be contiguous; cblk fits the map
+    for (int t = 0; t < 9; ++t)
+        if (d->dh[t] != t / 3 || d->dw[t] != t % 3) return -1;
+    WsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dz = (const bf16_t*)dz, a.dw = dw;
+    a.B = d->B, a.H = d->Ho, a.W = d->Wo, a.Cin = 2 * d->Cin, a.ldx = 2 * d->ldx, a.Cout = d->Cout, a.ldy = d->ldy;
+    a.ldgw = ldgw;
+    a.rowx = 2L * d->Wi * d->ldx;
+    a.cblk = d->Cin, a.cin_dst = d->Cin;
+    memset(a.map, -1, sizeof(a.map));
+    // odd rows: filter rows 0 (grid row i-1) and 2 (grid row i)
+    {
+        WsArgs o = a;
+        o.x = (const bf16_t*)x + (long)d->Wi * d->ldx;
+        o.PH = o.H + 1, o.PW = o.W + 1;
+        o.map[0][1] = 0, o.map[1][0] = 1, o.map[1][1] = 2;
+        o.map[2][1] = 6, o.map[3][0] = 7, o.map[3][1] = 8;
+        const int eh[4] = {-1, -1, 0, 0}, ew[4] = {-1, 0, -1, 0};
+        const int rc = launch_ws_taps(o, 4, eh, ew, (hipStream_t)stream);
+        if (rc != VT_OK) return rc;  // (-1 before anything was launched: the caller falls back; this launch has the larger ring)
+    }
+    // even rows: filter row 1.  tap 0 = (0, -1): pixel half 1 is column q = 0; tap 1 = (0, 0): halves 0 / 1 are q = 1 / 2
+    {
+        WsArgs e = a;
+        e.x = (const bf16_t*)x;
+        e.PH = e.H, e.PW = e.W + 1;
+        e.map[0][1] = 3, e.map[1][0] = 4, e.map[1][1] = 5;
+        const int eh[2] = {0, 0}, ew[2] = {-1, 0};
+        const int rc = launch_ws_taps(e, 2, eh, ew, (hipStream_t)stream);
+        if (rc != VT_OK) return rc == -1 ? VT_ERR_UNSUPPORTED : rc;  // the odd rows are already in dw
+    }
+    return VT_OK;
 }
