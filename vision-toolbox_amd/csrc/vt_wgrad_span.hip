@@ -29,6 +29,10 @@
 
 #include "vt_common.h"
 
+#ifndef VT_WS_PD
+#define VT_WS_PD 2
+#endif
+
 namespace {
 
 struct WsArgs {
@@ -206,12 +210,14 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
         // dz(s) and x chunk s+NH must have landed; the PD-1 younger steps (1 instruction per wave
         // each) may stay in flight
         const int younger = min(PD - 1, nsteps - 1 - s);
-        if (younger >= 2)
-            vm_wait<2>();
-        else if (younger == 1)
-            vm_wait<1>();
-        else
-            vm_wait<0>();
+        switch (younger) {  // (the count is an immediate of s_waitcnt)
+            case 0: vm_wait<0>(); break;
+            case 1: vm_wait<1>(); break;
+            case 2: vm_wait<2>(); break;
+            case 3: vm_wait<3>(); break;
+            case 4: vm_wait<4>(); break;
+            default: vm_wait<5>(); break;
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (s + PD < nsteps) VT_WS_ISSUE_STEP(nxt);
@@ -290,9 +296,16 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
     }
 }
 
+// Steps of LDS-DMA in flight per wave (-DVT_WS_PD=2..6).  Measured 2 .. 6 on 128->128 @28/56, 64->64 @56, 32->32 @112 and
+// the stride-2 views: no difference (0.124 / 0.337 / 0.126 / 0.235 ms at every depth), i.e. the 0.76 us step (a third
+// of the MFMA rate) is not memory latency: fragment reads and MFMAs of a wave run back to back and the two waves of a
+// SIMD sit in the same phase (one barrier per step) -- the cure is the two-tick schedule of vt_igemm_span6.hip.
+constexpr int kWsPD = VT_WS_PD;
+static_assert(kWsPD >= 2 && kWsPD <= 6, "vm_wait switch covers PD - 1 <= 5");
+
 template <int FI, int FJ, bool WIDE = false>
 int launch_ws(const WsArgs& a, long split, hipStream_t st) {
-    constexpr int PD = 2;
+    constexpr int PD = kWsPD;
     const int rings = (PD + 1) * kDzSlot + a.RX * 128;
     const int image = 2 * 32 * FI * (32 * FJ + 4) * 4;
     const int smem = rings > image ? rings : image;
@@ -325,7 +338,7 @@ int launch_ws_taps(WsArgs& a, int ntaps, const int* eh, const int* ew, hipStream
     }
     a.dmin = dmin;
     for (int t = 0; t < 9; ++t) a.o[t] = (short)(off[t < ntaps ? t : ntaps - 1] - dmin);
-    constexpr int PD = 2;
+    constexpr int PD = kWsPD;
     a.NH = (31 + dmax - dmin) / 32;
     int rx = 64;
     while (rx < 32 * (a.NH + PD + 1)) rx *= 2;
