@@ -298,8 +298,10 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
 
 // Steps of LDS-DMA in flight per wave (-DVT_WS_PD=2..6).  Measured 2 .. 6 on 128->128 @28/56, 64->64 @56, 32->32 @112 and
 // the stride-2 views: no difference (0.124 / 0.337 / 0.126 / 0.235 ms at every depth), i.e. the 0.76 us step (a third
-// of the MFMA rate) is not memory latency: fragment reads and MFMAs of a wave run back to back and the two waves of a
-// SIMD sit in the same phase (one barrier per step) -- the cure is the two-tick schedule of vt_igemm_span6.hip.
+// of the MFMA rate) is not memory latency.  Also measured and dropped: a two-tick schedule (tap group 0 reads its fragments
+// while group 1 multiplies the previous step from registers, then the reverse; two barriers per step): 0.180 instead of
+// 0.125 ms at 128->128 @28x28, 0.526 instead of 0.334 at @56x56 -- the hardware already overlaps one wave's LDS reads
+// with the other's MFMAs, and the second barrier costs ~0.45 us per step.
 constexpr int kWsPD = VT_WS_PD;
 static_assert(kWsPD >= 2 && kWsPD <= 6, "vm_wait switch covers PD - 1 <= 5");
 
