@@ -50,7 +50,7 @@ def conv_roofline(B, C, HW, dtype_id, iters=30, warmup=10, k=3, Cout=None):
     x = torch.randn(B, HW, HW, C, device=dev).to(torch.bfloat16)
     w = (torch.randn(Cout, k, k, C, device=dev) * (2.0 / (k * k * C)) ** 0.5).to(torch.bfloat16)
     y = torch.empty(B, HW, HW, Cout, device=dev, dtype=torch.bfloat16)
-    stats = torch.zeros(N.VT_STAT_REPLICAS, 2, Cout, device=dev)
+    stats = N.stats_buffer(Cout)
     d = N.ConvDesc()
     d.dtype = dtype_id
     d.B, d.Hi, d.Wi, d.Cin, d.ldx = B, HW, HW, C, C

@@ -54,7 +54,13 @@ extern "C" {
                             * gradient of a 3x3 stride-2 convolution (the four parity classes as column blocks of a
                             * 2x2-tap filter image, zero where a class has no tap) and reads dz once. */
 
-#define VT_STAT_REPLICAS 32 /* stats buffers are float[VT_STAT_REPLICAS][2][C]  */
+#define VT_STAT_REPLICAS 32
+/* A statistics buffer (`stats` of vt_conv_igemm, `sums` of the BatchNorm-backward reductions) is
+ * int64[VT_STAT_REPLICAS][2][C][2], VT_STAT_BYTES(C) bytes, zeroed by the caller and passed as float*: fixed point,
+ * value = hi*2^12 + lo/2^33, accumulated with integer atomics.  Integer addition is associative, so the statistics --
+ * and with them every activation, loss and data gradient -- are bit-identical from run to run;
+ * vt_bn_finalize / vt_bn_bwd_finalize sum the replicas exactly.  SyncBatchNorm all-reduces the buffer as int64. */
+#define VT_STAT_BYTES(C) ((int64_t)VT_STAT_REPLICAS * 2 * (C) * 16)
 
 /*
  * Geometry of one implicit-GEMM convolution launch.  One descriptor covers the
@@ -98,7 +104,7 @@ int vt_memset(void* ptr, int value, uint64_t bytes, void* stream);
  * it (components.py:36-44) and DarknetBlock's add (darknet.py:28).  With
  * VT_CONV_STATS it also produces the batch statistics BatchNorm2d needs in
  * training mode.  The same entry point computes conv data gradients.
- * `stats` is float[VT_STAT_REPLICAS][2][Cout], zeroed by the caller. */
+ * `stats` is a statistics buffer of VT_STAT_BYTES(Cout) bytes (see VT_STAT_REPLICAS), zeroed by the caller. */
 int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w, void* y,
                   const float* scale, const float* shift, const void* residual,
                   float* stats, void* stream);
@@ -132,7 +138,7 @@ int vt_bn_eval_coeffs(const float* gamma, const float* beta, const float* runnin
 int vt_bn_act_apply(const void* z, int32_t ldz, const float* scale, const float* shift,
                     const void* residual, int32_t ldr, void* y, int32_t ldy, int64_t M,
                     int32_t C, int32_t relu, int32_t dtype, void* stream);
-/* sums[rep][0][c] += sum g, sums[rep][1][c] += sum g*xhat, g = dy*[z*scale+shift>0] */
+/* sums (statistics buffer, see VT_STAT_REPLICAS): [0][c] += sum g, [1][c] += sum g*xhat, g = dy*[z*scale+shift>0] */
 int vt_bn_act_bwd_reduce(const void* dy, int32_t lddy, const void* z, int32_t ldz,
                          const float* scale, const float* shift, const float* mean,
                          const float* invstd, int64_t M, int32_t C, int32_t relu,
@@ -155,7 +161,7 @@ int vt_bn_act_bwd_apply(const void* dy, int32_t lddy, const void* z, int32_t ldz
  * (darknet.py:75 `ConvNormAct(3, 32, 3, 1)`; autograd backward of components.py:26-44 with respect to the
  * conv weight and the BatchNorm parameters -- the unit's input is the image, no data gradient exists).
  * vt_stem_bn_bwd_reduce reads x [B*H*W][8] (3 real channels), dy and z ONCE and accumulates
- *   sums  float[VT_STAT_REPLICAS][2][C]  as vt_bn_act_bwd_reduce, and
+ *   sums  (a statistics buffer, see VT_STAT_REPLICAS) as vt_bn_act_bwd_reduce, and
  *   gzx   float[vt_stem_bn_bwd_scratch_bytes(C) / 4]: the correlations of g, z and 1 with the tap-shifted x
  * (both zeroed by the caller); after vt_bn_bwd_finalize, vt_stem_bn_bwd_combine adds
  *   dw[n][t][c] += coef0[n]*G - coef1[n]*Z + coef2[n]*X,  dw float[C][9][cin]

@@ -60,7 +60,7 @@ def test_forward_conv_at_batch_256_spot_checked_in_float64(layer):
     w = _rand((Cout, k, k, Cin), (2.0 / (Cin * k * k)) ** 0.5, 2)
     Ho = (H + 2 * pad - k) // s + 1
     y = torch.full((B, Ho, Ho, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
-    stats = torch.zeros(N.VT_STAT_REPLICAS, 2, Cout, device="cuda")
+    stats = N.stats_buffer(Cout)
     d = conv_desc(N.VT_BF16, x, Cin, Cout, k, s, pad, Cout, flags=N.VT_CONV_STATS)
     before = N.launch_count()
     N.check(N.lib().vt_conv_igemm(C.byref(d), vp(x), vp(w), vp(y), None, None, None, vp(stats), stream()))
@@ -68,7 +68,7 @@ def test_forward_conv_at_batch_256_spot_checked_in_float64(layer):
     assert N.launch_count() > before
     assert torch.isfinite(y.float()).all()
     # checksum over every output: the epilogue's statistics are those of the stored values
-    st = stats.double().sum(0)
+    st = N.stats_decode(stats)
     yy = y.double().reshape(-1, Cout)
     np.testing.assert_allclose(st[0].cpu(), yy.sum(0).cpu(), rtol=2e-4, atol=2e-2 * (yy.shape[0] ** 0.5))
     np.testing.assert_allclose(st[1].cpu(), (yy * yy).sum(0).cpu(), rtol=2e-4)

@@ -70,14 +70,14 @@ def test_conv_forward_and_stats(dtype, case):
     xd, wd = nhwc(x, dtype), krsc(w, dtype)
     Ho, Wo = ref.shape[2:]
     y = torch.full((B, Ho, Wo, Cout), float("nan"), device="cuda", dtype=TD[dtype])
-    stats = torch.zeros(N.VT_STAT_REPLICAS, 2, Cout, device="cuda")
+    stats = N.stats_buffer(Cout)
     d = conv_desc(dtype, xd, Cin, Cout, k, s, pad, Cout, flags=N.VT_CONV_STATS)
     N.check(N.lib().vt_conv_igemm(C.byref(d), vp(xd), vp(wd), vp(y), None, None, None, vp(stats), stream()))
     got = to_nchw(y)
     assert torch.isfinite(got).all()
     assert rel_err(got, ref) < tol(dtype)
     # statistics are those of the values actually stored
-    st = stats.double().sum(0).cpu()
+    st = N.stats_decode(stats).cpu()
     yy = y.double().reshape(-1, Cout).cpu()
     np.testing.assert_allclose(st[0], yy.sum(0), rtol=1e-4, atol=1e-3)
     np.testing.assert_allclose(st[1], (yy * yy).sum(0), rtol=1e-4, atol=1e-3)
@@ -161,10 +161,10 @@ def test_batchnorm_relu_forward_backward_chain(dtype, shape):
     y_ref.backward(dy)
 
     zd, rd, dyd = nhwc(z0, dtype), nhwc(res, dtype), nhwc(dy, dtype)
-    stats = torch.zeros(N.VT_STAT_REPLICAS, 2, Cc, device="cuda")
+    stats = N.stats_buffer(Cc)
     zz = zd.float().reshape(-1, Cc)
-    stats[3, 0], stats[3, 1] = zz.sum(0), (zz * zz).sum(0)
-    stats[7, 0] += 0.0
+    N.stats_encode(stats, 0, zz.sum(0), replica=3)  # (any replica: the finalize kernel sums them all)
+    N.stats_encode(stats, 1, (zz * zz).sum(0), replica=7)
     g, b_ = gamma.detach().cuda(), beta.detach().cuda()
     rmd, rvd = rm.cuda(), rv.cuda()
     nbt = torch.zeros(2, dtype=torch.int64, device="cuda")
@@ -178,7 +178,7 @@ def test_batchnorm_relu_forward_backward_chain(dtype, shape):
     np.testing.assert_allclose(rmd.cpu(), rm_ref, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(rvd.cpu(), rv_ref, rtol=1e-4, atol=1e-6)
     assert nbt[0].item() == 1
-    sums = torch.zeros(N.VT_STAT_REPLICAS, 2, Cc, device="cuda")
+    sums = N.stats_buffer(Cc)
     N.check(L.vt_bn_act_bwd_reduce(vp(dyd), Cc, vp(zd), Cc, vp(coef[0]), vp(coef[1]), vp(coef[2]), vp(coef[3]),
                                    M, Cc, 1, dtype, vp(sums), stream()))
     dg, db = torch.ones(Cc, device="cuda"), torch.ones(Cc, device="cuda")

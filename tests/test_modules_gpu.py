@@ -246,6 +246,37 @@ def test_model_bf16_tracks_reference(name, golden_dir):
     assert np.median(np.abs(got[big] / norms[big] - 1)) < 0.15
 
 
+@pytest.mark.parametrize("name", ["vovnet39", "cspdarknet53"])
+def test_training_pass_is_bit_reproducible_up_to_the_filter_gradients(name):
+    """BatchNorm statistics and backward sums are 64-bit fixed-point integer atomics (vt_common.h): every activation,
+    the loss, the data gradients and the BatchNorm parameter gradients must be BIT-IDENTICAL from run to run (with f32
+    atomics this toy VoVNet-39 fell into two classes 12 % apart at the last feature map).  Only the conv filter
+    gradients still go through f32 atomics (split over pixel ranges): equal to ~1e-6."""
+    runs = []
+    for _ in range(4):
+        model = _classifier(name, torch.bfloat16)
+        model.train()
+        x = filler.images(4, 64).cuda().requires_grad_(True)
+        y = filler.labels(4, 16).cuda()
+        maps = model[0].get_feature_maps(x)
+        logits = model[3](model[2](model[1](maps[-1].float())))
+        loss = F.cross_entropy(logits, y, label_smoothing=0.1)
+        loss.backward()
+        params = dict(model.named_parameters())
+        runs.append(([m.detach().clone() for m in maps], loss.detach().clone(), x.grad.clone(),
+                     {k: v.grad.clone() for k, v in params.items()}))
+    maps0, loss0, dx0, g0 = runs[0]
+    for maps, loss, dx, g in runs[1:]:
+        for a, b in zip(maps, maps0):
+            assert torch.equal(a, b)
+        assert torch.equal(loss, loss0) and torch.equal(dx, dx0)
+        for k in g0:
+            if ".norm." in k:
+                assert torch.equal(g[k], g0[k]), k
+            else:
+                assert ((g[k] - g0[k]).norm() / (g0[k].norm() + 1e-30)).item() < 1e-5, k
+
+
 def test_config1_darknet19_224_forward(golden_dir):
     """BASELINE.json configs[0] (Darknet-19, 1x3x224x224): HIP forward vs the reference's CPU forward."""
     gm = np.load(golden_dir / "models.npz")

@@ -61,7 +61,7 @@ def test_stem_backward_matches_float64(B, H, W, lddy, ldz, relu):
     mu = torch.randn(Cc, device=dev) * 0.3 + 0.4
     istd = torch.rand(Cc, device=dev) + 0.5
     coef = torch.randn(3, Cc, device=dev) * torch.tensor([[1.0], [0.05], [0.02]], device=dev)
-    sums = torch.zeros(N.VT_STAT_REPLICAS, 2, Cc, device=dev)
+    sums = N.stats_buffer(Cc)
     lib = N.lib()
     gzx = torch.zeros(lib.vt_stem_bn_bwd_scratch_bytes(Cc) // 4, device=dev)
     dw = torch.full((Cc, 9, 3), 0.25, device=dev)  # the combine kernel ACCUMULATES
@@ -71,7 +71,7 @@ def test_stem_backward_matches_float64(B, H, W, lddy, ldz, relu):
     N.check(lib.vt_stem_bn_bwd_combine(Cc, 3, vp(gzx), vp(coef), vp(dw), st))
     torch.cuda.synchronize()
     ref_s, ref_dw = _reference(x, dy, z, sc, sf, mu, istd, coef, relu)
-    got_s = sums.double().sum(0)
+    got_s = N.stats_decode(sums)
     scale_s = ref_s.abs().max(dim=1, keepdim=True).values
     assert ((got_s - ref_s).abs() / scale_s).max().item() < 2e-5
     got_dw = dw.double() - 0.25

@@ -71,7 +71,7 @@ def main():
             x.zero_()
             w.zero_()
         y = torch.empty(B, Ho, Ho, Cout, device="cuda", dtype=torch.bfloat16)
-        stats = torch.zeros(N.VT_STAT_REPLICAS, 2, Cout, device="cuda")
+        stats = N.stats_buffer(Cout)
         dz = torch.randn(B, Ho, Ho, Cout, device="cuda").to(torch.bfloat16)
         dw = torch.zeros(Cout, k * k, Cin, device="cuda")
         flops = 2.0 * B * Ho * Ho * Cout * k * k * Cin

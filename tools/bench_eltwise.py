@@ -56,7 +56,7 @@ def main():
         shift = torch.randn(C, device=dev) * 0.1
         mean = torch.randn(C, device=dev) * 0.1
         invstd = torch.rand(C, device=dev) + 0.5
-        sums = torch.zeros(N.VT_STAT_REPLICAS, 2, C, device=dev)
+        sums = N.stats_buffer(C)
         coef = torch.rand(3, C, device=dev)
         vp = ctypes.c_void_p
 

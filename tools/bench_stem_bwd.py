@@ -22,7 +22,7 @@ def main():
     dy = torch.randn(B, H, H, 32, device=dev).to(torch.bfloat16)
     z = torch.randn(B, H, H, 32, device=dev).to(torch.bfloat16)
     co = [torch.randn(32, device=dev) for _ in range(4)]
-    sums = torch.zeros(N.VT_STAT_REPLICAS, 2, 32, device=dev)
+    sums = N.stats_buffer(32)
     gzx = torch.zeros(lib.vt_stem_bn_bwd_scratch_bytes(32) // 4, device=dev)
     st = int(torch.cuda.current_stream().cuda_stream)
     vp = lambda t: C.c_void_p(t.data_ptr())

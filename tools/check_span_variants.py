@@ -77,11 +77,11 @@ def main():
                 os.environ.update({k: "0" for k in allkeys})
                 os.environ.update(env)
                 y = torch.full((B, H, H, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
-                st = torch.zeros(N.VT_STAT_REPLICAS, 2, Cout, device="cuda") if flags & N.VT_CONV_STATS else None
+                st = N.stats_buffer(Cout) if flags & N.VT_CONV_STATS else None
                 name, _ = run(d, x, w, y, st, r_)
                 outs[tag] = [y, st.double().sum(0).cpu() if st is not None else None, name, []]
             if mode == "stats":  # interleaved timing rounds (guide rule 24): median and min per variant
-                st = torch.zeros(N.VT_STAT_REPLICAS, 2, Cout, device="cuda")
+                st = N.stats_buffer(Cout)
                 ysc = torch.empty_like(outs[VARIANTS[0][0]][0])
                 for _ in range(ROUNDS):
                     for tag, env in VARIANTS:

@@ -22,7 +22,7 @@ xb = torch.randn(B, H, W, ldx, device="cuda").to(torch.bfloat16)
 x = xb[..., xoff:xoff + Cin] if slices else xb
 w = (torch.randn(Cout, 9, Cin, device="cuda") * (2.0 / (9 * Cin)) ** 0.5).to(torch.bfloat16)
 d = _desc(B, Cin, Cout, H, W, ldx, ldy, 0, flags, False)
-st = torch.zeros(N.VT_STAT_REPLICAS, 2, Cout, device="cuda") if flags & N.VT_CONV_STATS else None
+st = N.stats_buffer(Cout) if flags & N.VT_CONV_STATS else None
 ys = []
 for env in (("0", "2") if not only else (only,)):
     yb = torch.full((B, H, W, ldy), float("nan"), device="cuda", dtype=torch.bfloat16)

@@ -19,6 +19,39 @@ void vt_count_launch();
 void vt_note_kernel(const char* fmt, ...);                            // name of the conv kernel a dispatch chose
 int vt_raise_dynamic_lds(const void* kern, int bytes, const char* who);  // per (kernel, device), thread-safe
 
+// BatchNorm statistics and the BatchNorm-backward sums are accumulated in FIXED POINT with integer atomics, which are
+// associative: the sums -- and with them every activation, loss value and data gradient -- are bit-identical from run
+// to run, whatever order the workgroups finish in.  (With f32 atomics the last bits of the statistics varied; a few
+// activations then rounded to the neighbouring bf16 value or a ReLU decision at the threshold flipped, and BatchNorm
+// over small maps amplified that into gradients that fell into discrete classes percents apart: DESIGN.md 5.)
+// A value is split exactly into hi = trunc(v / 2^12) and lo = (v - hi * 2^12) * 2^33, each with its own int64:
+// resolution 2^-34 absolute per contribution (a single 2^-20 grid made channels with variances ~1e-6 discontinuous),
+// and the hi atomic is skipped when hi = 0, i.e. for every partial sum below 4096 -- one 64-bit atomic per value in
+// practice.  |lo| < 2^45 per contribution: a replica takes 2^17 contributions of the largest size before it could
+// overflow (the layers here make < 4,000).  A statistics buffer is int64[VT_STAT_REPLICAS][2][C][2]
+// (VT_STAT_BYTES(C) bytes, zeroed by the caller); the kernels take it as float* and index the limbs themselves.
+constexpr int kStatReplicas = VT_STAT_REPLICAS;
+#ifdef __HIPCC__
+__device__ __forceinline__ void vt_stat_add(float* stats, long idx, float v) {
+    const float hf = truncf(v * (1.0f / 4096.0f));   // exact (power-of-two scaling, then an integer)
+    const float rem = v - hf * 4096.0f;               // exact: |rem| < 4096, a multiple of ulp(v)
+    unsigned long long* q = (unsigned long long*)stats + 2 * idx;
+    atomicAdd(q + 1, (unsigned long long)__float2ll_rn(rem * 8589934592.0f));  // 2^33
+    if (hf != 0.0f) atomicAdd(q, (unsigned long long)(long long)hf);
+}
+// exact integer sums over the replicas of entry `idx` (stride = entries per replica), as a double in natural units
+__device__ __forceinline__ double vt_stat_sum(const float* stats, long idx, long stride) {
+    const long long* q = (const long long*)stats;
+    long long hi = 0, lo = 0;
+#pragma unroll
+    for (int r = 0; r < kStatReplicas; ++r) {
+        hi += q[2 * (idx + r * stride)];
+        lo += q[2 * (idx + r * stride) + 1];
+    }
+    return (double)hi * 4096.0 + (double)lo * (1.0 / 8589934592.0);
+}
+#endif
+
 #define VT_REQUIRE(cond, code, ...)   \
     do {                              \
         if (!(cond)) {                \

@@ -61,20 +61,10 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int C, doubl
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     float rm = 0.f, rv = 0.f;
     if (running_mean) rm = running_mean[c], rv = running_var[c];
-    float v1[VT_STAT_REPLICAS], v2[VT_STAT_REPLICAS];
-#pragma unroll
-    for (int r = 0; r < VT_STAT_REPLICAS; ++r) {
-        v1[r] = stats[((long)r * 2 + 0) * C + c];
-        v2[r] = stats[((long)r * 2 + 1) * C + c];
-    }
-    double s = 0.0, ss = 0.0, sb = 0.0, ssb = 0.0;
-#pragma unroll
-    for (int r = 0; r < VT_STAT_REPLICAS; r += 2) {
-        s += (double)v1[r], sb += (double)v1[r + 1];
-        ss += (double)v2[r], ssb += (double)v2[r + 1];
-    }
-    const double mu = (s + sb) * inv_count;
-    double var = (ss + ssb) * inv_count - mu * mu;
+    // exact integer sums of the fixed-point replicas (vt_common.h)
+    const double s = vt_stat_sum(stats, c, 2L * C), ss = vt_stat_sum(stats, (long)C + c, 2L * C);
+    const double mu = s * inv_count;
+    double var = ss * inv_count - mu * mu;
     if (var < 0.0) var = 0.0;
     const float istd = 1.0f / sqrtf((float)(var + (double)eps));
     const float sc = g * istd;
@@ -184,7 +174,7 @@ bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z
     const int tc = t % rm.CT;
     const int W = rm.CT * EPC;  // channels covered per pass
     const long row0 = (long)blockIdx.x * rm.RT * rm.iters + r;
-    const int rep = blockIdx.x % VT_STAT_REPLICAS;
+    const int rep = blockIdx.x % kStatReplicas;
     for (int cbase = 0; cbase < rm.CPR; cbase += rm.CT) {
         const int col = cbase + tc;
         const bool active = (r < rm.RT) && (col < rm.CPR);
@@ -264,7 +254,7 @@ bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z
                 float acc = 0.f;
                 for (int rr = 0; rr < rows_l; ++rr) acc += sred[(long)(rr * 2 + which) * W + lc];
                 if (which) acc *= invstd[c];
-                atomicAdd(&sums[((long)rep * 2 + which) * C + c], acc);
+                vt_stat_add(sums, ((long)rep * 2 + which) * C + c, acc);
             }
         }
         __syncthreads();
@@ -281,19 +271,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, do
     float dg = 0.f, db = 0.f;
     if (dgamma) dg = dgamma[c];
     if (dbeta) db = dbeta[c];
-    float v1[VT_STAT_REPLICAS], v2[VT_STAT_REPLICAS];
-#pragma unroll
-    for (int r = 0; r < VT_STAT_REPLICAS; ++r) {
-        v1[r] = sums[((long)r * 2 + 0) * C + c];
-        v2[r] = sums[((long)r * 2 + 1) * C + c];
-    }
-    double s1 = 0.0, s2 = 0.0, s1b = 0.0, s2b = 0.0;
-#pragma unroll
-    for (int r = 0; r < VT_STAT_REPLICAS; r += 2) {
-        s1 += (double)v1[r], s1b += (double)v1[r + 1];
-        s2 += (double)v2[r], s2b += (double)v2[r + 1];
-    }
-    s1 += s1b, s2 += s2b;
+    const double s1 = vt_stat_sum(sums, c, 2L * C), s2 = vt_stat_sum(sums, (long)C + c, 2L * C);
     if (dgamma) dgamma[c] = dg + (float)(s2 * pscale);
     if (dbeta) dbeta[c] = db + (float)(s1 * pscale);
     float b = 0.f, d = 0.f;

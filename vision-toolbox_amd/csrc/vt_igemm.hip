@@ -356,22 +356,14 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs p) {
             s += __shfl_xor(s, 32, 64);
             ss += __shfl_xor(ss, 16, 64);
             ss += __shfl_xor(ss, 32, 64);
-            if (lane < 16) {
-                atomicAdd(&sStat[col], s);
-                atomicAdd(&sStat[BN + col], ss);
+            if (lane < 16 && n < p.Cout) {  // each wave adds its own partial: integer atomics, any order
+                const int rep = tm % kStatReplicas;
+                vt_stat_add(p.stats, ((long)rep * 2 + 0) * p.Cout + n, s);
+                vt_stat_add(p.stats, ((long)rep * 2 + 1) * p.Cout + n, ss);
             }
         }
     }
     __syncthreads();
-
-    if (stats && tid < 2 * BN) {
-        const int which = tid / BN, col = tid % BN;
-        const int n = tn * BN + col;
-        if (n < p.Cout) {
-            const int rep = tm % VT_STAT_REPLICAS;
-            atomicAdd(&p.stats[((long)rep * 2 + which) * p.Cout + n], sStat[tid]);
-        }
-    }
 
     constexpr int CPR = BN / EPC;  // 16-byte chunks per tile row
     const uint4* sOut4 = (const uint4*)sOut;

@@ -634,7 +634,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
         lds_fence();
     }
     if (stats) {
-        const int rep = tm % VT_STAT_REPLICAS;
+        const int rep = tm % kStatReplicas;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             float a = s1[j], b = s2[j];
@@ -644,8 +644,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
             b += __shfl_xor(b, 32, 64);
             const int n = tn * BN + wn * TN + j * 16 + c;
             if (q == 0 && n < p.Cout) {
-                atomicAdd(&p.stats[((long)rep * 2 + 0) * p.Cout + n], a);
-                atomicAdd(&p.stats[((long)rep * 2 + 1) * p.Cout + n], b);
+                vt_stat_add(p.stats, ((long)rep * 2 + 0) * p.Cout + n, a);
+                vt_stat_add(p.stats, ((long)rep * 2 + 1) * p.Cout + n, b);
             }
         }
     }

@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(128 * WM, 2) span3_kernel(const S3Args a) {
             }
             if (stats) {
                 // sum over the 16 pixel lanes (same q4): butterfly, then lane c16 == e keeps channel e
-                const int rep = (int)((m0_cur / UNIT) % VT_STAT_REPLICAS);
+                const int rep = (int)((m0_cur / UNIT) % kStatReplicas);
                 float u = 0.f, v = 0.f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -505,8 +505,8 @@ __global__ void __launch_bounds__(128 * WM, 2) span3_kernel(const S3Args a) {
                 }
                 const int n = ch0 + (c16 >> 3) * 32 + (c16 & 7);
                 if (n < Cout_) {
-                    atomicAdd(&stats_[((long)rep * 2 + 0) * Cout_ + n], u);
-                    atomicAdd(&stats_[((long)rep * 2 + 1) * Cout_ + n], v);
+                    vt_stat_add(stats_, ((long)rep * 2 + 0) * Cout_ + n, u);
+                    vt_stat_add(stats_, ((long)rep * 2 + 1) * Cout_ + n, v);
                 }
             }
         };

@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(320, 3) span5_kernel(const S5Args a) {
             const float* scale_ = Q->p.scale;
             const float* shift_ = Q->p.shift;
             float* stats_ = Q->p.stats;
-            const int rep = (int)((m0_cur / 32) % VT_STAT_REPLICAS);
+            const int rep = (int)((m0_cur / 32) % kStatReplicas);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 // (opaque: keeps the per-lane 64-bit output / statistics addresses from being hoisted out of the tile
@@ -492,8 +492,8 @@ __global__ void __launch_bounds__(320, 3) span5_kernel(const S5Args a) {
                     }
                     const int nn = n + c16;
                     if (c16 < 8 && nn < Cout_) {
-                        atomicAdd(&stats_[((long)rep * 2 + 0) * Cout_ + nn], u);
-                        atomicAdd(&stats_[((long)rep * 2 + 1) * Cout_ + nn], v);
+                        vt_stat_add(stats_, ((long)rep * 2 + 0) * Cout_ + nn, u);
+                        vt_stat_add(stats_, ((long)rep * 2 + 1) * Cout_ + nn, v);
                     }
                 }
             }

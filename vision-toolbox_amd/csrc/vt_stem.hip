@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(256) stem_kernel(const IgemmArgs p, const int 
         lds_fence();
     }
     if (stats) {
-        const int rep = (int)(blockIdx.x % VT_STAT_REPLICAS);
+        const int rep = (int)(blockIdx.x % kStatReplicas);
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             float a = s1[j], b = s2[j];
@@ -198,8 +198,8 @@ __global__ void __launch_bounds__(256) stem_kernel(const IgemmArgs p, const int 
             b += __shfl_xor(b, 32, 64);
             const int n = j * 16 + u;
             if (q == 0 && n < p.Cout) {
-                atomicAdd(&p.stats[((long)rep * 2 + 0) * p.Cout + n], a);
-                atomicAdd(&p.stats[((long)rep * 2 + 1) * p.Cout + n], b);
+                vt_stat_add(p.stats, ((long)rep * 2 + 0) * p.Cout + n, a);
+                vt_stat_add(p.stats, ((long)rep * 2 + 1) * p.Cout + n, b);
             }
         }
     }

@@ -37,7 +37,7 @@ struct SbArgs {
     const bf16_t* dy;   // ld lddy
     const bf16_t* z;    // ld ldz
     const float *scale, *shift, *mean, *invstd;
-    float* sums;        // [VT_STAT_REPLICAS][2][C]
+    float* sums;        // fixed-point [kStatReplicas][2][C] (vt_common.h)
     float* gzx;         // [kGzxReplicas][2C+16][96]
     int B, H, W, C, lddy, ldz, relu;
     int PW, PH, S;      // padded pitch / rows / positions per image
@@ -294,12 +294,12 @@ __global__ void __launch_bounds__(256, 2) stem_bwd_kernel(const SbArgs p) {
         }
     }
     if (lane < CPR) {
-        const int srep = (int)(blockIdx.x % VT_STAT_REPLICAS);
+        const int srep = (int)(blockIdx.x % kStatReplicas);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = chunk * 8 + e;
-            atomicAdd(&p.sums[((long)srep * 2 + 0) * C + c], s1[e]);
-            atomicAdd(&p.sums[((long)srep * 2 + 1) * C + c], s2[e] * p.invstd[c]);
+            vt_stat_add(p.sums, ((long)srep * 2 + 0) * C + c, s1[e]);
+            vt_stat_add(p.sums, ((long)srep * 2 + 1) * C + c, s2[e] * p.invstd[c]);
         }
     }
 }

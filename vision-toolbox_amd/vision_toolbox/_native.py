@@ -19,6 +19,37 @@ VT_F32, VT_BF16 = 0, 1
 VT_MAX_TAPS = 36
 VT_CONV_RELU, VT_CONV_STATS, VT_CONV_RESIDUAL, VT_CONV_AFFINE, VT_CONV_D2S = 1, 2, 4, 8, 16
 VT_STAT_REPLICAS = 32
+# a statistics buffer is int64[VT_STAT_REPLICAS][2][C][2]: value = hi * 2^12 + lo / 2^33 (vt_amd.h)
+
+
+def stat_floats(C_: int) -> int:
+    """size of a statistics buffer in 4-byte units (VT_STAT_BYTES(C) / 4)"""
+    return VT_STAT_REPLICAS * 2 * C_ * 4
+
+
+def stats_buffer(C_: int, device="cuda"):
+    """a zeroed statistics buffer for C channels"""
+    import torch
+
+    return torch.zeros(VT_STAT_REPLICAS, 2, C_, 2, dtype=torch.int64, device=device)
+
+
+def stats_decode(buf):
+    """statistics buffer as the kernels fill it -> float64 [2][C] (exact sum over the replicas)"""
+    q = buf.sum(0)
+    return q[..., 0].double() * 4096.0 + q[..., 1].double() / float(1 << 33)
+
+
+def stats_encode(buf, which: int, values, replica: int = 0):
+    """add `values` [C] (natural units) into replica `replica` of row `which` of a statistics buffer (tests)"""
+    import torch
+
+    v = values.double()
+    hi = torch.trunc(v / 4096.0)
+    buf[replica, which, :, 0] += hi.to(torch.int64)
+    buf[replica, which, :, 1] += torch.round((v - hi * 4096.0) * float(1 << 33)).to(torch.int64)
+
+
 VT_OP_MAX_PTR, VT_OP_MAX_INT, VT_OP_MAX_FLT, VT_MAX_BASES = 12, 110, 8, 16
 
 (

@@ -560,7 +560,7 @@ class Builder:
         elif has_bn:
             z = self.act(B, Ho, Wo, Cout, name + ".z")
             if unit_training:
-                stats = self.zeroed_f32(N.VT_STAT_REPLICAS * 2 * Cout, "stats")
+                stats = self.zeroed_f32(N.stat_floats(Cout), "stats")
                 d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, z.ld, ldw, N.VT_CONV_STATS)
                 self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, z.addr(), None, None, None, self.bp(stats)], desc=d)
                 self.emit(N.OP_BN_FINALIZE,
@@ -599,7 +599,7 @@ class Builder:
                     # dz = a*g - b*z + d feeds nothing but the filter gradient (the unit's input is the image): the
                     # pass that reduces (sum g, sum g*xhat) also correlates g, z and 1 with the tap-shifted x, and a
                     # small kernel finishes dW = a*G - b*Z + d*X once (a, b, d) exist (vt_stem_bwd.hip)
-                    sums = self.zeroed_f32(N.VT_STAT_REPLICAS * 2 * Cout, "bwdsums")
+                    sums = self.zeroed_f32(N.stat_floats(Cout), "bwdsums")
                     gzx = self.zeroed_f32(N.lib().vt_stem_bn_bwd_scratch_bytes(Cout) // 4, "stem_gzx")
                     self.emit(N.OP_STEM_BWD_REDUCE,
                               [x.addr(), dy.addr(), z.addr(), cp[0], cp[1], cp[2], cp[3], self.bp(sums), self.bp(gzx)],
@@ -611,7 +611,7 @@ class Builder:
                     self.emit(N.OP_STEM_BWD_COMBINE, [self.bp(gzx), self.bp(bcoef), self.pgrad(w)], [Cout, Cin_w])
                     return
                 if has_bn:
-                    sums = self.zeroed_f32(N.VT_STAT_REPLICAS * 2 * Cout, "bwdsums")
+                    sums = self.zeroed_f32(N.stat_floats(Cout), "bwdsums")
                     self.emit(N.OP_BN_BWD_REDUCE,
                               [dy.addr(), z.addr(), cp[0], cp[1], cp[2], cp[3], self.bp(sums)],
                               [dy.ld, z.ld, Cout, int(relu), dt], [M])

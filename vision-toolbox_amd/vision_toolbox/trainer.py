@@ -264,12 +264,13 @@ class TrainStep:
         for idx in range(n):
             op = ops[idx]
             if (op.kind & 0xFFFF) == kind:
-                pts.append((idx, op.ptr[0].base, op.ptr[0].offset, N.VT_STAT_REPLICAS * 2 * op.i[0] * 4))
+                pts.append((idx, op.ptr[0].base, op.ptr[0].offset, N.stat_floats(op.i[0]) * 4))
         return pts
 
     def _sync_view(self, base, off, nbytes):
         start = {E.ZERO_F: self.prog.zf_off, E.ZERO_B: self.prog.zb_off}[base] + off
-        return self.arena[start : start + nbytes].view(torch.float32)
+        # the sums are 64-bit fixed point (vt_amd.h, VT_STAT_REPLICAS): an integer all-reduce, exact and order-free
+        return self.arena[start : start + nbytes].view(torch.int64)
 
     def _run_list(self, ops, n, sync, cuts, cut_buckets, s, side):
         """run a launch list in segments: a segment ends before every finalize kernel whose statistics
@@ -380,7 +381,7 @@ class TrainStep:
             else:
                 if self._side is None:
                     self._side = torch.cuda.Stream(self.device)
-                side = int(self._side.cuda_stream)
+                side = int(self._side.cuda_stream) if os.environ.get("VT_NO_SIDE_STREAM", "0") == "0" else 0  # (diagnostics: one stream)
                 N.run_ops(self.zero_ops, 1, self.bases, s)
                 self._run_list(p.fwd_ops, p.n_fwd, self._fwd_sync, [], {}, s, side)
                 self._run_list(p.bwd_ops, p.n_bwd, self._bwd_sync, self.bwd_cuts,
