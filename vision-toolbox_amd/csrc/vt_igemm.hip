@@ -54,7 +54,7 @@
 namespace {
 
 constexpr int kTapBytes = VT_MAX_TAPS * 16;  // int4 per tap
-constexpr int kStatBytes = 2 * 128 * 4;      // sum, sumsq for BN <= 128
+constexpr int kStatBytes = 4 * 128 * 4;      // per row-wave (sum, sumsq): WM * 2 * BN floats, WM * BN <= 256
 constexpr int kHdrBytes = kTapBytes + kStatBytes;
 
 __device__ __attribute__((aligned(16))) unsigned int vt_zero16[4];  // source of every padded chunk
@@ -356,14 +356,25 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs p) {
             s += __shfl_xor(s, 32, 64);
             ss += __shfl_xor(ss, 16, 64);
             ss += __shfl_xor(ss, 32, 64);
-            if (lane < 16 && n < p.Cout) {  // each wave adds its own partial: integer atomics, any order
-                const int rep = tm % kStatReplicas;
-                vt_stat_add(p.stats, ((long)rep * 2 + 0) * p.Cout + n, s);
-                vt_stat_add(p.stats, ((long)rep * 2 + 1) * p.Cout + n, ss);
+            if (lane < 16) {  // parked per row-wave, folded in a FIXED order below (LDS float atomics would not be)
+                sStat[(wm * 2 + 0) * BN + col] = s;
+                sStat[(wm * 2 + 1) * BN + col] = ss;
             }
         }
     }
     __syncthreads();
+
+    if (stats && tid < 2 * BN) {
+        static_assert(WM * 2 * BN * 4 <= kStatBytes, "statistics staging");
+        const int which = tid / BN, col = tid % BN;
+        const int n = tn * BN + col;
+        if (n < p.Cout) {
+            float acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) acc += sStat[(w * 2 + which) * BN + col];
+            vt_stat_add(p.stats, ((long)(tm % kStatReplicas) * 2 + which) * p.Cout + n, acc);
+        }
+    }
 
     constexpr int CPR = BN / EPC;  // 16-byte chunks per tile row
     const uint4* sOut4 = (const uint4*)sOut;
