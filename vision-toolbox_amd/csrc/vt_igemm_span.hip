@@ -633,8 +633,13 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
         }
         lds_fence();
     }
-    if (stats) {
-        const int rep = tm % kStatReplicas;
+    if (stats) {  // (uniform per launch: every wave takes the barriers)
+        // The WM row-waves of a column fold their partials in LDS in a fixed order and ONE fixed-point atomic leaves
+        // the workgroup per (column, moment): the 64-bit atomics queue ~100 ns per address, and the 256 x 64 tiles of
+        // the large maps (12.5 k tiles of 4 row-waves at 64 -> 64 @112x112) spent 14 % of their time there.
+        static_assert(WM * 2 * BN * 4 <= (PD + 1) * BROWS * 64, "statistics fold fits the filter ring");
+        float* sFold = (float*)(smem + L::kB);  // [WM][2][BN], over the staging windows: behind a barrier
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             float a = s1[j], b = s2[j];
@@ -642,10 +647,21 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
             a += __shfl_xor(a, 32, 64);
             b += __shfl_xor(b, 16, 64);
             b += __shfl_xor(b, 32, 64);
-            const int n = tn * BN + wn * TN + j * 16 + c;
-            if (q == 0 && n < p.Cout) {
-                vt_stat_add(p.stats, ((long)rep * 2 + 0) * p.Cout + n, a);
-                vt_stat_add(p.stats, ((long)rep * 2 + 1) * p.Cout + n, b);
+            if (q == 0) {
+                sFold[(wm * 2 + 0) * BN + wn * TN + j * 16 + c] = a;
+                sFold[(wm * 2 + 1) * BN + wn * TN + j * 16 + c] = b;
+            }
+        }
+        __syncthreads();
+        const int rep = tm % kStatReplicas;
+        for (int i = threadIdx.x; i < 2 * BN; i += NT) {
+            const int which = i / BN, col = i % BN;
+            const int n = tn * BN + col;
+            if (n < p.Cout) {
+                float acc = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) acc += sFold[(w * 2 + which) * BN + col];
+                vt_stat_add(p.stats, ((long)rep * 2 + which) * p.Cout + n, acc);
             }
         }
     }
