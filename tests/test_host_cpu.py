@@ -240,3 +240,24 @@ def test_warmup_cosine_matches_torch_schedulers():
         assert opt.param_groups[0]["lr"] == pytest.approx(warmup_cosine_lr(epoch, 100, 0.5), rel=1e-6, abs=1e-9)
         opt.step()
         sched.step()
+
+
+def test_statistics_buffer_fixed_point_roundtrip():
+    """include/vt_amd.h: a statistics buffer is int64[VT_STAT_REPLICAS][2][C][2], value = hi*2^12 + lo/2^33; the
+    Python helpers the tests use to fill / read one follow the kernels' split (vt_common.h vt_stat_add): good for
+    any sign and magnitude to 2^-34 absolute, and additive across replicas."""
+    C_ = 7
+    buf = torch.zeros(N.VT_STAT_REPLICAS, 2, C_, 2, dtype=torch.int64)
+    assert buf.numel() * 8 == N.stat_floats(C_) * 4
+    v = torch.tensor([0.0, 1e-6, -1e-6, 3.25, -4095.75, 4096.0, 1.2345e7], dtype=torch.float32)
+    w = torch.tensor([5e-9, -7.5, 123456.7, -0.03125, 4095.999, -8192.5, -1.2345e7], dtype=torch.float32)
+    N.stats_encode(buf, 0, v, replica=3)
+    N.stats_encode(buf, 0, w, replica=31)
+    N.stats_encode(buf, 1, w, replica=0)
+    got = N.stats_decode(buf)
+    # resolution 2^-33 per contribution (values with finer bits, 1e-6 or 5e-9, round to it): 2^-34 error each
+    assert (got[0] - (v.double() + w.double())).abs().max().item() <= 2 * 2.0 ** -34
+    assert (got[1] - w.double()).abs().max().item() <= 2.0 ** -34
+    assert got[0][3].item() == 3.25 - 0.03125 and got[0][5].item() == 4096.0 - 8192.5  # dyadic values: exact
+    hi = buf[3, 0, :, 0]
+    assert hi.tolist() == [0, 0, 0, 0, 0, 1, 3013]  # trunc(v / 4096): the hi limb stays zero below 4096
