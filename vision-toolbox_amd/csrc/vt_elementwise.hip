@@ -21,6 +21,7 @@ struct RowMap {
     int CT;   // threads along the row
     int RT;   // rows per block pass
     int iters;
+    int rev;  // walk the row blocks from the last to the first (see vt_bn_order)
     __host__ static RowMap make(int C, int epc, long M, int target_blocks = 4096) {
         RowMap r;
         r.CPR = C / epc;
@@ -30,6 +31,7 @@ struct RowMap {
         if (it < 1) it = 1;
         if (it > 64) it = 64;
         r.iters = (int)it;
+        r.rev = 0;
         return r;
     }
     __host__ unsigned blocks(long M) const {
@@ -103,7 +105,7 @@ bn_act_apply_kernel(const T* __restrict__ z, int ldz, const float* __restrict__ 
     const int t = threadIdx.x;
     const int r = t / rm.CT;
     if (r >= rm.RT) return;
-    const long row0 = (long)blockIdx.x * rm.RT * rm.iters + r;
+    const long row0 = (long)(rm.rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * rm.RT * rm.iters + r;
     for (int col = t % rm.CT; col < rm.CPR; col += rm.CT) {
         float sc[EPC], sf[EPC];
 #pragma unroll
@@ -173,7 +175,7 @@ bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z
     const int r = t / rm.CT;
     const int tc = t % rm.CT;
     const int W = rm.CT * EPC;  // channels covered per pass
-    const long row0 = (long)blockIdx.x * rm.RT * rm.iters + r;
+    const long row0 = (long)(rm.rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * rm.RT * rm.iters + r;
     const int rep = blockIdx.x % kStatReplicas;
     for (int cbase = 0; cbase < rm.CPR; cbase += rm.CT) {
         const int col = cbase + tc;
@@ -297,7 +299,7 @@ bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z,
     const int t = threadIdx.x;
     const int r = t / rm.CT;
     if (r >= rm.RT) return;
-    const long row0 = (long)blockIdx.x * rm.RT * rm.iters + r;
+    const long row0 = (long)(rm.rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * rm.RT * rm.iters + r;
     for (int col = t % rm.CT; col < rm.CPR; col += rm.CT) {
         float sc[EPC], sf[EPC], ca[EPC], cb[EPC], cd[EPC];
 #pragma unroll
@@ -902,6 +904,16 @@ pack_dgrad_kernel(const S* __restrict__ w, int ldw, D* __restrict__ out, SelTabl
     }
 }
 
+// Walking order of the three BatchNorm passes over their rows (bit 0: bn_act_apply, 1: bn_bwd_reduce, 2: bn_bwd_apply;
+// set = last row block first).  A pass that follows a kernel which just streamed the same tensor front to back finds
+// that tensor's TAIL in the memory-side cache (256 MB), not its head: walking backwards would turn those into hits.
+// Measured on the full step, every combination: 23.14 .. 23.25 ms against 23.23 .. 23.25 for the default (0) -- no
+// effect beyond noise; the knob stays for experiments.
+inline int vt_bn_order() {
+    static const int v = getenv("VT_BN_REV") ? atoi(getenv("VT_BN_REV")) : 0;
+    return v;
+}
+
 inline unsigned flat_blocks(long total, int per_thread = 1) {
     long b = (total + (long)kThreads * per_thread - 1) / ((long)kThreads * per_thread);
     if (b > 8192) b = 8192;
@@ -979,7 +991,8 @@ int vt_bn_act_apply(const void* z, int32_t ldz, const float* scale, const float*
     VT_TRY(check_mat("vt_bn_act_apply(z)", z, ldz, C, dtype));
     VT_TRY(check_mat("vt_bn_act_apply(y)", y, ldy, C, dtype));
     if (residual) VT_TRY(check_mat("vt_bn_act_apply(residual)", residual, ldr, C, dtype));
-    const RowMap rm = RowMap::make(C, vt_epc(dtype), M);
+    RowMap rm = RowMap::make(C, vt_epc(dtype), M);
+    rm.rev = (vt_bn_order() >> 0) & 1;
     if (residual) {
         VT_DISPATCH_T(dtype, "vt_bn_act_apply",
                       hipLaunchKernelGGL((bn_act_apply_kernel<T, true>), dim3(rm.blocks(M)), dim3(kThreads), 0,
@@ -1006,7 +1019,8 @@ int vt_bn_act_bwd_reduce(const void* dy, int32_t lddy, const void* z, int32_t ld
     // every block ends with 2*C 64-bit atomics into one of 32 replicas: ~100 ns each when they queue on the same address,
     // so fewer, longer blocks win over grid-filling ones (measured per step: 1024 -> 23.53, 512 -> 23.36, 256 -> 23.27 ms)
     static const int target = getenv("VT_REDUCE_BLOCKS") ? atoi(getenv("VT_REDUCE_BLOCKS")) : 256;
-    const RowMap rm = RowMap::make(C, epc, M, target);
+    RowMap rm = RowMap::make(C, epc, M, target);
+    rm.rev = (vt_bn_order() >> 1) & 1;
     static const int inwave_env = getenv("VT_REDUCE_INWAVE") ? atoi(getenv("VT_REDUCE_INWAVE")) : 1;
     const bool inwave = inwave_env && rm.CT < 64 && (rm.CT & (rm.CT - 1)) == 0;  // (as in the kernel)
     const int smem = (inwave ? kThreads / 64 : rm.RT) * 2 * rm.CT * epc * (int)sizeof(float);
@@ -1036,7 +1050,8 @@ int vt_bn_act_bwd_apply(const void* dy, int32_t lddy, const void* z, int32_t ldz
     VT_TRY(check_mat("vt_bn_act_bwd_apply(dy)", dy, lddy, C, dtype));
     VT_TRY(check_mat("vt_bn_act_bwd_apply(z)", z, ldz, C, dtype));
     VT_TRY(check_mat("vt_bn_act_bwd_apply(dz)", dz, lddz, C, dtype));
-    const RowMap rm = RowMap::make(C, vt_epc(dtype), M);
+    RowMap rm = RowMap::make(C, vt_epc(dtype), M);
+    rm.rev = (vt_bn_order() >> 2) & 1;
     VT_DISPATCH_T(dtype, "vt_bn_act_bwd_apply",
                   hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(rm.blocks(M)), dim3(kThreads), 0,
                                      (hipStream_t)stream, (const T*)dy, lddy, (const T*)z, ldz, scale, shift,
