@@ -48,6 +48,10 @@ extern "C" {
 #define VT_CONV_STATS 2    /* accumulate per-channel sum / sum-of-squares       */
 #define VT_CONV_RESIDUAL 4 /* y += residual (after relu)                        */
 #define VT_CONV_AFFINE 8   /* y = y*scale[c] + shift[c]; scale==NULL means 1    */
+#define VT_CONV_WGRAD_FIXED 32 /* vt_conv_wgrad only: `dw` is a FIXED-POINT shadow of the gradient, int64[rows*ldgw][2] with
+                            * value = hi*2^12 + lo/2^33 (as the statistics buffers), accumulated with integer atomics:
+                            * the sum over the pixel splits no longer depends on their order.  Zeroed by the caller;
+                            * vt_fixed_to_f32 folds it into the f32 gradient.  (Deterministic mode.) */
 #define VT_CONV_D2S 16     /* depth-to-space 2x2: the Cout = 4*C' columns of grid pixel (i, j) are the output pixels
                             * (2i+a, 2j+b) x C' channels, column = (2a+b)*C' + c; needs oHs = oWs = 2, oh0 = ow0 = 0,
                             * oH = 2*Ho, oW = 2*Wo, no STATS / AFFINE / RELU.  One launch then forms the whole data
@@ -115,6 +119,9 @@ int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w, void* y,
  * autograd backward of nn.Conv2d (components.py:26-35). */
 int vt_conv_wgrad(const vt_conv_desc* d, const void* x, const void* dz, float* dw,
                   int32_t ldgw, void* stream);
+
+/* dst[i] (+)= hi[i]*2^12 + lo[i]/2^33 for a fixed-point buffer q = int64[n][2] (VT_CONV_WGRAD_FIXED, vt_colsum_fixed). */
+int vt_fixed_to_f32(const void* q, float* dst, int64_t n, int32_t accumulate, void* stream);
 
 /* Re-pack a [Cout][ntaps][Cin] filter (f32 master or dtype mirror) into the
  * [Cin][nsel][Cout] image the data-gradient launch reads; sel[i] is the source
@@ -222,6 +229,8 @@ int vt_ese_gate_bwd(const void* dy, int32_t lddy, const void* x, int32_t ldx, co
 /* per-column sums of a [M][C] matrix into out[C] (+=): bias gradients. */
 int vt_colsum(const void* a, int32_t lda, int64_t M, int32_t C, int32_t dtype, float* out,
               void* stream);
+/* the same sums into a zeroed fixed-point buffer q = int64[C][2] (deterministic mode; vt_fixed_to_f32 folds it in) */
+int vt_colsum_fixed(const void* a, int32_t lda, int64_t M, int32_t C, int32_t dtype, void* q, void* stream);
 /* F.cross_entropy(logits, labels, label_smoothing) with mean reduction and its
  * gradient times grad_scale; loss_sum[0] += sum_b loss_b / B. */
 int vt_softmax_xent(const void* logits, int32_t ldl, const int64_t* labels,
@@ -307,6 +316,7 @@ enum vt_op_kind {
                         work between the mark and the side-stream ops that depend on it */
     VT_OP_STEM_BWD_REDUCE,  /* vt_stem_bn_bwd_reduce */
     VT_OP_STEM_BWD_COMBINE, /* vt_stem_bn_bwd_combine */
+    VT_OP_FIXED_TO_F32,     /* vt_fixed_to_f32 */
     VT_OP_KIND_END
 };
 

@@ -220,3 +220,35 @@ def test_one_rank_rccl_group_runs_the_data_parallel_schedule(sync_bn):
     assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     buf = torch.zeros(16, device="cuda")  # the launch-count guard of this module wants a launch here too
     N.check(N.lib().vt_memset(buf.data_ptr(), 0, 64, int(torch.cuda.current_stream().cuda_stream)))
+
+
+@pytest.mark.parametrize("model,dtype", [("darknet_yolov5n", "f32"), ("vovnet19_slim_ese", "bf16"), ("cspdarknet53", "bf16")])
+def test_deterministic_mode_gives_identical_bits(model, dtype):
+    """VT_DETERMINISTIC=1 (read once per process, hence the child process): four fresh runs of two SGD steps end with
+    bit-identical parameters, gradients, momentum and BatchNorm state (tools/deterministic_check.py) -- the filter
+    gradients and bias sums go through a fixed-point shadow like the BatchNorm statistics always do."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / "tools" / "deterministic_check.py"), model, dtype], capture_output=True,
+                       text=True, timeout=600, env=dict(os.environ, VT_DETERMINISTIC="1"))
+    assert r.returncode == 0 and "DETERMINISTIC_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    buf = torch.zeros(16, device="cuda")  # the launch-count guard of this module wants a launch here too
+    N.check(N.lib().vt_memset(buf.data_ptr(), 0, 64, int(torch.cuda.current_stream().cuda_stream)))
+
+
+def test_deterministic_mode_matches_the_oracle_like_the_default_mode():
+    """the gradient checks of this module against the float64 / f32 oracle, re-run with VT_DETERMINISTIC=1"""
+    import os
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, "-k",
+                        "frozen_bn_step_gradients_match_oracle_tightly or first_step_gradients_track_oracle"],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, VT_DETERMINISTIC="1"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    buf = torch.zeros(16, device="cuda")
+    N.check(N.lib().vt_memset(buf.data_ptr(), 0, 64, int(torch.cuda.current_stream().cuda_stream)))

@@ -40,6 +40,15 @@ struct RowMap {
     }
 };
 
+// LDS sums over the row lanes of a block as 64-bit fixed point (2^-32): integer atomics, order-free (a float LDS
+// atomic made the pooled features, and with them logits and loss, differ in the last bit from run to run)
+__device__ __forceinline__ void lds_fix_add(unsigned long long* s, int i, float v) {
+    atomicAdd(&s[i], (unsigned long long)__float2ll_rn(v * 4294967296.0f));
+}
+__device__ __forceinline__ float lds_fix_get(const unsigned long long* s, int i) {
+    return (float)((double)(long long)s[i] * (1.0 / 4294967296.0));
+}
+
 template <typename T>
 __device__ __forceinline__ uint4 ld16(const T* p) { return *(const uint4*)p; }
 template <typename T>
@@ -448,14 +457,15 @@ template <typename T>
 __global__ void __launch_bounds__(kThreads)
 avgpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int HW, int C, int CT) {
     constexpr int EPC = VecIO<T>::EPC;
-    extern __shared__ float sred[];  // [CT*EPC]
+    extern __shared__ unsigned long long sfix[];  // [CT*EPC] fixed point
+    unsigned long long* sred = sfix;
     const int t = threadIdx.x;
     const int RT = kThreads / CT;
     const int b = blockIdx.x;
     const int col = blockIdx.y * CT + t % CT;
     const int r = t / CT;
     const int CPR = C / EPC;
-    for (int i = t; i < CT * EPC; i += kThreads) sred[i] = 0.f;
+    for (int i = t; i < CT * EPC; i += kThreads) sred[i] = 0ull;
     __syncthreads();
     if (r < RT && col < CPR) {
         float s[EPC];
@@ -468,14 +478,14 @@ avgpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
             for (int e = 0; e < EPC; ++e) s[e] += v[e];
         }
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) atomicAdd(&sred[(t % CT) * EPC + e], s[e]);
+        for (int e = 0; e < EPC; ++e) lds_fix_add(sred, (t % CT) * EPC + e, s[e]);
     }
     __syncthreads();
     if (r == 0 && col < CPR) {
         float v[EPC];
         const float inv = 1.f / (float)HW;
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) v[e] = sred[(t % CT) * EPC + e] * inv;
+        for (int e = 0; e < EPC; ++e) v[e] = lds_fix_get(sred, (t % CT) * EPC + e) * inv;
         st16(y + (long)b * ldy + col * EPC, VecIO<T>::pack(v));
     }
 }
@@ -629,14 +639,15 @@ ese_bwd_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int 
                int lds, T* __restrict__ dx, int lddx, float* __restrict__ ds, int HW, int C, int CT,
                int accumulate) {
     constexpr int EPC = VecIO<T>::EPC;
-    extern __shared__ float sred[];
+    extern __shared__ unsigned long long sfix[];  // [CT*EPC] fixed point
+    unsigned long long* sred = sfix;
     const int t = threadIdx.x;
     const int RT = kThreads / CT;
     const int b = blockIdx.x;
     const int col = blockIdx.y * CT + t % CT;
     const int r = t / CT;
     const int CPR = C / EPC;
-    for (int i = t; i < CT * EPC; i += kThreads) sred[i] = 0.f;
+    for (int i = t; i < CT * EPC; i += kThreads) sred[i] = 0ull;
     __syncthreads();
     float sv[EPC];
     if (r < RT && col < CPR) {
@@ -663,14 +674,14 @@ ese_bwd_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int 
             st16(dx + row * lddx + col * EPC, VecIO<T>::pack(o));
         }
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) atomicAdd(&sred[(t % CT) * EPC + e], acc[e]);
+        for (int e = 0; e < EPC; ++e) lds_fix_add(sred, (t % CT) * EPC + e, acc[e]);
     }
     __syncthreads();
     if (r == 0 && col < CPR) {
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             const float d = (sv[e] > -3.f && sv[e] < 3.f) ? (1.f / 6.f) : 0.f;
-            ds[(long)b * C + col * EPC + e] = sred[(t % CT) * EPC + e] * d;
+            ds[(long)b * C + col * EPC + e] = lds_fix_get(sred, (t % CT) * EPC + e) * d;
         }
     }
 }
@@ -680,7 +691,7 @@ ese_bwd_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ x, int 
 // ---------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
-colsum_kernel(const T* __restrict__ a, int lda, long M, int C, RowMap rm, float* __restrict__ out) {
+colsum_kernel(const T* __restrict__ a, int lda, long M, int C, RowMap rm, float* __restrict__ out, int fixed) {
     constexpr int EPC = VecIO<T>::EPC;
     const int t = threadIdx.x;
     const int r = t / rm.CT;
@@ -699,7 +710,12 @@ colsum_kernel(const T* __restrict__ a, int lda, long M, int C, RowMap rm, float*
             for (int e = 0; e < EPC; ++e) s[e] += v[e];
         }
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) atomicAdd(&out[col * EPC + e], s[e]);
+        for (int e = 0; e < EPC; ++e) {
+            if (fixed)
+                vt_stat_add(out, col * EPC + e, s[e]);
+            else
+                atomicAdd(&out[col * EPC + e], s[e]);
+        }
     }
 }
 
@@ -914,6 +930,14 @@ inline int vt_bn_order() {
     return v;
 }
 
+__global__ void __launch_bounds__(kThreads)
+fixed_to_f32_kernel(const long long* __restrict__ q, float* __restrict__ dst, long n, int accumulate) {
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+        const double v = (double)q[2 * i] * 4096.0 + (double)q[2 * i + 1] * (1.0 / 8589934592.0);
+        dst[i] = accumulate ? dst[i] + (float)v : (float)v;
+    }
+}
+
 inline unsigned flat_blocks(long total, int per_thread = 1) {
     long b = (total + (long)kThreads * per_thread - 1) / ((long)kThreads * per_thread);
     if (b > 8192) b = 8192;
@@ -1111,7 +1135,7 @@ int vt_global_avgpool_fwd(const void* x, int32_t ldx, void* y, int32_t ldy, int3
     const int CT = pool_ct(C, epc);
     const dim3 grid(B, (C / epc + CT - 1) / CT);
     VT_DISPATCH_T(dtype, "vt_global_avgpool_fwd",
-                  hipLaunchKernelGGL(avgpool_fwd_kernel<T>, grid, dim3(kThreads), CT * epc * sizeof(float),
+                  hipLaunchKernelGGL(avgpool_fwd_kernel<T>, grid, dim3(kThreads), CT * epc * sizeof(unsigned long long),
                                      (hipStream_t)stream, (const T*)x, ldx, (T*)y, ldy, HW, C, CT));
     VT_CHECK_LAUNCH("vt_global_avgpool_fwd");
     return VT_OK;
@@ -1199,21 +1223,38 @@ int vt_ese_gate_bwd(const void* dy, int32_t lddy, const void* x, int32_t ldx, co
     const int CT = pool_ct(C, epc);
     const dim3 grid(B, (C / epc + CT - 1) / CT);
     VT_DISPATCH_T(dtype, "vt_ese_gate_bwd",
-                  hipLaunchKernelGGL(ese_bwd_kernel<T>, grid, dim3(kThreads), CT * epc * sizeof(float),
+                  hipLaunchKernelGGL(ese_bwd_kernel<T>, grid, dim3(kThreads), CT * epc * sizeof(unsigned long long),
                                      (hipStream_t)stream, (const T*)dy, lddy, (const T*)x, ldx, (const T*)s,
                                      lds, (T*)dx, lddx, ds, HW, C, CT, accumulate));
     VT_CHECK_LAUNCH("vt_ese_gate_bwd");
     return VT_OK;
 }
 
-int vt_colsum(const void* a, int32_t lda, int64_t M, int32_t C, int32_t dtype, float* out, void* stream) {
+static int colsum_impl(const void* a, int32_t lda, int64_t M, int32_t C, int32_t dtype, float* out, int fixed,
+                       void* stream) {
     VT_REQUIRE(M > 0 && out, VT_ERR_INVALID, "vt_colsum: bad argument");
     VT_TRY(check_mat("vt_colsum(a)", a, lda, C, dtype));
     const RowMap rm = RowMap::make(C, vt_epc(dtype), M, 256);
     VT_DISPATCH_T(dtype, "vt_colsum",
                   hipLaunchKernelGGL(colsum_kernel<T>, dim3(rm.blocks(M)), dim3(kThreads), 0,
-                                     (hipStream_t)stream, (const T*)a, lda, (long)M, C, rm, out));
+                                     (hipStream_t)stream, (const T*)a, lda, (long)M, C, rm, out, fixed));
     VT_CHECK_LAUNCH("vt_colsum");
+    return VT_OK;
+}
+
+int vt_colsum(const void* a, int32_t lda, int64_t M, int32_t C, int32_t dtype, float* out, void* stream) {
+    return colsum_impl(a, lda, M, C, dtype, out, 0, stream);
+}
+
+int vt_colsum_fixed(const void* a, int32_t lda, int64_t M, int32_t C, int32_t dtype, void* q, void* stream) {
+    return colsum_impl(a, lda, M, C, dtype, (float*)q, 1, stream);
+}
+
+int vt_fixed_to_f32(const void* q, float* dst, int64_t n, int32_t accumulate, void* stream) {
+    VT_REQUIRE(q && dst && n > 0, VT_ERR_INVALID, "vt_fixed_to_f32: bad argument");
+    hipLaunchKernelGGL(fixed_to_f32_kernel, dim3(flat_blocks(n)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const long long*)q, dst, (long)n, accumulate);
+    VT_CHECK_LAUNCH("vt_fixed_to_f32");
     return VT_OK;
 }
 

@@ -137,8 +137,11 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
         case VT_OP_ESE_BWD:  // ptr: dy x s dx ds | i: lddy ldx lds lddx B HW C accumulate dtype
             return vt_ese_gate_bwd(P[0], I[0], P[1], I[1], P[2], I[2], P[3], I[3], (float*)P[4], I[4], I[5],
                                    I[6], I[7], I[8], st);
-        case VT_OP_COLSUM:  // ptr: a out | i: lda C dtype | f: M
-            return vt_colsum(P[0], I[0], (int64_t)F[0], I[1], I[2], (float*)P[1], st);
+        case VT_OP_COLSUM:  // ptr: a out | i: lda C dtype fixed | f: M
+            return I[3] ? vt_colsum_fixed(P[0], I[0], (int64_t)F[0], I[1], I[2], P[1], st)
+                        : vt_colsum(P[0], I[0], (int64_t)F[0], I[1], I[2], (float*)P[1], st);
+        case VT_OP_FIXED_TO_F32:  // ptr: q dst | i: accumulate | f: n
+            return vt_fixed_to_f32(P[0], (float*)P[1], (int64_t)F[0], I[0], st);
         case VT_OP_XENT:  // ptr: logits labels loss dlogits [mix] | i: ldl lddl B N dtype | f: eps grad_scale
             if (P[4])
                 return vt_softmax_xent_mix(P[0], I[0], (const int64_t*)P[1], (float)F[0], (float)F[1], (float*)P[2],

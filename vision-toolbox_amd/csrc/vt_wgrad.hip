@@ -35,6 +35,7 @@ struct WgradArgs {
     float* dw;
     int B, Hi, Wi, Cin, ldx, Ho, Wo, sh, sw, h0, w0, Cout, ldy, ntaps;
     int M, Ktot, ldgw, tiles_n, tiles_k, chunk, ablate;
+    int fixed;  // dw is a fixed-point shadow (VT_CONV_WGRAD_FIXED)
     unsigned magic_w, magic_h;  // ceil(2^32 / Wo), ceil(2^32 / Ho): exact n / d for n < 2^16
     int8_t dh[VT_MAX_TAPS];
     int8_t dwv[VT_MAX_TAPS];
@@ -303,7 +304,12 @@ __global__ void __launch_bounds__(256 * G) wgrad_kernel(const WgradArgs p) {
             const int n = n0 + h * ROWS + nrow, k = k0 + kcol;
             const int gq = ((nrow & 15) >> 2);  // the row's g at write time
             const float v = sAcc[nrow * 128 + (kcol ^ (gq << 4))];
-            if (n < p.Cout && k < p.Ktot && !p.ablate) atomicAdd(p.dw + ((long)n * p.ldgw + k), v);
+            if (n < p.Cout && k < p.Ktot && !p.ablate) {
+                if (p.fixed)
+                    vt_stat_add(p.dw, (long)n * p.ldgw + k, v);
+                else
+                    atomicAdd(p.dw + ((long)n * p.ldgw + k), v);
+            }
         }
         if (HALVES > 1) __syncthreads();
     }
@@ -385,6 +391,7 @@ extern "C" int vt_conv_wgrad(const vt_conv_desc* d, const void* x, const void* d
     a.chunk = (int)chunk;
     static const int ablate = getenv("VT_WGRAD_ABLATE") ? atoi(getenv("VT_WGRAD_ABLATE")) : 0;  // timing experiments
     a.ablate = ablate;
+    a.fixed = (d->flags & VT_CONV_WGRAD_FIXED) ? 1 : 0;
 
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)tiles, (unsigned)split);

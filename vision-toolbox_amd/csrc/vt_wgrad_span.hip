@@ -47,6 +47,7 @@ struct WsArgs {
     short o[9];              // d_t - dmin
     int ntaps, tgn;          // taps (<= 9) and how many of them the first tap group owns (<= 5)
     long rowx;               // elements between image rows of x (W*ldx for a dense tensor; larger for a row-parity view)
+    int fixed;               // dw is a fixed-point shadow (VT_CONV_WGRAD_FIXED)
     int cblk, cin_dst;       // flush map (cblk > 0): input channel c -> destination tap map[t][c / cblk], channel c % cblk
     signed char map[9][4];   // (-1: the column is dropped)
 };
@@ -290,7 +291,10 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
                     if (td < 0) continue;
                     col = (long)td * p.cin_dst + (c0 + c - blk * p.cblk);
                 }
-                atomicAdd(p.dw + ((long)(n0 + n) * p.ldgw + col), sAcc[img * IMG + n * PITCH + c]);
+                if (p.fixed)
+                    vt_stat_add(p.dw, (long)(n0 + n) * p.ldgw + col, sAcc[img * IMG + n * PITCH + c]);
+                else
+                    atomicAdd(p.dw + ((long)(n0 + n) * p.ldgw + col), sAcc[img * IMG + n * PITCH + c]);
             }
         }
     }
@@ -392,6 +396,7 @@ int vt_wgrad_span_dispatch(const vt_conv_desc* d, const void* x, const void* dz,
     a.x = (const bf16_t*)x, a.dz = (const bf16_t*)dz, a.dw = dw;
     a.B = d->B, a.H = d->Hi, a.W = d->Wi, a.Cin = d->Cin, a.ldx = d->ldx, a.Cout = d->Cout, a.ldy = d->ldy;
     a.ldgw = ldgw;
+    a.fixed = (d->flags & VT_CONV_WGRAD_FIXED) ? 1 : 0;
     a.rowx = (long)d->Wi * d->ldx;
     a.PH = d->Hi + ph, a.PW = d->Wi + pw;
     return launch_ws_taps(a, 9, eh, ew, (hipStream_t)stream);
@@ -426,6 +431,7 @@ int vt_wgrad_span_s2_dispatch(const vt_conv_desc* d, const void* x, const void* 
     a.dz = (const bf16_t*)dz, a.dw = dw;
     a.B = d->B, a.H = d->Ho, a.W = d->Wo, a.Cin = 2 * d->Cin, a.ldx = 2 * d->ldx, a.Cout = d->Cout, a.ldy = d->ldy;
     a.ldgw = ldgw;
+    a.fixed = (d->flags & VT_CONV_WGRAD_FIXED) ? 1 : 0;
     a.rowx = 2L * d->Wi * d->ldx;
     a.cblk = d->Cin, a.cin_dst = d->Cin;
     memset(a.map, -1, sizeof(a.map));

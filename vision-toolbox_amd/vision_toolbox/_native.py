@@ -17,7 +17,7 @@ LIB_PATH = Path(os.environ.get("VT_AMD_LIB", _HERE.parent / "csrc" / "libvt_amd.
 VT_OK, VT_ERR_INVALID, VT_ERR_UNSUPPORTED, VT_ERR_HIP = 0, 1, 2, 3
 VT_F32, VT_BF16 = 0, 1
 VT_MAX_TAPS = 36
-VT_CONV_RELU, VT_CONV_STATS, VT_CONV_RESIDUAL, VT_CONV_AFFINE, VT_CONV_D2S = 1, 2, 4, 8, 16
+VT_CONV_RELU, VT_CONV_STATS, VT_CONV_RESIDUAL, VT_CONV_AFFINE, VT_CONV_D2S, VT_CONV_WGRAD_FIXED = 1, 2, 4, 8, 16, 32
 VT_STAT_REPLICAS = 32
 # a statistics buffer is int64[VT_STAT_REPLICAS][2][C][2]: value = hi * 2^12 + lo / 2^33 (vt_amd.h)
 
@@ -83,7 +83,8 @@ VT_OP_MAX_PTR, VT_OP_MAX_INT, VT_OP_MAX_FLT, VT_MAX_BASES = 12, 110, 8, 16
     OP_FORK_WAIT,
     OP_STEM_BWD_REDUCE,
     OP_STEM_BWD_COMBINE,
-) = range(1, 31)
+    OP_FIXED_TO_F32,
+) = range(1, 32)
 OP_SIDE_STREAM = 0x10000  # OR-ed into Op.kind: enqueue on the side stream
 
 OP_NAMES = {
@@ -115,6 +116,7 @@ OP_NAMES = {
     OP_FORK_WAIT: "fork_wait",
     OP_STEM_BWD_REDUCE: "stem_bwd_reduce",
     OP_STEM_BWD_COMBINE: "stem_bwd_combine",
+    OP_FIXED_TO_F32: "fixed_to_f32",
     OP_RESAMPLE_FWD: "resample_fwd",
     OP_RESAMPLE_BWD: "resample_bwd",
 }
@@ -174,6 +176,8 @@ SYMBOLS = {
     "vt_bn_act_apply": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "vt_bn_act_bwd_reduce": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "vt_bn_bwd_finalize": (_i32, [_vp, _i32, _f64, _f64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "vt_fixed_to_f32": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "vt_colsum_fixed": (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "vt_stem_bn_bwd_scratch_bytes": (_i64, [_i32]),
     "vt_stem_bn_bwd_reduce": (_i32, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "vt_stem_bn_bwd_combine": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp]),

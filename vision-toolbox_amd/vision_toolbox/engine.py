@@ -247,6 +247,10 @@ class Builder:
         # 3x3 stride-2 data gradients whose dz has at most this many channels (the HBM-bound ones) run as ONE
         # depth-to-space launch instead of four parity-class launches that each re-read dz
         self.dgrad_d2s_maxc = int(os.environ.get("VT_DGRAD_D2S_MAXC", "64"))
+        # deterministic mode: the filter gradients and bias column sums, the last sums still made with f32 atomics, go
+        # through a fixed-point shadow (integer atomics) and one conversion pass each; with the fixed-point BatchNorm
+        # statistics every gradient and every parameter update is then bit-identical from run to run
+        self.deterministic = os.environ.get("VT_DETERMINISTIC", "0") != "0"
         self._hoisted: list[N.Op] = []
         # SyncBatchNorm (configs/base.yaml:22): the trainer all-reduces every layer's statistics
         # between the kernel that accumulates them and the finalize kernel; the finalize kernels
@@ -581,7 +585,7 @@ class Builder:
                       [x.addr(), wptr, y.addr(), None, self.pref(conv.bias) if conv.bias is not None else None,
                        residual.addr() if residual else None, None], desc=d)
 
-        stem_fused = (self.stem_fused_bwd and track and padded and has_bn and not fused and residual is None and
+        stem_fused = (self.stem_fused_bwd and not self.deterministic and track and padded and has_bn and not fused and residual is None and
                       not x.needs_grad and w.requires_grad and dt == N.VT_BF16 and Cout == 32 and k == 3 and s == 1 and
                       pad == 1 and x.C == 8 and x.ld == 8 and x.W <= 896 and B * (x.H + 1) * (x.W + 1) < 0x7fff0000)  # (ring in LDS)
         if track:
@@ -626,7 +630,12 @@ class Builder:
                 else:
                     dz = dy
                     if conv.bias is not None and conv.bias.requires_grad:
-                        self.emit(N.OP_COLSUM, [dz.addr(), self.pgrad(conv.bias)], [dz.ld, Cout, dt], [M])
+                        if self.deterministic:
+                            qb = self.zeroed_f32(4 * Cout, "dbq", bwd=True)
+                            self.emit(N.OP_COLSUM, [dz.addr(), self.bp(qb)], [dz.ld, Cout, dt, 1], [M])
+                            self.emit(N.OP_FIXED_TO_F32, [self.bp(qb), self.pgrad(conv.bias)], [1], [Cout])
+                        else:
+                            self.emit(N.OP_COLSUM, [dz.addr(), self.pgrad(conv.bias)], [dz.ld, Cout, dt], [M])
                 # filter gradient: needs only x and dz and nothing in backward waits for it, so it goes to the
                 # side stream.  It is released AFTER this unit's data gradient (wgrad_late): both are MFMA-bound
                 # and only slow each other down, whereas the HBM-bound BatchNorm passes of the next unit in
@@ -634,14 +643,24 @@ class Builder:
                 def emit_wgrad(wait_only=False):
                     if not w.requires_grad:
                         return
-                    dfwd = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, dz.ld, ldw, 0)
+                    det = self.deterministic
+                    dfwd = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, dz.ld, ldw, N.VT_CONV_WGRAD_FIXED if det else 0)
                     self.emit(N.OP_FORK_WAIT if wait_only else N.OP_FORK)
+                    nel = Cout * ntaps * x.C
+                    if det:  # fixed-point shadow of the gradient (16 bytes per weight), then one conversion pass
+                        q = self.zeroed_f32(4 * nel, "dwq", bwd=True)
+                        self.emit(N.OP_CONV_WGRAD, [x.addr(), dz.addr(), self.bp(q)], desc=dfwd, extra_ints=[ldw], side=True)
                     if padded:
-                        ws = self.zeroed_f32(Cout * ntaps * x.C, "dwpad", bwd=True)
-                        self.emit(N.OP_CONV_WGRAD, [x.addr(), dz.addr(), self.bp(ws)], desc=dfwd, extra_ints=[ldw],
-                                  side=True)
+                        ws = self.zeroed_f32(nel, "dwpad", bwd=True)
+                        if det:
+                            self.emit(N.OP_FIXED_TO_F32, [self.bp(q), self.bp(ws)], [0], [nel], side=True)
+                        else:
+                            self.emit(N.OP_CONV_WGRAD, [x.addr(), dz.addr(), self.bp(ws)], desc=dfwd, extra_ints=[ldw],
+                                      side=True)
                         self.emit(N.OP_COPY2D, [self.bp(ws), self.pgrad(w)], [N.VT_F32, N.VT_F32, Cin_w, 1],
                                   [x.C, Cin_w, Cout * ntaps], side=True)
+                    elif det:
+                        self.emit(N.OP_FIXED_TO_F32, [self.bp(q), self.pgrad(w)], [1], [nel], side=True)
                     else:
                         self.emit(N.OP_CONV_WGRAD, [x.addr(), dz.addr(), self.pgrad(w)], desc=dfwd,
                                   extra_ints=[ldw], side=True)
