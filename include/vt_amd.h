@@ -48,10 +48,6 @@ extern "C" {
 #define VT_CONV_STATS 2    /* accumulate per-channel sum / sum-of-squares       */
 #define VT_CONV_RESIDUAL 4 /* y += residual (after relu)                        */
 #define VT_CONV_AFFINE 8   /* y = y*scale[c] + shift[c]; scale==NULL means 1    */
-#define VT_CONV_WGRAD_FIXED 32 /* vt_conv_wgrad only: `dw` is a FIXED-POINT shadow of the gradient, int64[rows*ldgw][2] with
-                            * value = hi*2^12 + lo/2^33 (as the statistics buffers), accumulated with integer atomics:
-                            * the sum over the pixel splits no longer depends on their order.  Zeroed by the caller;
-                            * vt_fixed_to_f32 folds it into the f32 gradient.  (Deterministic mode.) */
 #define VT_CONV_D2S 16     /* depth-to-space 2x2: the Cout = 4*C' columns of grid pixel (i, j) are the output pixels
                             * (2i+a, 2j+b) x C' channels, column = (2a+b)*C' + c; needs oHs = oWs = 2, oh0 = ow0 = 0,
                             * oH = 2*Ho, oW = 2*Wo, no STATS / AFFINE / RELU.  One launch then forms the whole data
@@ -120,7 +116,15 @@ int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w, void* y,
 int vt_conv_wgrad(const vt_conv_desc* d, const void* x, const void* dz, float* dw,
                   int32_t ldgw, void* stream);
 
-/* dst[i] (+)= hi[i]*2^12 + lo[i]/2^33 for a fixed-point buffer q = int64[n][2] (VT_CONV_WGRAD_FIXED, vt_colsum_fixed). */
+/* The same filter gradient in two stages: every (tile, pixel split) workgroup stores its partial tile into its own slab of
+ * `scratch` (plain stores) and a second kernel adds the slabs to dw in split order -- no atomics, and a result that does
+ * not depend on the order in which workgroups finish.  One scratch of ~40 MB serves every layer (launches on one stream
+ * reuse it, so it stays in the memory-side cache); a scratch too small for a layer's usual split gets fewer, longer splits,
+ * never atomics across splits.  (Deterministic mode.) */
+int vt_conv_wgrad_slabs(const vt_conv_desc* d, const void* x, const void* dz, float* dw, int32_t ldgw,
+                        void* scratch, int64_t scratch_bytes, void* stream);
+
+/* dst[i] (+)= hi[i]*2^12 + lo[i]/2^33 for a fixed-point buffer q = int64[n][2] (vt_colsum_fixed). */
 int vt_fixed_to_f32(const void* q, float* dst, int64_t n, int32_t accumulate, void* stream);
 
 /* Re-pack a [Cout][ntaps][Cin] filter (f32 master or dtype mirror) into the

@@ -1,7 +1,8 @@
 """VT_DETERMINISTIC=1: two fresh train runs (same seed, same data, two SGD steps with momentum) must end with
 BIT-IDENTICAL parameters, gradients, momentum and BatchNorm state.  What makes that possible: the BatchNorm statistics
-and backward sums are always fixed-point integer atomics (vt_common.h), and in this mode the filter gradients and bias
-column sums go through a fixed-point shadow too (VT_CONV_WGRAD_FIXED, vt_colsum_fixed, vt_fixed_to_f32).  (The scalar
+and backward sums are always fixed-point integer atomics (vt_common.h), and in this mode the filter gradients are
+two-stage (vt_conv_wgrad_slabs: stored partial tiles + an ordered reducer) and the bias column sums go through a
+fixed-point shadow (vt_colsum_fixed, vt_fixed_to_f32).  (The scalar
 loss is still a float atomic over the batch rows: it is reported, nothing is computed from it.)
 
     VT_DETERMINISTIC=1 python tools/deterministic_check.py [model] [f32|bf16]        (GPU box)"""
@@ -43,7 +44,7 @@ def main():
         rel = [float((u.double() - v.double()).norm() / (v.double().norm() + 1e-30)) for u, v in zip(a, b)]
         print(f"run {r + 1}: params/grads/momentum/bn-state identical {same} (rel diff {['%.1e' % v for v in rel]})", flush=True)
         ok = ok and all(same)
-    print("ops:", {k: v for k, v in hist.items() if k in ("conv_wgrad", "fixed_to_f32", "colsum", "stem_bwd_reduce")})
+    print("ops:", {k: v for k, v in hist.items() if k in ("conv_wgrad", "fixed_to_f32", "colsum", "stem_bwd_reduce")}, "slab MiB", os.environ.get("VT_WGRAD_SLABS_MB", "48 (default in this mode)"))
     det = os.environ.get("VT_DETERMINISTIC", "0") != "0"
     if det:
         assert ok, "deterministic mode produced different bits"

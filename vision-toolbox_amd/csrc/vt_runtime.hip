@@ -85,9 +85,12 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
             return vt_conv_igemm(&d, P[0], P[1], P[2], (const float*)P[3], (const float*)P[4], P[5],
                                  (float*)P[6], st);
         }
-        case VT_OP_CONV_WGRAD: {  // ptr: x dz dw | i: vt_conv_desc image, then ldgw
+        case VT_OP_CONV_WGRAD: {  // ptr: x dz dw [scratch] | i: vt_conv_desc image, then ldgw, scratch MiB
             vt_conv_desc d;
             memcpy(&d, I, sizeof(d));
+            if (P[3])
+                return vt_conv_wgrad_slabs(&d, P[0], P[1], (float*)P[2], I[sizeof(d) / 4], P[3],
+                                           (int64_t)I[sizeof(d) / 4 + 1] << 20, st);
             return vt_conv_wgrad(&d, P[0], P[1], (float*)P[2], I[sizeof(d) / 4], st);
         }
         case VT_OP_PACK_DGRAD:  // ptr: w out | i: src_dtype ldw dst_dtype nsel Cout ntaps Cin _ sel[36]

@@ -35,7 +35,8 @@ struct WgradArgs {
     float* dw;
     int B, Hi, Wi, Cin, ldx, Ho, Wo, sh, sw, h0, w0, Cout, ldy, ntaps;
     int M, Ktot, ldgw, tiles_n, tiles_k, chunk, ablate;
-    int fixed;  // dw is a fixed-point shadow (VT_CONV_WGRAD_FIXED)
+    float* slab;       // partial tiles go to slab[blockIdx.y * slab_stride + ...] with plain stores (no atomics)
+    long slab_stride;  // elements per pixel split: Cout * ldgw
     unsigned magic_w, magic_h;  // ceil(2^32 / Wo), ceil(2^32 / Ho): exact n / d for n < 2^16
     int8_t dh[VT_MAX_TAPS];
     int8_t dwv[VT_MAX_TAPS];
@@ -305,8 +306,8 @@ __global__ void __launch_bounds__(256 * G) wgrad_kernel(const WgradArgs p) {
             const int gq = ((nrow & 15) >> 2);  // the row's g at write time
             const float v = sAcc[nrow * 128 + (kcol ^ (gq << 4))];
             if (n < p.Cout && k < p.Ktot && !p.ablate) {
-                if (p.fixed)
-                    vt_stat_add(p.dw, (long)n * p.ldgw + k, v);
+                if (p.slab)
+                    p.slab[(long)blockIdx.y * p.slab_stride + (long)n * p.ldgw + k] = v;
                 else
                     atomicAdd(p.dw + ((long)n * p.ldgw + k), v);
             }
@@ -319,13 +320,60 @@ __global__ void __launch_bounds__(256 * G) wgrad_kernel(const WgradArgs p) {
 
 // vt_wgrad_span.hip: stride-1 3x3 bf16 layers; -1 when it does not apply
 int vt_wgrad_span_dispatch(const vt_conv_desc* d, const void* x, const void* dz, float* dw, int32_t ldgw,
-                           void* stream);
+                           float* scratch, int64_t scratch_bytes, void* stream);
 // vt_wgrad_span.hip: stride-2 3x3 bf16 layers on even maps as two stride-1 launches over row-parity views
 int vt_wgrad_span_s2_dispatch(const vt_conv_desc* d, const void* x, const void* dz, float* dw, int32_t ldgw,
                               void* stream);
 
+// dw[n][k] += sum over the splits of slab[s][n][k], in split order: the ordered second stage of the filter gradient
+__global__ void __launch_bounds__(256) wgrad_reduce_slabs_kernel(const float* __restrict__ slab, long stride, int split,
+                                                                 float* __restrict__ dw, int Cout, int Ktot, int ldgw) {
+    const long total = (long)Cout * (Ktot / 4);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / (Ktot / 4), k = (i - n * (Ktot / 4)) * 4;
+        const long off = n * ldgw + k;
+        float4 acc = *(const float4*)(slab + off);
+        for (int s = 1; s < split; ++s) {
+            const float4 v = *(const float4*)(slab + (long)s * stride + off);
+            acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+        }
+        float4 o = *(float4*)(dw + off);
+        o.x += acc.x, o.y += acc.y, o.z += acc.z, o.w += acc.w;
+        *(float4*)(dw + off) = o;
+    }
+}
+
+int vt_wgrad_reduce_slabs(const float* slab, long stride, int split, float* dw, int Cout, int Ktot, int ldgw,
+                          hipStream_t st) {
+    const long total = (long)Cout * (Ktot / 4);
+    long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, slab, stride, split, dw, Cout,
+                       Ktot, ldgw);
+    VT_CHECK_LAUNCH("vt_conv_wgrad(reduce)");
+    return VT_OK;
+}
+
+static int wgrad_impl(const vt_conv_desc* d, const void* x, const void* dz, float* dw, int32_t ldgw, float* scratch,
+                      int64_t scratch_bytes, void* stream);
+
 extern "C" int vt_conv_wgrad(const vt_conv_desc* d, const void* x, const void* dz, float* dw,
                              int32_t ldgw, void* stream) {
+    return wgrad_impl(d, x, dz, dw, ldgw, nullptr, 0, stream);
+}
+
+// Two-stage filter gradient: every (tile, pixel split) workgroup STORES its partial tile into its own slab of `scratch`
+// and a second kernel adds the slabs to dw in split order -- no atomics (they run at ~1 TB/s; a 40 MB scratch that is
+// reused by every layer stays in the memory-side cache) and the result does not depend on the order of the workgroups.
+// A scratch too small for a layer's usual split gets fewer, longer splits (never atomics across splits); the row-parity
+// stride-2 path (atomic, column-mapped) is not taken in this mode.
+extern "C" int vt_conv_wgrad_slabs(const vt_conv_desc* d, const void* x, const void* dz, float* dw, int32_t ldgw,
+                                   void* scratch, int64_t scratch_bytes, void* stream) {
+    return wgrad_impl(d, x, dz, dw, ldgw, (float*)scratch, scratch_bytes, stream);
+}
+
+static int wgrad_impl(const vt_conv_desc* d, const void* x, const void* dz, float* dw, int32_t ldgw, float* scratch,
+                      int64_t scratch_bytes, void* stream) {
     VT_REQUIRE(d && x && dz && dw, VT_ERR_INVALID, "vt_conv_wgrad: null argument");
     VT_REQUIRE(d->dtype == VT_F32 || d->dtype == VT_BF16, VT_ERR_UNSUPPORTED, "vt_conv_wgrad: dtype %d",
                d->dtype);
@@ -344,11 +392,12 @@ extern "C" int vt_conv_wgrad(const vt_conv_desc* d, const void* x, const void* d
     const long M = (long)d->B * d->Ho * d->Wo;
     VT_REQUIRE(in_elems < 0x7fffffffL && M * d->ldy < 0x7fffffffL, VT_ERR_UNSUPPORTED,
                "vt_conv_wgrad: tensor exceeds 2^31 elements");
+    const bool slabs = scratch && (d->ntaps * d->Cin) % 4 == 0 && ldgw % 4 == 0;
     {
-        const int rc = vt_wgrad_span_dispatch(d, x, dz, dw, ldgw, stream);
+        const int rc = vt_wgrad_span_dispatch(d, x, dz, dw, ldgw, slabs ? scratch : nullptr, scratch_bytes, stream);
         if (rc >= 0) return rc;
     }
-    {
+    if (!slabs) {  // (the row-parity stride-2 launches scatter through a column map: atomic flush only)
         const int rc = vt_wgrad_span_s2_dispatch(d, x, dz, dw, ldgw, stream);
         if (rc >= 0) return rc;
     }
@@ -384,6 +433,9 @@ extern "C" int vt_conv_wgrad(const vt_conv_desc* d, const void* x, const void* d
     const long max_split = (M + 8L * pk * G - 1) / (8L * pk * G);
     if (split > max_split) split = max_split;
     if (split > max_split_env) split = max_split_env;
+    const long slab_stride = (long)d->Cout * ldgw;
+    // two-stage mode never falls back to atomics: a scratch too small for the chosen split gets fewer, longer splits
+    if (slabs && split * slab_stride * 4 > scratch_bytes) split = scratch_bytes / (slab_stride * 4);
     if (split < 1) split = 1;
     long chunk = (M + split - 1) / split;
     chunk = (chunk + (long)pk * G - 1) / ((long)pk * G) * ((long)pk * G);
@@ -391,7 +443,9 @@ extern "C" int vt_conv_wgrad(const vt_conv_desc* d, const void* x, const void* d
     a.chunk = (int)chunk;
     static const int ablate = getenv("VT_WGRAD_ABLATE") ? atoi(getenv("VT_WGRAD_ABLATE")) : 0;  // timing experiments
     a.ablate = ablate;
-    a.fixed = (d->flags & VT_CONV_WGRAD_FIXED) ? 1 : 0;
+    const bool use_slabs = slabs && split > 1 && split * slab_stride * 4 <= scratch_bytes;  // (split 1: one writer per element)
+    a.slab = use_slabs ? scratch : nullptr;
+    a.slab_stride = slab_stride;
 
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)tiles, (unsigned)split);
@@ -427,5 +481,6 @@ extern "C" int vt_conv_wgrad(const vt_conv_desc* d, const void* x, const void* d
     }
 #undef VT_WG_LAUNCH
     VT_CHECK_LAUNCH("vt_conv_wgrad");
+    if (use_slabs) return vt_wgrad_reduce_slabs(scratch, slab_stride, (int)split, dw, d->Cout, a.Ktot, ldgw, st);
     return VT_OK;
 }

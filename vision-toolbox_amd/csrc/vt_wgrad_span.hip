@@ -47,7 +47,8 @@ struct WsArgs {
     short o[9];              // d_t - dmin
     int ntaps, tgn;          // taps (<= 9) and how many of them the first tap group owns (<= 5)
     long rowx;               // elements between image rows of x (W*ldx for a dense tensor; larger for a row-parity view)
-    int fixed;               // dw is a fixed-point shadow (VT_CONV_WGRAD_FIXED)
+    float* slab;             // partial tiles go to slab[blockIdx.y * slab_stride + ...] with plain stores (no atomics)
+    long slab_stride;        // elements per pixel split: Cout * ldgw
     int cblk, cin_dst;       // flush map (cblk > 0): input channel c -> destination tap map[t][c / cblk], channel c % cblk
     signed char map[9][4];   // (-1: the column is dropped)
 };
@@ -291,8 +292,8 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
                     if (td < 0) continue;
                     col = (long)td * p.cin_dst + (c0 + c - blk * p.cblk);
                 }
-                if (p.fixed)
-                    vt_stat_add(p.dw, (long)(n0 + n) * p.ldgw + col, sAcc[img * IMG + n * PITCH + c]);
+                if (p.slab)
+                    p.slab[(long)blockIdx.y * p.slab_stride + (long)(n0 + n) * p.ldgw + col] = sAcc[img * IMG + n * PITCH + c];
                 else
                     atomicAdd(p.dw + ((long)(n0 + n) * p.ldgw + col), sAcc[img * IMG + n * PITCH + c]);
             }
@@ -328,7 +329,15 @@ int launch_ws(const WsArgs& a, long split, hipStream_t st) {
 
 // ring geometry, pixel split and launch for a filled-in WsArgs (x, dz, dw, B, H, W, Cin, ldx, Cout, ldy, ldgw, rowx, PH, PW
 // and the flush map are set); eh/ew = tap offsets in the position grid.  -1 when the ring would not fit.
-int launch_ws_taps(WsArgs& a, int ntaps, const int* eh, const int* ew, hipStream_t st) {
+}  // namespace
+
+int vt_wgrad_reduce_slabs(const float* slab, long stride, int split, float* dw, int Cout, int Ktot, int ldgw,
+                          hipStream_t st);  // vt_wgrad.hip
+
+namespace {
+
+int launch_ws_taps(WsArgs& a, int ntaps, const int* eh, const int* ew, hipStream_t st, float* scratch = nullptr,
+                   long scratch_bytes = 0) {
     a.S = a.PH * a.PW;
     a.magic_pw = (unsigned)((0x100000000ull + a.PW - 1) / a.PW);
     a.magic_ph = (unsigned)((0x100000000ull + a.PH - 1) / a.PH);
@@ -359,6 +368,8 @@ int launch_ws_taps(WsArgs& a, int ntaps, const int* eh, const int* ew, hipStream
     long split = target / tiles;
     const long max_split = (NP + 511) / 512;
     if (split > max_split) split = max_split;
+    if (scratch && !a.cblk && split * (long)a.Cout * a.ldgw * 4 > scratch_bytes)
+        split = scratch_bytes / ((long)a.Cout * a.ldgw * 4);  // two-stage mode: fewer, longer splits rather than atomics
     if (split < 1) split = 1;
     long chunk = (NP + split - 1) / split;
     chunk = (chunk + 31) / 32 * 32;
@@ -366,18 +377,30 @@ int launch_ws_taps(WsArgs& a, int ntaps, const int* eh, const int* ew, hipStream
     a.chunk = (int)chunk;
     static const int ablate = getenv("VT_WGRAD_ABLATE") ? atoi(getenv("VT_WGRAD_ABLATE")) : 0;  // timing experiments
     a.ablate = ablate;
+    a.slab_stride = (long)a.Cout * a.ldgw;
+    const bool use_slabs = scratch && !a.cblk && split > 1 && split * a.slab_stride * 4 <= scratch_bytes &&
+                           (ntaps * a.Cin) % 4 == 0 && a.ldgw % 4 == 0;
+    a.slab = use_slabs ? scratch : nullptr;
+    int rc;
     static const int wide = getenv("VT_WGRAD_SPAN_WIDE") ? atoi(getenv("VT_WGRAD_SPAN_WIDE")) : 1;
-    if (FI == 2 && FJ == 2) return wide ? launch_ws<2, 2, true>(a, split, st) : launch_ws<2, 2>(a, split, st);
-    if (FI == 2) return launch_ws<2, 1>(a, split, st);
-    if (FJ == 2) return launch_ws<1, 2>(a, split, st);
-    return launch_ws<1, 1>(a, split, st);
+    if (FI == 2 && FJ == 2)
+        rc = wide ? launch_ws<2, 2, true>(a, split, st) : launch_ws<2, 2>(a, split, st);
+    else if (FI == 2)
+        rc = launch_ws<2, 1>(a, split, st);
+    else if (FJ == 2)
+        rc = launch_ws<1, 2>(a, split, st);
+    else
+        rc = launch_ws<1, 1>(a, split, st);
+    if (rc == VT_OK && use_slabs)
+        rc = vt_wgrad_reduce_slabs(scratch, a.slab_stride, (int)split, a.dw, a.Cout, ntaps * a.Cin, a.ldgw, st);
+    return rc;
 }
 
 }  // namespace
 
 // returns -1 when this kernel does not apply (the caller then uses the general kernel)
 int vt_wgrad_span_dispatch(const vt_conv_desc* d, const void* x, const void* dz, float* dw, int32_t ldgw,
-                           void* stream) {
+                           float* scratch, int64_t scratch_bytes, void* stream) {
     static const int enabled = getenv("VT_WGRAD_SPAN") ? atoi(getenv("VT_WGRAD_SPAN")) : 1;
     if (!enabled) return -1;
     if (d->dtype != VT_BF16 || d->ntaps != 9 || d->sh != 1 || d->sw != 1 || d->Ho != d->Hi || d->Wo != d->Wi)
@@ -396,10 +419,9 @@ int vt_wgrad_span_dispatch(const vt_conv_desc* d, const void* x, const void* dz,
     a.x = (const bf16_t*)x, a.dz = (const bf16_t*)dz, a.dw = dw;
     a.B = d->B, a.H = d->Hi, a.W = d->Wi, a.Cin = d->Cin, a.ldx = d->ldx, a.Cout = d->Cout, a.ldy = d->ldy;
     a.ldgw = ldgw;
-    a.fixed = (d->flags & VT_CONV_WGRAD_FIXED) ? 1 : 0;
     a.rowx = (long)d->Wi * d->ldx;
     a.PH = d->Hi + ph, a.PW = d->Wi + pw;
-    return launch_ws_taps(a, 9, eh, ew, (hipStream_t)stream);
+    return launch_ws_taps(a, 9, eh, ew, (hipStream_t)stream, scratch, (long)scratch_bytes);
 }
 
 // Filter gradient of a 3x3 STRIDE-2 convolution (the first conv of every Darknet / CSPDarknet stage,
@@ -431,7 +453,6 @@ int vt_wgrad_span_s2_dispatch(const vt_conv_desc* d, const void* x, const void* 
     a.dz = (const bf16_t*)dz, a.dw = dw;
     a.B = d->B, a.H = d->Ho, a.W = d->Wo, a.Cin = 2 * d->Cin, a.ldx = 2 * d->ldx, a.Cout = d->Cout, a.ldy = d->ldy;
     a.ldgw = ldgw;
-    a.fixed = (d->flags & VT_CONV_WGRAD_FIXED) ? 1 : 0;
     a.rowx = 2L * d->Wi * d->ldx;
     a.cblk = d->Cin, a.cin_dst = d->Cin;
     memset(a.map, -1, sizeof(a.map));

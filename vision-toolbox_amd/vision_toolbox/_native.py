@@ -17,7 +17,7 @@ LIB_PATH = Path(os.environ.get("VT_AMD_LIB", _HERE.parent / "csrc" / "libvt_amd.
 VT_OK, VT_ERR_INVALID, VT_ERR_UNSUPPORTED, VT_ERR_HIP = 0, 1, 2, 3
 VT_F32, VT_BF16 = 0, 1
 VT_MAX_TAPS = 36
-VT_CONV_RELU, VT_CONV_STATS, VT_CONV_RESIDUAL, VT_CONV_AFFINE, VT_CONV_D2S, VT_CONV_WGRAD_FIXED = 1, 2, 4, 8, 16, 32
+VT_CONV_RELU, VT_CONV_STATS, VT_CONV_RESIDUAL, VT_CONV_AFFINE, VT_CONV_D2S = 1, 2, 4, 8, 16
 VT_STAT_REPLICAS = 32
 # a statistics buffer is int64[VT_STAT_REPLICAS][2][C][2]: value = hi * 2^12 + lo / 2^33 (vt_amd.h)
 
@@ -176,6 +176,7 @@ SYMBOLS = {
     "vt_bn_act_apply": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "vt_bn_act_bwd_reduce": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "vt_bn_bwd_finalize": (_i32, [_vp, _i32, _f64, _f64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "vt_conv_wgrad_slabs": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i32, _vp, _i64, _vp]),
     "vt_fixed_to_f32": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "vt_colsum_fixed": (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "vt_stem_bn_bwd_scratch_bytes": (_i64, [_i32]),

@@ -247,10 +247,13 @@ class Builder:
         # 3x3 stride-2 data gradients whose dz has at most this many channels (the HBM-bound ones) run as ONE
         # depth-to-space launch instead of four parity-class launches that each re-read dz
         self.dgrad_d2s_maxc = int(os.environ.get("VT_DGRAD_D2S_MAXC", "64"))
-        # deterministic mode: the filter gradients and bias column sums, the last sums still made with f32 atomics, go
-        # through a fixed-point shadow (integer atomics) and one conversion pass each; with the fixed-point BatchNorm
-        # statistics every gradient and every parameter update is then bit-identical from run to run
+        # deterministic mode: the last sums still made with f32 atomics take an order-free form -- the filter gradients
+        # become two-stage (partial tiles stored into slabs of ONE scratch that every layer reuses, then an ordered
+        # reducer), the bias column sums go through a fixed-point shadow, the stem takes its three-pass backward; with
+        # the fixed-point BatchNorm statistics every gradient and parameter update is then bit-identical from run to run
         self.deterministic = os.environ.get("VT_DETERMINISTIC", "0") != "0"
+        self.wgrad_slab_mb = int(os.environ.get("VT_WGRAD_SLABS_MB", "48" if self.deterministic else "0"))  # 0 = atomics
+        self._wgrad_slab = None
         self._hoisted: list[N.Op] = []
         # SyncBatchNorm (configs/base.yaml:22): the trainer all-reduces every layer's statistics
         # between the kernel that accumulates them and the finalize kernel; the finalize kernels
@@ -643,27 +646,22 @@ class Builder:
                 def emit_wgrad(wait_only=False):
                     if not w.requires_grad:
                         return
-                    det = self.deterministic
-                    dfwd = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, dz.ld, ldw, N.VT_CONV_WGRAD_FIXED if det else 0)
+                    dfwd = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, dz.ld, ldw, 0)
                     self.emit(N.OP_FORK_WAIT if wait_only else N.OP_FORK)
-                    nel = Cout * ntaps * x.C
-                    if det:  # fixed-point shadow of the gradient (16 bytes per weight), then one conversion pass
-                        q = self.zeroed_f32(4 * nel, "dwq", bwd=True)
-                        self.emit(N.OP_CONV_WGRAD, [x.addr(), dz.addr(), self.bp(q)], desc=dfwd, extra_ints=[ldw], side=True)
+                    slab, slab_mb = None, 0
+                    if self.wgrad_slab_mb > 0:  # two-stage (stored slabs + ordered reducer) instead of f32 atomics
+                        if self._wgrad_slab is None:
+                            self._wgrad_slab = self.alloc(self.wgrad_slab_mb << 20, "wgrad_slabs")
+                        slab, slab_mb = self.bp(self._wgrad_slab), self.wgrad_slab_mb
                     if padded:
-                        ws = self.zeroed_f32(nel, "dwpad", bwd=True)
-                        if det:
-                            self.emit(N.OP_FIXED_TO_F32, [self.bp(q), self.bp(ws)], [0], [nel], side=True)
-                        else:
-                            self.emit(N.OP_CONV_WGRAD, [x.addr(), dz.addr(), self.bp(ws)], desc=dfwd, extra_ints=[ldw],
-                                      side=True)
+                        ws = self.zeroed_f32(Cout * ntaps * x.C, "dwpad", bwd=True)
+                        self.emit(N.OP_CONV_WGRAD, [x.addr(), dz.addr(), self.bp(ws), slab], desc=dfwd,
+                                  extra_ints=[ldw, slab_mb], side=True)
                         self.emit(N.OP_COPY2D, [self.bp(ws), self.pgrad(w)], [N.VT_F32, N.VT_F32, Cin_w, 1],
                                   [x.C, Cin_w, Cout * ntaps], side=True)
-                    elif det:
-                        self.emit(N.OP_FIXED_TO_F32, [self.bp(q), self.pgrad(w)], [1], [nel], side=True)
                     else:
-                        self.emit(N.OP_CONV_WGRAD, [x.addr(), dz.addr(), self.pgrad(w)], desc=dfwd,
-                                  extra_ints=[ldw], side=True)
+                        self.emit(N.OP_CONV_WGRAD, [x.addr(), dz.addr(), self.pgrad(w), slab], desc=dfwd,
+                                  extra_ints=[ldw, slab_mb], side=True)
 
                 # Host issue order: [mark the main stream's position: dz is complete] [data gradient, main stream]
                 # [side stream waits for the MARK] [filter gradient].  The filter gradient still depends on dz only,
