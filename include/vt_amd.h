@@ -173,17 +173,19 @@ int vt_bn_act_bwd_apply(const void* dy, int32_t lddy, const void* z, int32_t ldz
  * conv weight and the BatchNorm parameters -- the unit's input is the image, no data gradient exists).
  * vt_stem_bn_bwd_reduce reads x [B*H*W][8] (3 real channels), dy and z ONCE and accumulates
  *   sums  (a statistics buffer, see VT_STAT_REPLICAS) as vt_bn_act_bwd_reduce, and
- *   gzx   float[vt_stem_bn_bwd_scratch_bytes(C) / 4]: the correlations of g, z and 1 with the tap-shifted x
- * (both zeroed by the caller); after vt_bn_bwd_finalize, vt_stem_bn_bwd_combine adds
+ *   gzx   vt_stem_bn_bwd_scratch_bytes(C) bytes: the correlations of g, z and 1 with the tap-shifted x, as f32
+ *         (fixed = 0: f32 atomics, the first quarter of the buffer) or as fixed-point int64 pairs (fixed = 1: integer
+ *         atomics, order-free -- the deterministic mode)
+ * (both zeroed by the caller); after vt_bn_bwd_finalize, vt_stem_bn_bwd_combine (same `fixed`) adds
  *   dw[n][t][c] += coef0[n]*G - coef1[n]*Z + coef2[n]*X,  dw float[C][9][cin]
  * i.e. the filter gradient of dz = coef0*g - coef1*z + coef2 without forming dz.  bf16, C = 32 (the stems of the reference's models). */
 int64_t vt_stem_bn_bwd_scratch_bytes(int32_t C);
 int vt_stem_bn_bwd_reduce(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, const void* x,
                           const void* dy, int32_t lddy, const void* z, int32_t ldz, const float* scale,
                           const float* shift, const float* mean, const float* invstd, int32_t relu,
-                          float* sums, float* gzx, void* stream);
+                          float* sums, float* gzx, int32_t fixed, void* stream);
 int vt_stem_bn_bwd_combine(int32_t C, int32_t cin, const float* gzx, const float* coef, float* dw,
-                           void* stream);
+                           int32_t fixed, void* stream);
 
 /* ---- pooling ------------------------------------------------------------ */
 /* nn.MaxPool2d(3, 2, 1) at the head of every VoVNet stage (vovnet.py:94). */

@@ -45,8 +45,9 @@ def _reference(x, dy, z, sc, sf, mu, istd, coef, relu):
     return torch.stack([s1, s2]), dw
 
 
+@pytest.mark.parametrize("fixed", [0, 1], ids=["f32_atomics", "fixed_point"])
 @pytest.mark.parametrize("B,H,W,lddy,ldz,relu", CASES)
-def test_stem_backward_matches_float64(B, H, W, lddy, ldz, relu):
+def test_stem_backward_matches_float64(B, H, W, lddy, ldz, relu, fixed):
     torch.manual_seed(B * 1000 + W)
     dev = "cuda"
     Cc = 32
@@ -67,8 +68,8 @@ def test_stem_backward_matches_float64(B, H, W, lddy, ldz, relu):
     dw = torch.full((Cc, 9, 3), 0.25, device=dev)  # the combine kernel ACCUMULATES
     st = stream()
     N.check(lib.vt_stem_bn_bwd_reduce(N.VT_BF16, B, H, W, Cc, vp(x), vp(dy), lddy, vp(z), ldz, vp(sc), vp(sf), vp(mu),
-                                      vp(istd), relu, vp(sums), vp(gzx), st))
-    N.check(lib.vt_stem_bn_bwd_combine(Cc, 3, vp(gzx), vp(coef), vp(dw), st))
+                                      vp(istd), relu, vp(sums), vp(gzx), fixed, st))
+    N.check(lib.vt_stem_bn_bwd_combine(Cc, 3, vp(gzx), vp(coef), vp(dw), fixed, st))
     torch.cuda.synchronize()
     ref_s, ref_dw = _reference(x, dy, z, sc, sf, mu, istd, coef, relu)
     got_s = N.stats_decode(sums)
@@ -83,6 +84,6 @@ def test_stem_backward_rejects_what_it_has_no_kernel_for():
     lib = N.lib()
     t = torch.zeros(64, device="cuda")
     assert lib.vt_stem_bn_bwd_reduce(N.VT_BF16, 1, 8, 8, 64, vp(t), vp(t), 64, vp(t), 64, vp(t), vp(t), vp(t), vp(t), 1,
-                                     vp(t), vp(t), stream()) == N.VT_ERR_UNSUPPORTED
+                                     vp(t), vp(t), 0, stream()) == N.VT_ERR_UNSUPPORTED
     assert lib.vt_stem_bn_bwd_reduce(N.VT_F32, 1, 8, 8, 32, vp(t), vp(t), 32, vp(t), 32, vp(t), vp(t), vp(t), vp(t), 1,
-                                     vp(t), vp(t), stream()) == N.VT_ERR_UNSUPPORTED
+                                     vp(t), vp(t), 0, stream()) == N.VT_ERR_UNSUPPORTED

@@ -1,6 +1,7 @@
 """Time vt_stem_bn_bwd_reduce (vt_stem_bwd.hip) on the real stem geometry (GPU box):
     python tools/bench_stem_bwd.py [B=256] [H=224]
 Prints ms per launch and the HBM rate of its algorithmic bytes (dy + z + x read once)."""
+import os
 import sys
 from pathlib import Path
 
@@ -29,7 +30,7 @@ def main():
 
     def run():
         N.check(lib.vt_stem_bn_bwd_reduce(N.VT_BF16, B, H, H, 32, vp(x), vp(dy), 32, vp(z), 32, vp(co[0]), vp(co[1]),
-                                          vp(co[2]), vp(co[3]), 1, vp(sums), vp(gzx), st))
+                                          vp(co[2]), vp(co[3]), 1, vp(sums), vp(gzx), int(os.environ.get('FIXED', '0')), st))
     for _ in range(3):
         run()
     e0, e1 = N.Event(), N.Event()

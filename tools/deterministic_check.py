@@ -1,8 +1,8 @@
 """VT_DETERMINISTIC=1: two fresh train runs (same seed, same data, two SGD steps with momentum) must end with
 BIT-IDENTICAL parameters, gradients, momentum and BatchNorm state.  What makes that possible: the BatchNorm statistics
 and backward sums are always fixed-point integer atomics (vt_common.h), and in this mode the filter gradients are
-two-stage (vt_conv_wgrad_slabs: stored partial tiles + an ordered reducer) and the bias column sums go through a
-fixed-point shadow (vt_colsum_fixed, vt_fixed_to_f32).  (The scalar
+two-stage (vt_conv_wgrad_slabs: stored partial tiles + an ordered reducer), the bias column sums go through a
+fixed-point shadow (vt_colsum_fixed, vt_fixed_to_f32) and the one-pass stem kernel accumulates in fixed point.  (The scalar
 loss is still a float atomic over the batch rows: it is reported, nothing is computed from it.)
 
     VT_DETERMINISTIC=1 python tools/deterministic_check.py [model] [f32|bf16]        (GPU box)"""

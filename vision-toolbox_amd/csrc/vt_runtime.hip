@@ -116,12 +116,12 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
         case VT_OP_BN_BWD_APPLY:  // ptr: dy z scale shift coef dz | i: lddy ldz lddz C relu dtype | f: M
             return vt_bn_act_bwd_apply(P[0], I[0], P[1], I[1], (const float*)P[2], (const float*)P[3],
                                        (const float*)P[4], P[5], I[2], (int64_t)F[0], I[3], I[4], I[5], st);
-        case VT_OP_STEM_BWD_REDUCE:  // ptr: x dy z scale shift mean invstd sums gzx | i: dtype B H W C lddy ldz relu
+        case VT_OP_STEM_BWD_REDUCE:  // ptr: x dy z scale shift mean invstd sums gzx | i: dtype B H W C lddy ldz relu fixed
             return vt_stem_bn_bwd_reduce(I[0], I[1], I[2], I[3], I[4], P[0], P[1], I[5], P[2], I[6], (const float*)P[3],
                                          (const float*)P[4], (const float*)P[5], (const float*)P[6], I[7], (float*)P[7],
-                                         (float*)P[8], st);
-        case VT_OP_STEM_BWD_COMBINE:  // ptr: gzx coef dw | i: C cin
-            return vt_stem_bn_bwd_combine(I[0], I[1], (const float*)P[0], (const float*)P[1], (float*)P[2], st);
+                                         (float*)P[8], I[8], st);
+        case VT_OP_STEM_BWD_COMBINE:  // ptr: gzx coef dw | i: C cin fixed
+            return vt_stem_bn_bwd_combine(I[0], I[1], (const float*)P[0], (const float*)P[1], (float*)P[2], I[2], st);
         case VT_OP_MAXPOOL_FWD:  // ptr: x y argmax | i: ldx ldy B H W C dtype
             return vt_maxpool3x3s2_fwd(P[0], I[0], P[1], I[1], (uint8_t*)P[2], I[2], I[3], I[4], I[5], I[6], st);
         case VT_OP_MAXPOOL_BWD:  // ptr: dy argmax dx | i: lddy lddx B H W C accumulate dtype

@@ -38,7 +38,8 @@ struct SbArgs {
     const bf16_t* z;    // ld ldz
     const float *scale, *shift, *mean, *invstd;
     float* sums;        // fixed-point [kStatReplicas][2][C] (vt_common.h)
-    float* gzx;         // [kGzxReplicas][2C+16][96]
+    float* gzx;         // [kGzxReplicas][2C+16][96] f32, or the same entries as fixed-point int64 pairs (fixed)
+    int fixed;
     int B, H, W, C, lddy, ldz, relu;
     int PW, PH, S;      // padded pitch / rows / positions per image
     int NP, chunk;      // total positions, positions per workgroup (multiple of 64)
@@ -283,7 +284,13 @@ __global__ void __launch_bounds__(256, 2) stem_bwd_kernel(const SbArgs p) {
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * a + 4 * g + r;
                 if (a < 2 * FA || row == 2 * C)  // of the flag block only its first row carries anything
-                    atomicAdd(out + (long)row * kCols + 16 * (3 * half + ff) + u, acc[a][ff][r]);
+                {
+                    const long e = (long)row * kCols + 16 * (3 * half + ff) + u;
+                    if (p.fixed)  // integer atomics: the correlations do not depend on the order of the workgroups
+                        vt_stat_add(p.gzx, (long)rep * (2 * C + 16) * kCols + e, acc[a][ff][r]);
+                    else
+                        atomicAdd(out + e, acc[a][ff][r]);
+                }
             }
     // per-channel sums: fold the lanes that share a chunk, one writer per (wave, chunk)
     for (int off = CPR; off < 64; off <<= 1) {
@@ -306,13 +313,26 @@ __global__ void __launch_bounds__(256, 2) stem_bwd_kernel(const SbArgs p) {
 
 // dW[n][t][c] += a_n*G - b_n*Z + d_n*X  (coef = [a | b | d] of bn_bwd_finalize), c < cin of the 8 staged channels
 __global__ void stem_bwd_combine_kernel(const float* __restrict__ gzx, const float* __restrict__ coef, int C, int cin,
-                                        float* __restrict__ dw) {
+                                        float* __restrict__ dw, int fixed) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= C * 9 * cin) return;
     const int c = idx % cin, t = (idx / cin) % 9, n = idx / (9 * cin);
     const int col = (t / 3) * 32 + (t % 3) * 8 + c;
     const int rows = 2 * C + 16;
     double G = 0.0, Z = 0.0, X = 0.0;
+    if (fixed) {
+        const long long* q = (const long long*)gzx;
+        long long h[3] = {0, 0, 0}, l[3] = {0, 0, 0};
+        for (int r = 0; r < kGzxReplicas; ++r) {
+            const long base = (long)r * rows * kCols;
+            const long e[3] = {base + (long)n * kCols + col, base + (long)(C + n) * kCols + col,
+                               base + (long)(2 * C) * kCols + col};
+            for (int k = 0; k < 3; ++k) h[k] += q[2 * e[k]], l[k] += q[2 * e[k] + 1];
+        }
+        G = (double)h[0] * 4096.0 + (double)l[0] * (1.0 / 8589934592.0);
+        Z = (double)h[1] * 4096.0 + (double)l[1] * (1.0 / 8589934592.0);
+        X = (double)h[2] * 4096.0 + (double)l[2] * (1.0 / 8589934592.0);
+    } else
     for (int r = 0; r < kGzxReplicas; ++r) {
         const float* o = gzx + (long)r * rows * kCols;
         G += (double)o[(long)n * kCols + col];
@@ -327,11 +347,12 @@ __global__ void stem_bwd_combine_kernel(const float* __restrict__ gzx, const flo
 
 extern "C" {
 
-int64_t vt_stem_bn_bwd_scratch_bytes(int32_t C) { return (int64_t)kGzxReplicas * (2 * C + 16) * kCols * 4; }
+int64_t vt_stem_bn_bwd_scratch_bytes(int32_t C) { return (int64_t)kGzxReplicas * (2 * C + 16) * kCols * 16; }
 
 int vt_stem_bn_bwd_reduce(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_t C, const void* x, const void* dy,
                           int32_t lddy, const void* z, int32_t ldz, const float* scale, const float* shift,
-                          const float* mean, const float* invstd, int32_t relu, float* sums, float* gzx, void* stream) {
+                          const float* mean, const float* invstd, int32_t relu, float* sums, float* gzx, int32_t fixed,
+                          void* stream) {
     VT_REQUIRE(dtype == VT_BF16 && C == 32 && B > 0 && H > 0 && W > 0 && lddy % 8 == 0 && ldz % 8 == 0 &&
                    lddy >= C && ldz >= C,
                VT_ERR_UNSUPPORTED, "vt_stem_bn_bwd_reduce: bf16, 32 channels, 16-byte aligned rows");
@@ -342,6 +363,7 @@ int vt_stem_bn_bwd_reduce(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_
     a.x = (const bf16_t*)x, a.dy = (const bf16_t*)dy, a.z = (const bf16_t*)z;
     a.scale = scale, a.shift = shift, a.mean = mean, a.invstd = invstd, a.sums = sums, a.gzx = gzx;
     a.B = B, a.H = H, a.W = W, a.C = C, a.lddy = lddy, a.ldz = ldz, a.relu = relu;
+    a.fixed = fixed ? 1 : 0;
     a.PW = W + 1, a.PH = H + 1, a.S = a.PW * a.PH;
     const long NP = (long)B * a.S;
     VT_REQUIRE(NP <= 0x7fff0000L, VT_ERR_UNSUPPORTED, "vt_stem_bn_bwd_reduce: more than 2^31 positions");
@@ -370,12 +392,13 @@ int vt_stem_bn_bwd_reduce(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_
     return VT_OK;
 }
 
-int vt_stem_bn_bwd_combine(int32_t C, int32_t cin, const float* gzx, const float* coef, float* dw, void* stream) {
+int vt_stem_bn_bwd_combine(int32_t C, int32_t cin, const float* gzx, const float* coef, float* dw, int32_t fixed,
+                           void* stream) {
     VT_REQUIRE(C == 32 && cin >= 1 && cin <= 8 && gzx && coef && dw, VT_ERR_INVALID,
                "vt_stem_bn_bwd_combine: bad argument");
     const int n = C * 9 * cin;
     hipLaunchKernelGGL(stem_bwd_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, gzx, coef, C,
-                       cin, dw);
+                       cin, dw, fixed ? 1 : 0);
     VT_CHECK_LAUNCH("vt_stem_bn_bwd_combine");
     return VT_OK;
 }

@@ -180,8 +180,8 @@ SYMBOLS = {
     "vt_fixed_to_f32": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "vt_colsum_fixed": (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "vt_stem_bn_bwd_scratch_bytes": (_i64, [_i32]),
-    "vt_stem_bn_bwd_reduce": (_i32, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
-    "vt_stem_bn_bwd_combine": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp]),
+    "vt_stem_bn_bwd_reduce": (_i32, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
+    "vt_stem_bn_bwd_combine": (_i32, [_i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "vt_bn_act_bwd_apply": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "vt_maxpool3x3s2_fwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vt_maxpool3x3s2_bwd": (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

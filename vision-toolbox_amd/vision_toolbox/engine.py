@@ -249,7 +249,7 @@ class Builder:
         self.dgrad_d2s_maxc = int(os.environ.get("VT_DGRAD_D2S_MAXC", "64"))
         # deterministic mode: the last sums still made with f32 atomics take an order-free form -- the filter gradients
         # become two-stage (partial tiles stored into slabs of ONE scratch that every layer reuses, then an ordered
-        # reducer), the bias column sums go through a fixed-point shadow, the stem takes its three-pass backward; with
+        # reducer), the bias column sums and the one-pass stem kernel's correlations go through fixed point; with
         # the fixed-point BatchNorm statistics every gradient and parameter update is then bit-identical from run to run
         self.deterministic = os.environ.get("VT_DETERMINISTIC", "0") != "0"
         self.wgrad_slab_mb = int(os.environ.get("VT_WGRAD_SLABS_MB", "48" if self.deterministic else "0"))  # 0 = atomics
@@ -588,7 +588,7 @@ class Builder:
                       [x.addr(), wptr, y.addr(), None, self.pref(conv.bias) if conv.bias is not None else None,
                        residual.addr() if residual else None, None], desc=d)
 
-        stem_fused = (self.stem_fused_bwd and not self.deterministic and track and padded and has_bn and not fused and residual is None and
+        stem_fused = (self.stem_fused_bwd and track and padded and has_bn and not fused and residual is None and
                       not x.needs_grad and w.requires_grad and dt == N.VT_BF16 and Cout == 32 and k == 3 and s == 1 and
                       pad == 1 and x.C == 8 and x.ld == 8 and x.W <= 896 and B * (x.H + 1) * (x.W + 1) < 0x7fff0000)  # (ring in LDS)
         if track:
@@ -610,12 +610,13 @@ class Builder:
                     gzx = self.zeroed_f32(N.lib().vt_stem_bn_bwd_scratch_bytes(Cout) // 4, "stem_gzx")
                     self.emit(N.OP_STEM_BWD_REDUCE,
                               [x.addr(), dy.addr(), z.addr(), cp[0], cp[1], cp[2], cp[3], self.bp(sums), self.bp(gzx)],
-                              [dt, B, x.H, x.W, Cout, dy.ld, z.ld, int(relu)])
+                              [dt, B, x.H, x.W, Cout, dy.ld, z.ld, int(relu), int(self.deterministic)])
                     bcoef = self.f32(3 * Cout, "bwdcoef")
                     self.emit(N.OP_BN_BWD_FINALIZE,
                               [self.bp(sums), cp[0], cp[2], cp[3], self.pgrad(norm.weight), self.pgrad(norm.bias),
                                self.bp(bcoef)], [Cout, int(training)], [M * self.bn_world, 1.0 / self.bn_world])
-                    self.emit(N.OP_STEM_BWD_COMBINE, [self.bp(gzx), self.bp(bcoef), self.pgrad(w)], [Cout, Cin_w])
+                    self.emit(N.OP_STEM_BWD_COMBINE, [self.bp(gzx), self.bp(bcoef), self.pgrad(w)],
+                              [Cout, Cin_w, int(self.deterministic)])
                     return
                 if has_bn:
                     sums = self.zeroed_f32(N.stat_floats(Cout), "bwdsums")
