@@ -325,6 +325,8 @@ def main():
                     help="run the step on a torch stream of this priority (-1 = high): the filter-gradient side "
                          "stream then only fills what the critical path leaves")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 child runs that measure `traffic`")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="bit-identical parameter updates (two-stage filter gradients, fixed-point bias sums): ~3 %% slower")
     ap.add_argument("--steps-only", action="store_true",
                     help="(profiling) run warm-up + timed steps and print their time; no roofline / baseline launches, so a "
                          "rocprofv3 pass over this command counts the step's kernels and nothing else")
@@ -377,7 +379,7 @@ def main():
     bb = getattr(backbones, args.model)()
     ts = TrainStep(bb, 1000, args.batch, args.image_size, torch.bfloat16, lr=0.05, momentum=0.9, weight_decay=2e-5,
                    label_smoothing=0.1, device=dev, bucket_mb=args.bucket_mb, use_graphs=args.graphs,
-                   sync_bn=args.sync_bn)
+                   sync_bn=args.sync_bn, deterministic=True if args.deterministic else None)
     ts.broadcast_parameters(0)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
@@ -468,7 +470,8 @@ def main():
             "config": {"workload": f"{args.model} train step (fwd+CE+bwd+allreduce+SGD), batch {args.batch}/GPU, "
                                    f"3x{args.image_size}x{args.image_size}, 1000 classes, BASELINE configs[1]",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "hip_graphs": bool(args.graphs), "sync_bn": bool(args.sync_bn), "final_loss": round(loss, 4)},
+                       "hip_graphs": bool(args.graphs), "sync_bn": bool(args.sync_bn), "deterministic": bool(ts.deterministic),
+                       "final_loss": round(loss, 4)},
             "roofline": {"bound": "mfma", "achieved": round(dom["tflops"], 1), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4),
                          "traffic": traffic["bytes"] if traffic else None,

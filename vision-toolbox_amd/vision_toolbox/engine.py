@@ -212,7 +212,7 @@ class Builder:
     """Emits the forward / backward launch lists of one model instance."""
 
     def __init__(self, store: ParamStore, dtype: int, training: bool, need_grad: bool,
-                 grad_base: int = ARENA, master_mirror_fresh: bool = False):
+                 grad_base: int = ARENA, master_mirror_fresh: bool = False, deterministic: Optional[bool] = None):
         self.store = store
         self.dtype = dtype
         self.training = training
@@ -251,7 +251,7 @@ class Builder:
         # become two-stage (partial tiles stored into slabs of ONE scratch that every layer reuses, then an ordered
         # reducer), the bias column sums and the one-pass stem kernel's correlations go through fixed point; with
         # the fixed-point BatchNorm statistics every gradient and parameter update is then bit-identical from run to run
-        self.deterministic = os.environ.get("VT_DETERMINISTIC", "0") != "0"
+        self.deterministic = (os.environ.get("VT_DETERMINISTIC", "0") != "0") if deterministic is None else bool(deterministic)
         self.wgrad_slab_mb = int(os.environ.get("VT_WGRAD_SLABS_MB", "48" if self.deterministic else "0"))  # 0 = atomics
         self._wgrad_slab = None
         self._hoisted: list[N.Op] = []

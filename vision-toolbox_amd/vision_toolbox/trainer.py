@@ -132,6 +132,7 @@ class TrainStep:
         sync_bn: bool = False,
         mix: bool = False,
         freeze_bn: bool = False,
+        deterministic: Optional[bool] = None,
     ):
         N.lib()
         self.device = torch.device(device if device is not None else "cuda")
@@ -173,7 +174,10 @@ class TrainStep:
         total = st.pflat.numel()
 
         # ---- forward + loss + backward launch lists ---------------------------------------
-        b = E.Builder(st, self.dtype, training=True, need_grad=True, grad_base=E.GRADS)
+        # deterministic=True (default: the VT_DETERMINISTIC environment variable): order-free filter gradients and bias
+        # sums on top of the always fixed-point BatchNorm statistics -- bit-identical parameter updates
+        b = E.Builder(st, self.dtype, training=True, need_grad=True, grad_base=E.GRADS, deterministic=deterministic)
+        self.deterministic = b.deterministic
         b.hoist_dgrad_packs = True
         # SyncBatchNorm, the reference recipe's setting (configs/base.yaml:22): batch statistics over
         # ALL ranks.  Off by default for the throughput metric: it adds two small,
