@@ -137,6 +137,7 @@ def test_filter_gradient_at_batch_256_linear_and_equal_to_cpu_autograd(layer):
 UNITS = [  # Cin, Cout, k, s, H
     (128, 128, 3, 1, 28),  # span kernel forward + stride-1 span data gradient + all-taps filter gradient
     (64, 128, 3, 2, 112),  # stride 2: gather forward, 4 parity-class data gradients
+    (32, 64, 3, 2, 224),   # the first stride-2 conv: depth-to-space data gradient (one launch), row-parity filter gradient
     (3, 32, 3, 1, 224),    # the RGB stem: 12.8 M rows, vt_stem.hip, padded filter gradient (no data gradient)
     (160, 160, 3, 1, 28),  # VoVNet-39 width: N / K tile tails
     (256, 128, 1, 1, 28),  # 1x1
