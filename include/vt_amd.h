@@ -96,6 +96,10 @@ const char* vt_last_kernel_name(void);
 /* number of kernel launches issued by this process through the library; the
  * GPU tests assert it advances, i.e. that the HIP path is what ran. */
 uint64_t vt_launch_count(void);
+/* Experiment / test switch of the kernel dispatchers (the names INTEGRATION.md lists, e.g. "VT_SPAN6"): each is read
+ * from the environment variable of the same name ONCE per process; this call sets it afterwards (the GPU tests force a
+ * kernel with it).  No switch changes results beyond summation order. */
+int vt_set_knob(const char* name, int32_t value);
 int vt_memset(void* ptr, int value, uint64_t bytes, void* stream);
 
 /* ---- convolution --------------------------------------------------------

@@ -1,5 +1,5 @@
-"""Dev check (GPU box): the persistent span kernel (vt_igemm_span3.hip) against the shipped span kernel on the
-same operands -- outputs, BN statistics -- and both timed.   python tools/check_span3.py [Cin,Cout,H[,B]] ..."""
+"""Dev check (GPU box): dispatcher variants of the 3x3 span kernels (default: span6 against the span kernel) on the
+same operands -- outputs, BN statistics -- and interleaved timing rounds.   python tools/check_span_variants.py [Cin,Cout,H[,B]] ..."""
 import ctypes
 import os
 import sys
@@ -48,10 +48,16 @@ def run(d, x, w, y, stats, res=None, iters=0):
 
 
 # (tag, environment) per variant; the first one is the reference.  VT_CHECK_VARIANTS="tag:K=V,K=V;tag2:K=V" overrides
-VARIANTS = [("old", {"VT_SPAN3": "0", "VT_SPAN_DB": "0"}), ("dbuf", {"VT_SPAN3": "0", "VT_SPAN_DB": "1"})]
+VARIANTS = [("span", {"VT_SPAN6": "0"}), ("span6", {"VT_SPAN6": "2"})]
 if os.environ.get("VT_CHECK_VARIANTS"):
     VARIANTS = [(v.split(":")[0], dict(kv.split("=") for kv in v.split(":")[1].split(",") if kv))
                 for v in os.environ["VT_CHECK_VARIANTS"].split(";")]
+
+
+def set_knobs(allkeys, env):
+    """the dispatchers read the environment once per process: variants are switched through vt_set_knob"""
+    for k in allkeys:
+        N.set_knob(k, int(env.get(k, "0")))
 
 
 ROUNDS = int(os.environ.get("VT_CHECK_ROUNDS", "7"))
@@ -74,8 +80,7 @@ def main():
             d = desc(B, Cin, Cout, H, flags, ldr=Cout if flags & N.VT_CONV_RESIDUAL else 0)
             r_ = res if flags & N.VT_CONV_RESIDUAL else None
             for tag, env in VARIANTS:
-                os.environ.update({k: "0" for k in allkeys})
-                os.environ.update(env)
+                set_knobs(allkeys, env)
                 y = torch.full((B, H, H, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
                 st = N.stats_buffer(Cout) if flags & N.VT_CONV_STATS else None
                 name, _ = run(d, x, w, y, st, r_)
@@ -85,8 +90,7 @@ def main():
                 ysc = torch.empty_like(outs[VARIANTS[0][0]][0])
                 for _ in range(ROUNDS):
                     for tag, env in VARIANTS:
-                        os.environ.update({k: "0" for k in allkeys})
-                        os.environ.update(env)
+                        set_knobs(allkeys, env)
                         outs[tag][3].append(run(d, x, w, ysc, st, r_, iters=10)[1])
             y0, s0 = outs[VARIANTS[0][0]][0], outs[VARIANTS[0][0]][1]
             line = f"{Cin}->{Cout} @{H} B={B} {mode:8s}"

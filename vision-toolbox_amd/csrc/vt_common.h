@@ -18,6 +18,13 @@ void vt_set_error(const char* fmt, ...);
 void vt_count_launch();
 void vt_note_kernel(const char* fmt, ...);                            // name of the conv kernel a dispatch chose
 int vt_raise_dynamic_lds(const void* kern, int bytes, const char* who);  // per (kernel, device), thread-safe
+// Experiment / test switches of the dispatchers: a named integer, initialised ONCE per process from the environment
+// variable of the same name and afterwards only changed through vt_set_knob (C-ABI; the GPU tests force a kernel with
+// it).  A call site keeps the returned slot in a function-local static, so a launch reads one int, never the environment.
+int* vt_knob_slot(const char* name, int dflt);
+#define VT_KNOB(name, dflt) ([]() -> int { static int* slot__ = vt_knob_slot(name, dflt); return *slot__; }())
+// multiprocessor (CU) count of the current device, cached per device
+int vt_device_cus(void);
 
 // BatchNorm statistics and the BatchNorm-backward sums are accumulated in FIXED POINT with integer atomics, which are
 // associative: the sums -- and with them every activation, loss value and data gradient -- are bit-identical from run
@@ -32,7 +39,16 @@ int vt_raise_dynamic_lds(const void* kern, int bytes, const char* who);  // per 
 // (VT_STAT_BYTES(C) bytes, zeroed by the caller); the kernels take it as float* and index the limbs themselves.
 constexpr int kStatReplicas = VT_STAT_REPLICAS;
 #ifdef __HIPCC__
+// A non-finite (or absurdly large) contribution cannot be represented: it adds the marker 2^40 to the hi limb instead
+// (no legitimate sum of a layer comes near 2^38 * 4096 = 1e15), and vt_stat_sum turns a marked sum into NaN -- a
+// diverged activation shows up in the batch / running statistics as it did with float atomics, instead of as a
+// finite garbage value.  (2^20 marked contributions per replica before the limb could wrap.)
+constexpr long long kStatPoison = 1LL << 40;
 __device__ __forceinline__ void vt_stat_add(float* stats, long idx, float v) {
+    if (!(fabsf(v) < 1.0e30f)) {
+        atomicAdd((unsigned long long*)stats + 2 * idx, (unsigned long long)kStatPoison);
+        return;
+    }
     const float hf = truncf(v * (1.0f / 4096.0f));   // exact (power-of-two scaling, then an integer)
     const float rem = v - hf * 4096.0f;               // exact: |rem| < 4096, a multiple of ulp(v)
     unsigned long long* q = (unsigned long long*)stats + 2 * idx;
@@ -48,6 +64,7 @@ __device__ __forceinline__ double vt_stat_sum(const float* stats, long idx, long
         hi += q[2 * (idx + r * stride)];
         lo += q[2 * (idx + r * stride) + 1];
     }
+    if (hi >= (kStatPoison >> 2) || hi <= -(kStatPoison >> 2)) return __longlong_as_double(0x7ff8000000000000LL);  // poisoned
     return (double)hi * 4096.0 + (double)lo * (1.0 / 8589934592.0);
 }
 #endif

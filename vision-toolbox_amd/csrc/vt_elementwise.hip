@@ -926,7 +926,7 @@ pack_dgrad_kernel(const S* __restrict__ w, int ldw, D* __restrict__ out, SelTabl
 // Measured on the full step, every combination: 23.14 .. 23.25 ms against 23.23 .. 23.25 for the default (0) -- no
 // effect beyond noise; the knob stays for experiments.
 inline int vt_bn_order() {
-    static const int v = getenv("VT_BN_REV") ? atoi(getenv("VT_BN_REV")) : 0;
+    const int v = VT_KNOB("VT_BN_REV", 0);
     return v;
 }
 
@@ -1042,10 +1042,10 @@ int vt_bn_act_bwd_reduce(const void* dy, int32_t lddy, const void* z, int32_t ld
     const int epc = vt_epc(dtype);
     // every block ends with 2*C 64-bit atomics into one of 32 replicas: ~100 ns each when they queue on the same address,
     // so fewer, longer blocks win over grid-filling ones (measured per step: 1024 -> 23.53, 512 -> 23.36, 256 -> 23.27 ms)
-    static const int target = getenv("VT_REDUCE_BLOCKS") ? atoi(getenv("VT_REDUCE_BLOCKS")) : 256;
+    const int target = VT_KNOB("VT_REDUCE_BLOCKS", 256);
     RowMap rm = RowMap::make(C, epc, M, target);
     rm.rev = (vt_bn_order() >> 1) & 1;
-    static const int inwave_env = getenv("VT_REDUCE_INWAVE") ? atoi(getenv("VT_REDUCE_INWAVE")) : 1;
+    const int inwave_env = VT_KNOB("VT_REDUCE_INWAVE", 1);
     const bool inwave = inwave_env && rm.CT < 64 && (rm.CT & (rm.CT - 1)) == 0;  // (as in the kernel)
     const int smem = (inwave ? kThreads / 64 : rm.RT) * 2 * rm.CT * epc * (int)sizeof(float);
     VT_DISPATCH_T(dtype, "vt_bn_act_bwd_reduce",

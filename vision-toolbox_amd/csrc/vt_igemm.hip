@@ -514,14 +514,6 @@ extern "C" int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w
         const int rc = vt_span6_dispatch(a, d->dtype, stream);  // MFMA-bound 3x3 stride-1 layers: two-group + loader kernel
         if (rc >= 0) return rc;
     }
-    if (!d2s) {  // (these kernels write dense rows only)
-        const int rc = vt_span5_dispatch(a, d->dtype, stream);  // MFMA-bound 3x3 stride-1 layers: loader-wave span kernel
-        if (rc >= 0) return rc;
-    }
-    if (!d2s) {  // (these kernels write dense rows only)
-        const int rc = vt_span3_dispatch(a, d->dtype, stream);  // MFMA-bound 3x3 stride-1 layers: persistent span kernel
-        if (rc >= 0) return rc;
-    }
     {
         const int rc = vt_span_dispatch(a, d->dtype, stream);  // stride-1-grid convs: input-span kernel
         if (rc >= 0) return rc;

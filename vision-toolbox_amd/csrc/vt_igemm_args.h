@@ -31,14 +31,6 @@ __device__ __forceinline__ long vt_out_col(const IgemmArgs& p, int n, int ld) {
 // apply to `a` (the caller then launches the general kernel), else a VT_* status.
 int vt_span_dispatch(IgemmArgs& a, int dtype, void* stream);
 
-// vt_igemm_span3.hip: persistent, software-pipelined span kernel for the MFMA-bound 3x3 stride-1 layers (bf16);
-// -1 when it does not apply.
-int vt_span3_dispatch(IgemmArgs& a, int dtype, void* stream);
-
-// vt_igemm_span5.hip: persistent span kernel with a dedicated LDS-DMA loader wave (bf16, 3x3 stride 1, Cout >= 64);
-// -1 when it does not apply.
-int vt_span5_dispatch(IgemmArgs& a, int dtype, void* stream);
-
 // vt_igemm_span6.hip: persistent span kernel, one 12-wave workgroup per CU (two compute groups half a step apart +
 // four loader waves); -1 when it does not apply.
 int vt_span6_dispatch(IgemmArgs& a, int dtype, void* stream);

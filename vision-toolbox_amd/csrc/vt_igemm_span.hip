@@ -730,7 +730,7 @@ template <typename T, int BM, int BN, int WM, int WN>
 int launch_span(IgemmArgs& a, int dmin, int span, hipStream_t st) {
     // two filter slices in flight; a third (VT_SPAN_PD=3, where two workgroups still fit a CU) measured
     // 3 % slower once the issue stream was cleaned up (703 vs 727 TFLOP/s on 128ch @28x28)
-    static const int pd_env = getenv("VT_SPAN_PD") ? atoi(getenv("VT_SPAN_PD")) : 0;
+    const int pd_env = VT_KNOB("VT_SPAN_PD", 0);
     constexpr int NW = WM * WN;
     const int ita = (span + 16 * NW - 1) / (16 * NW);
     const int nchunks = a.Cin / (64 / (int)sizeof(T));
@@ -739,7 +739,7 @@ int launch_span(IgemmArgs& a, int dmin, int span, hipStream_t st) {
     if (pd3) return launch_span_pd<T, BM, BN, WM, WN, 3>(a, dmin, span, st);
     if constexpr (sizeof(T) == 2 && BN == 128 && WM == 2 && WN == 2 && (BM == 224 || BM == 256)) {
         // the MFMA-bound 3x3 layers: fragments of step s+1 are read under the MFMAs of step s
-        const int db_env = getenv("VT_SPAN_DB") ? atoi(getenv("VT_SPAN_DB")) : 0;  // TODO static once settled
+        const int db_env = VT_KNOB("VT_SPAN_DB", 0);
         if (db_env && a.ntaps >= 3 && nchunks * a.ntaps >= 4)
             return launch_span_pd<T, BM, BN, WM, WN, 2, false, true>(a, dmin, span, st);
     }
@@ -754,7 +754,7 @@ int launch_span_bn(IgemmArgs& a, int dmin, int span, hipStream_t st) {
         // K loop is 1-4 steps long, so a workgroup is mostly prologue + epilogue and what matters
         // is the bytes it keeps in flight.
         if (a.Cout > 64) {
-            static const int pp = getenv("VT_SPAN_PP") ? atoi(getenv("VT_SPAN_PP")) : 1;
+            const int pp = VT_KNOB("VT_SPAN_PP", 1);
             if (pp && a.ntaps >= 3) return launch_span_pd<T, BM, 128, 4, 2, 3, true>(a, dmin, span, st);
             return launch_span<T, BM, 128, 4, 2>(a, dmin, span, st);
         }
@@ -768,7 +768,7 @@ int launch_span_bn(IgemmArgs& a, int dmin, int span, hipStream_t st) {
     } else {
         if (a.Cout > 64) {
             // 256 x 128 tile: 4 waves of 128 x 64 (VT_SPAN_WAVES=8: 8 waves of 64 x 64; measured equal)
-            static const int waves = getenv("VT_SPAN_WAVES") ? atoi(getenv("VT_SPAN_WAVES")) : 4;
+            const int waves = VT_KNOB("VT_SPAN_WAVES", 4);
             if constexpr (BM == 256 && sizeof(T) == 2) {
                 if (waves == 8) return launch_span<T, BM, 128, 4, 2>(a, dmin, span, st);
             }
@@ -783,10 +783,10 @@ int launch_span_bn(IgemmArgs& a, int dmin, int span, hipStream_t st) {
 
 // returns -1 when the span kernel does not apply (the caller then uses the general kernel)
 int vt_span_dispatch(IgemmArgs& a, int dtype, void* stream) {
-    static const int enabled = getenv("VT_IGEMM_SPAN") ? atoi(getenv("VT_IGEMM_SPAN")) : 1;
+    const int enabled = VT_KNOB("VT_IGEMM_SPAN", 1);
     if (!enabled) return -1;
-    static const int fast_dma = getenv("VT_SPAN_FAST_DMA") ? atoi(getenv("VT_SPAN_FAST_DMA")) : 1;
-    const int prio = getenv("VT_SPAN_PRIO") ? atoi(getenv("VT_SPAN_PRIO")) : 0;  // TODO static once settled
+    const int fast_dma = VT_KNOB("VT_SPAN_FAST_DMA", 1);
+    const int prio = VT_KNOB("VT_SPAN_PRIO", 0);
     a.fast_dma = (fast_dma & 1) | ((prio & 3) << 1);
     const int ch = 4 * vt_epc(dtype);
     if (a.sh != 1 || a.sw != 1 || a.Ho != a.Hi || a.Wo != a.Wi) return -1;
@@ -812,7 +812,7 @@ int vt_span_dispatch(IgemmArgs& a, int dtype, void* stream) {
             // 256-row tiles often end in a thin last round (784 tiles = 1.53 rounds); 224-row
             // tiles divide those counts exactly (896 tiles = 1.75 rounds of 7/8 the length).
             // Pick the height with the smaller rounds x height (VT_SPAN_BM=256/224 overrides).
-            static const int bm_env = getenv("VT_SPAN_BM") ? atoi(getenv("VT_SPAN_BM")) : 0;
+            const int bm_env = VT_KNOB("VT_SPAN_BM", 0);
             const long t224 = (long)((a.M + 223) / 224) * tiles_n;
             const long c256 = (tiles256 + 511) / 512 * 256, c224 = (t224 + 511) / 512 * 224;
             // (only the 128-wide tiles gain: the narrow ones are bound by their epilogue/HBM traffic)

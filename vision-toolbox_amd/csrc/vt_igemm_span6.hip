@@ -708,8 +708,11 @@ int vt_span6_dispatch(IgemmArgs& a0, int dtype, void* stream) {
     // VT_SPAN6=0 disables, =2 forces this kernel wherever it applies (tests); default: the layers it measured faster
     // on than vt_igemm_span.hip (128-wide filter tiles on maps of 20 x 20 and larger, where the padded coordinates
     // cost <= 10 % extra MFMA work)
-    const int enabled = getenv("VT_SPAN6") ? atoi(getenv("VT_SPAN6")) : 1;
+    const int enabled = VT_KNOB("VT_SPAN6", 1);
     if (!enabled || dtype != VT_BF16) return -1;
+    // one 12-wave workgroup per CU on 8 XCDs x 32 CUs with 160 KiB of LDS each: the grid, the row slots and the unit
+    // split below are built for exactly that chip; any other device (or a partitioned one) takes the span kernel
+    if (vt_device_cus() != 256) return -1;
     if (enabled < 2 && (a0.Cout < 128 || a0.Wi < 20 || a0.Hi < 20)) return -1;
     if (a0.sh != 1 || a0.sw != 1 || a0.Ho != a0.Hi || a0.Wo != a0.Wi) return -1;
     // (Cin >= 64: with a single channel chunk the next tile's piece sources would be needed before they are computed)
@@ -721,7 +724,7 @@ int vt_span6_dispatch(IgemmArgs& a0, int dtype, void* stream) {
     S6Args a;
     a.p = a0;
     IgemmArgs& p = a.p;
-    a.debug = getenv("VT_SPAN6_ABL") ? atoi(getenv("VT_SPAN6_ABL")) : 0;
+    a.debug = VT_KNOB("VT_SPAN6_ABL", 0);
     // padded coordinates: every tap within one pixel of the centre (3x3, padding 1: forward and stride-1 data gradient)
     a.Hp = a0.Hi + 1, a.Wp = a0.Wi + 1;
     if ((long)a0.B * a.Hp * a.Wp > 0x3fffffffL) return -1;

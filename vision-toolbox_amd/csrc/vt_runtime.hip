@@ -7,6 +7,7 @@
 // Here the host builds the launch list once per (model, input shape) and a
 // step is ONE call into vt_run_ops / vt_graph_launch.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <atomic>
 #include <map>
@@ -52,6 +53,51 @@ int vt_raise_dynamic_lds(const void* kern, int bytes, const char* who) {
     }
     have = bytes;
     return VT_OK;
+}
+
+// ---- dispatcher switches -------------------------------------------------------------------------------
+namespace {
+struct Knob {
+    char name[48];
+    int value;
+};
+constexpr int kMaxKnobs = 96;
+Knob g_knobs[kMaxKnobs];  // slots never move: call sites keep pointers into this table
+int g_nknobs = 0;
+std::mutex g_knob_mu;
+int* knob_find_or_add(const char* name, int dflt, bool from_env) {
+    std::lock_guard<std::mutex> lock(g_knob_mu);
+    for (int i = 0; i < g_nknobs; ++i)
+        if (strcmp(g_knobs[i].name, name) == 0) return &g_knobs[i].value;
+    if (g_nknobs == kMaxKnobs) return nullptr;
+    Knob& k = g_knobs[g_nknobs++];
+    snprintf(k.name, sizeof(k.name), "%s", name);
+    const char* e = from_env ? getenv(name) : nullptr;
+    k.value = e ? atoi(e) : dflt;
+    return &k.value;
+}
+}  // namespace
+
+int* vt_knob_slot(const char* name, int dflt) {
+    static int overflow = 0;
+    int* s = knob_find_or_add(name, dflt, true);
+    if (!s) {
+        overflow = dflt;
+        return &overflow;
+    }
+    return s;
+}
+
+int vt_device_cus(void) {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int v = cus[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = -1;
+        cus[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
 }
 
 namespace {
@@ -178,7 +224,15 @@ struct Graph {
 
 extern "C" {
 
-int vt_version(void) { return 100; }
+int vt_version(void) { return 101; }
+int vt_set_knob(const char* name, int32_t value) {
+    VT_REQUIRE(name && strlen(name) < 48, VT_ERR_INVALID, "vt_set_knob: bad name");
+    // (a knob set before its first use overrides the environment: the slot exists from here on)
+    int* s = knob_find_or_add(name, value, false);
+    VT_REQUIRE(s, VT_ERR_INVALID, "vt_set_knob: table full");
+    *s = value;
+    return VT_OK;
+}
 const char* vt_last_error(void) { return g_err; }
 const char* vt_last_kernel_name(void) { return g_kernel; }
 uint64_t vt_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
@@ -263,8 +317,24 @@ static int run_ops_impl(const vt_op* ops, int32_t n, void* const* bases, int32_t
             if (two) rc = stream_wait((hipStream_t)side, (hipStream_t)stream, bag);
         } else if (op.kind == VT_OP_FORK_MARK) {
             if (two) {
-                hipError_t e;
-                mark = take_event(bag, &e);
+                // (eager: an event of its own per thread and device, never a slot of the shared ring, which 64 later
+                // stream waits could re-record before this mark's FORK_WAIT)
+                hipError_t e = hipSuccess;
+                if (bag) {
+                    mark = take_event(bag, &e);
+                } else {
+                    static thread_local int mark_dev = -1;
+                    int dev = 0;
+                    (void)hipGetDevice(&dev);
+                    if (eager_mark != nullptr && mark_dev != dev) {
+                        (void)hipEventDestroy(eager_mark);
+                        eager_mark = nullptr;
+                    }
+                    if (eager_mark == nullptr) {
+                        e = hipEventCreateWithFlags(&eager_mark, hipEventDisableTiming);
+                        mark_dev = dev;
+                    }
+                }
                 if (e == hipSuccess) e = hipEventRecord(mark, (hipStream_t)stream);
                 if (e != hipSuccess) {
                     vt_set_error("fork mark: %s", hipGetErrorString(e));

@@ -378,7 +378,7 @@ int vt_stem_bn_bwd_reduce(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_
     const int smem = 4 * 64 * pitch + 3 * C * 4 + rx * 16;
     VT_REQUIRE(smem <= 64 * 1024, VT_ERR_UNSUPPORTED, "vt_stem_bn_bwd_reduce: image too wide for the LDS ring");
     // two workgroups' worth of positions per CU slot; a chunk must dwarf the ring warm-up (2*halo rows)
-    static const int target = getenv("VT_STEM_BWD_WGS") ? atoi(getenv("VT_STEM_BWD_WGS")) : 1024;
+    const int target = VT_KNOB("VT_STEM_BWD_WGS", 1024);
     long chunk = (NP + target - 1) / target;
     const long min_chunk = 16l * a.halo;
     if (chunk < min_chunk) chunk = min_chunk;

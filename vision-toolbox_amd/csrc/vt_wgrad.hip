@@ -420,9 +420,9 @@ static int wgrad_impl(const vt_conv_desc* d, const void* x, const void* dz, floa
 
     // Split of the pixel range: aim for `target` workgroups (about 2 per CU), but keep >= 8
     // steps per wave group; atomic traffic is (#workgroups x 64 KiB) whatever the layer.
-    static const int target = getenv("VT_WGRAD_TARGET") ? atoi(getenv("VT_WGRAD_TARGET")) : 512;
-    static const int max_split_env = getenv("VT_WGRAD_MAXSPLIT") ? atoi(getenv("VT_WGRAD_MAXSPLIT")) : 4096;
-    static const int variant = getenv("VT_WGRAD_VARIANT") ? atoi(getenv("VT_WGRAD_VARIANT")) : 0;
+    const int target = VT_KNOB("VT_WGRAD_TARGET", 512);
+    const int max_split_env = VT_KNOB("VT_WGRAD_MAXSPLIT", 4096);
+    const int variant = VT_KNOB("VT_WGRAD_VARIANT", 0);
     const int G = variant == 1 ? 1 : (variant == 2 ? 4 : 2);
     const int pk = 4 * epc;
     const long tiles = (long)a.tiles_n * a.tiles_k;
@@ -441,7 +441,7 @@ static int wgrad_impl(const vt_conv_desc* d, const void* x, const void* dz, floa
     chunk = (chunk + (long)pk * G - 1) / ((long)pk * G) * ((long)pk * G);
     split = (M + chunk - 1) / chunk;
     a.chunk = (int)chunk;
-    static const int ablate = getenv("VT_WGRAD_ABLATE") ? atoi(getenv("VT_WGRAD_ABLATE")) : 0;  // timing experiments
+    const int ablate = VT_KNOB("VT_WGRAD_ABLATE", 0);  // timing experiments
     a.ablate = ablate;
     const bool use_slabs = slabs && split > 1 && split * slab_stride * 4 <= scratch_bytes;  // (split 1: one writer per element)
     a.slab = use_slabs ? scratch : nullptr;

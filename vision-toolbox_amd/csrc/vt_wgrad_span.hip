@@ -363,7 +363,7 @@ int launch_ws_taps(WsArgs& a, int ntaps, const int* eh, const int* ew, hipStream
     a.tiles_n = (a.Cout + 32 * FI - 1) / (32 * FI);
     a.tiles_c = (a.Cin + 32 * FJ - 1) / (32 * FJ);
     // pixel split: one 8-wave workgroup per CU, at least 16 steps each (the halo warm-up is NH chunks)
-    static const int target = getenv("VT_WGRAD_SPAN_TARGET") ? atoi(getenv("VT_WGRAD_SPAN_TARGET")) : 256;
+    const int target = VT_KNOB("VT_WGRAD_SPAN_TARGET", 256);
     const long tiles = (long)a.tiles_n * a.tiles_c;
     long split = target / tiles;
     const long max_split = (NP + 511) / 512;
@@ -375,14 +375,14 @@ int launch_ws_taps(WsArgs& a, int ntaps, const int* eh, const int* ew, hipStream
     chunk = (chunk + 31) / 32 * 32;
     split = (NP + chunk - 1) / chunk;
     a.chunk = (int)chunk;
-    static const int ablate = getenv("VT_WGRAD_ABLATE") ? atoi(getenv("VT_WGRAD_ABLATE")) : 0;  // timing experiments
+    const int ablate = VT_KNOB("VT_WGRAD_ABLATE", 0);  // timing experiments
     a.ablate = ablate;
     a.slab_stride = (long)a.Cout * a.ldgw;
     const bool use_slabs = scratch && !a.cblk && split > 1 && split * a.slab_stride * 4 <= scratch_bytes &&
                            (ntaps * a.Cin) % 4 == 0 && a.ldgw % 4 == 0;
     a.slab = use_slabs ? scratch : nullptr;
     int rc;
-    static const int wide = getenv("VT_WGRAD_SPAN_WIDE") ? atoi(getenv("VT_WGRAD_SPAN_WIDE")) : 1;
+    const int wide = VT_KNOB("VT_WGRAD_SPAN_WIDE", 1);
     if (FI == 2 && FJ == 2)
         rc = wide ? launch_ws<2, 2, true>(a, split, st) : launch_ws<2, 2>(a, split, st);
     else if (FI == 2)
@@ -401,7 +401,7 @@ int launch_ws_taps(WsArgs& a, int ntaps, const int* eh, const int* ew, hipStream
 // returns -1 when this kernel does not apply (the caller then uses the general kernel)
 int vt_wgrad_span_dispatch(const vt_conv_desc* d, const void* x, const void* dz, float* dw, int32_t ldgw,
                            float* scratch, int64_t scratch_bytes, void* stream) {
-    static const int enabled = getenv("VT_WGRAD_SPAN") ? atoi(getenv("VT_WGRAD_SPAN")) : 1;
+    const int enabled = VT_KNOB("VT_WGRAD_SPAN", 1);
     if (!enabled) return -1;
     if (d->dtype != VT_BF16 || d->ntaps != 9 || d->sh != 1 || d->sw != 1 || d->Ho != d->Hi || d->Wo != d->Wi)
         return -1;
@@ -439,8 +439,8 @@ int vt_wgrad_span_s2_dispatch(const vt_conv_desc* d, const void* x, const void* 
     // tap count, so two launches of 2 and 4 taps only match the general kernel's time where that one is at its worst
     // (32 -> 64 @224->112: 0.49 vs 0.47 ms alone, but 1.6 instead of 2.6 GB fetched: -0.1 ms per step beside the
     // HBM-bound BatchNorm passes); at 64 -> 128 @112->56 it is 0.44 vs 0.29 ms, on the 8-channel VoVNet stem slower too.
-    static const int minw = getenv("VT_WGRAD_S2_MINW") ? atoi(getenv("VT_WGRAD_S2_MINW")) : 100;
-    static const int minc = getenv("VT_WGRAD_S2_MINC") ? atoi(getenv("VT_WGRAD_S2_MINC")) : 32;
+    const int minw = VT_KNOB("VT_WGRAD_S2_MINW", 100);
+    const int minc = VT_KNOB("VT_WGRAD_S2_MINC", 32);
     if (d->Cin < minc) return -1;
     if (minw <= 0 || d->dtype != VT_BF16 || d->ntaps != 9 || d->sh != 2 || d->sw != 2 || d->h0 != -1 || d->w0 != -1)
         return -1;

@@ -167,6 +167,7 @@ SYMBOLS = {
     "vt_last_error": (C.c_char_p, []),
     "vt_last_kernel_name": (C.c_char_p, []),
     "vt_launch_count": (_u64, []),
+    "vt_set_knob": (_i32, [C.c_char_p, _i32]),
     "vt_memset": (_i32, [_vp, _i32, _u64, _vp]),
     "vt_conv_igemm": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vt_conv_wgrad": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i32, _vp]),
@@ -251,6 +252,11 @@ def last_kernel_name() -> str:
 def check(rc: int) -> None:
     if rc != VT_OK:
         raise NativeError(rc, last_error())
+
+
+def set_knob(name: str, value: int) -> None:
+    """set a dispatcher switch (vt_set_knob): the environment is only read once per process"""
+    check(lib().vt_set_knob(name.encode(), int(value)))
 
 
 def launch_count() -> int:

@@ -8,9 +8,13 @@ SURVEY 8b): its CUDA implementation runs the forward launch list, its registered
 autograd formula the explicit backward list, and its fake-tensor (meta) implementation
 gives shapes / strides / dtypes without touching the GPU -- so `torch.jit.trace`
 (reference tests/test_backbones.py:76-78) records a real, serialisable operator node and
-`torch.compile` / `torch.export` can trace through the module.  The returned feature
-maps are ordinary autograd-tracked tensors, so user heads / necks (necks.py:83) compose
-with them.
+`torch.compile` / `torch.export` can trace through the module in INFERENCE mode
+(need_grad=False).  Not supported: tracing a training forward under fake tensors
+(AOTAutograd / `torch.compile` of a training step) -- the run state of a forward lives
+in this process, keyed by a token the fake implementation cannot produce, so the traced
+backward raises; and loading a saved trace in ANOTHER process (the graph holds this
+process's `handle`).  Eager autograd is the training path.  The returned feature maps are
+ordinary autograd-tracked tensors, so user heads / necks (necks.py:83) compose with them.
 """
 from __future__ import annotations
 
@@ -179,7 +183,11 @@ def _backbone_fake(x, params, handle, all_maps, dtype, need_grad):
 def _backbone_setup(ctx, inputs, output):
     x, params, handle, all_maps, dtype, need_grad = inputs
     ctx.handle, ctx.n_params, ctx.x_requires_grad = handle, len(params), x.requires_grad
-    ctx.st = _runner(handle)._pending.pop(int(output[-1]), None) if need_grad else None
+    tok = output[-1]
+    # under FakeTensorMode (AOTAutograd, torch.compile, export) the token holds no data: reading it would raise
+    # DataDependentOutputException; such a context has no run state and its backward says so
+    fake = isinstance(tok, torch._subclasses.fake_tensor.FakeTensor)
+    ctx.st = _runner(handle)._pending.pop(int(tok), None) if (need_grad and not fake) else None
 
 
 def _backbone_backward(ctx, gouts):

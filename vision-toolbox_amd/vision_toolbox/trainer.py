@@ -276,7 +276,7 @@ class TrainStep:
         # the sums are 64-bit fixed point (vt_amd.h, VT_STAT_REPLICAS): an integer all-reduce, exact and order-free
         return self.arena[start : start + nbytes].view(torch.int64)
 
-    def _run_list(self, ops, n, sync, cuts, cut_buckets, s, side):
+    def _run_list(self, ops, n, sync, cuts, cut_buckets, s, side, keep_side_open=True):
         """run a launch list in segments: a segment ends before every finalize kernel whose statistics
         must be all-reduced first (SyncBatchNorm) and after every op that completes a gradient bucket.
 
@@ -284,14 +284,16 @@ class TrainStep:
         (side) stream open instead of joining it, and a bucket's collective is issued with the SIDE stream current,
         after ordering that stream behind the main stream's position (BatchNorm / bias gradients are written
         there).  RCCL's stream then waits for exactly the producers of the bucket, the main stream for nothing;
-        the list's own JOIN op (last segment) and `bucketer.finish()` close both before the optimiser."""
+        the list's own JOIN op (last segment) and `bucketer.finish()` close both before the optimiser.
+        `keep_side_open=False` (the forward list, which carries no JOIN op of its own): every segment joins the side
+        stream on return, so the data-gradient filter packs hoisted onto it are ordered before backward reads them."""
         marks = {idx: ("sync", (base, off, nb)) for idx, base, off, nb in sync}
         ends = sorted(set(marks) | set(cuts) | {n})
         lo = 0
         for hi in ends:
             if hi > lo:
                 sub = (N.Op * (hi - lo)).from_address(ctypes.addressof(ops) + lo * ctypes.sizeof(N.Op))
-                N.run_ops(sub, hi - lo, self.bases, s, side=side, leave_side_open=hi != n)
+                N.run_ops(sub, hi - lo, self.bases, s, side=side, leave_side_open=keep_side_open and hi != n)
             if hi in marks:  # stream-ordered: NCCL makes the launch stream wait, no host sync
                 torch.distributed.all_reduce(self._sync_view(*marks[hi][1]), group=self.pg)
             if hi in cut_buckets and cut_buckets[hi]:
@@ -387,7 +389,7 @@ class TrainStep:
                     self._side = torch.cuda.Stream(self.device)
                 side = int(self._side.cuda_stream) if os.environ.get("VT_NO_SIDE_STREAM", "0") == "0" else 0  # (diagnostics: one stream)
                 N.run_ops(self.zero_ops, 1, self.bases, s)
-                self._run_list(p.fwd_ops, p.n_fwd, self._fwd_sync, [], {}, s, side)
+                self._run_list(p.fwd_ops, p.n_fwd, self._fwd_sync, [], {}, s, side, keep_side_open=False)
                 self._run_list(p.bwd_ops, p.n_bwd, self._bwd_sync, self.bwd_cuts,
                                dict(zip(self.bwd_cuts, self.cut_buckets)), s, side)
             if self.bucketer is not None:
