@@ -191,6 +191,44 @@ int vt_stem_bn_bwd_reduce(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_
 int vt_stem_bn_bwd_combine(int32_t C, int32_t cin, const float* gzx, const float* coef, float* dw,
                            int32_t fixed, void* stream);
 
+/* ---- pointwise (1x1) ConvNormAct unit without materialised pre-activations (vt_pointwise.hip) ---------------
+ * A 1x1 `ConvNormAct` (components.py:26-44: nn.Conv2d(k=1, bias=False) -> nn.BatchNorm2d -> nn.ReLU) and its autograd
+ * backward as four streaming passes that RECOMPUTE z = W x from the unit's input instead of storing z and dz:
+ *   vt_pw_fwd_stats   x            -> batch statistics of z                       (then vt_bn_finalize)
+ *   vt_pw_fwd_apply   x (+ res)    -> y = relu(z*scale + shift) (+ residual)
+ *   vt_pw_bwd_reduce  dy, x        -> sums of g and g*xhat, g = dy*[y>0]          (then vt_bn_bwd_finalize)
+ *   vt_pw_bwd_apply   dy, x (+add) -> dx = W^T dz (+ addend), dW += dz^T x, dz = coef0*g - coef1*z + coef2 in registers
+ * z is rounded to bf16 where the unfused path stores it, so values agree with vt_conv_igemm + vt_bn_* to summation
+ * order.  Up to two OUTPUT GROUPS share a launch -- CSPDarknetStage.conv1 / conv2 (darknet.py:46-47,53) read the same
+ * tensor: one GEMM with N = C[0] + C[1] whose halves have their own filters, BatchNorm coefficients, statistics and
+ * destinations.  bf16; K and every C[g] multiples of 32; vt_pw_supported() says whether a shape has a kernel:
+ *   0 no;  2 yes;  1 yes, but the filter gradient does not fit the kernel's accumulators: vt_pw_bwd_apply then WRITES dz
+ *   (pass `dz`) and the caller runs vt_conv_wgrad on it, `dw` must be NULL.
+ * `coef` is float[4][N] = scale | shift | mean | invstd over all N = C[0] + C[1] channels (group 1 after group 0);
+ * statistics / sums buffers and the vt_bn_bwd_finalize coefficients `bcoef` (float[3][C[g]]) are per group.
+ * Arrays of per-group values have `ngroups` entries. */
+typedef struct vt_pw_desc {
+    int32_t dtype; /* VT_BF16 */
+    int32_t K;     /* input channels */
+    int32_t ngroups;
+    int32_t relu;
+    int64_t M;     /* pixels (B*H*W) */
+    const void* x; /* [M][K], pixel stride ldx */
+    int32_t ldx;
+    int32_t C[2];       /* output channels per group */
+    const void* w[2];   /* filters [C[g]][K], row stride ldw[g] */
+    int32_t ldw[2];
+} vt_pw_desc;
+int vt_pw_supported(int32_t dtype, int32_t K, int32_t C0, int32_t C1);
+int vt_pw_fwd_stats(const vt_pw_desc* d, float* const* stats, void* stream);
+int vt_pw_fwd_apply(const vt_pw_desc* d, const float* coef, void* const* y, const int32_t* ldy,
+                    const void* const* res, const int32_t* ldr, void* stream);
+int vt_pw_bwd_reduce(const vt_pw_desc* d, const float* coef, const void* const* dy, const int32_t* lddy,
+                     float* const* sums, void* stream);
+int vt_pw_bwd_apply(const vt_pw_desc* d, const float* coef, const void* const* dy, const int32_t* lddy,
+                    const float* const* bcoef, void* dx, int32_t lddx, const void* addend, int32_t ldadd,
+                    float* const* dw, const int32_t* lddw, void* const* dz, const int32_t* lddz, void* stream);
+
 /* ---- pooling ------------------------------------------------------------ */
 /* nn.MaxPool2d(3, 2, 1) at the head of every VoVNet stage (vovnet.py:94). */
 int vt_maxpool3x3s2_fwd(const void* x, int32_t ldx, void* y, int32_t ldy, uint8_t* argmax,
@@ -289,7 +327,7 @@ int vt_nhwc_to_nchw(const void* y, int32_t ldy, float* x, int32_t B, int32_t C, 
  * the list once per (model, input shape) and replays it with one call, or as a
  * captured hipGraph.  Pointers are (base, byte offset) pairs so one list serves
  * any arena placement. */
-#define VT_OP_MAX_PTR 12
+#define VT_OP_MAX_PTR 16
 #define VT_OP_MAX_INT 110
 #define VT_OP_MAX_FLT 8
 #define VT_MAX_BASES 16
@@ -327,6 +365,10 @@ enum vt_op_kind {
     VT_OP_STEM_BWD_REDUCE,  /* vt_stem_bn_bwd_reduce */
     VT_OP_STEM_BWD_COMBINE, /* vt_stem_bn_bwd_combine */
     VT_OP_FIXED_TO_F32,     /* vt_fixed_to_f32 */
+    VT_OP_PW_STATS,         /* vt_pw_fwd_stats */
+    VT_OP_PW_APPLY,         /* vt_pw_fwd_apply */
+    VT_OP_PW_REDUCE,        /* vt_pw_bwd_reduce */
+    VT_OP_PW_BWD,           /* vt_pw_bwd_apply */
     VT_OP_KIND_END
 };
 

@@ -156,16 +156,23 @@ def test_cspdarknet53_program_structure():
     # the stem unit's backward is ONE streaming pass (BatchNorm reduction + filter-gradient correlations) and a
     # combine kernel: no dz, no bn_bwd_reduce / bn_bwd_apply / conv_wgrad for it (vt_stem_bwd.hip)
     assert h["stem_bwd_reduce"] == 1 and h["stem_bwd_combine"] == 1
-    assert h["conv_wgrad"] == 66 and h["bn_finalize"] == 67 and h["bn_bwd_apply"] == 66 and h["bn_bwd_reduce"] == 66
+    # 17 of the 38 1x1 units run as pointwise passes that recompute z (vt_pointwise.hip: the 32 / 64 / 128-channel ones
+    # of stages 0-2), conv1 | conv2 of stages 0 and 1 as ONE two-group launch each: 15 launches per pass
+    pw_units, pw_launches = 17, 15
+    assert h["pw_stats"] == h["pw_apply"] == h["pw_reduce"] == h["pw_bwd"] == pw_launches
+    # their filter gradient is formed inside pw_bwd up to 64 x 64; the 128-channel ones (stage 1 pair + out_conv, the 8
+    # block units of stage 2: 11 filters) hand dz to the filter-gradient kernel
+    assert h["conv_wgrad"] == 66 - pw_units + 11 and h["bn_finalize"] == 67
+    assert h["bn_bwd_apply"] == 66 - pw_units and h["bn_bwd_reduce"] == 66 - pw_units
     assert h["bn_bwd_finalize"] == 67
     # residual adds are folded into the normalise pass and torch.cat is elided: the ONLY
-    # elementwise launches are one bn_act_apply per unit; the only copies are the bf16 weight
+    # elementwise launches are one bn_act_apply per remaining unit; the only copies are the bf16 weight
     # mirror and the 3->8 channel stem filter pad
-    assert h["bn_act_apply"] == 67
+    assert h["bn_act_apply"] == 67 - pw_units
     assert h["copy2d"] == 2
     # forward convs + one data-gradient launch per conv; the 5 stride-2 convs take 4 parity-class launches, except the
     # HBM-bound first one (32 -> 64 channels), whose classes are the column blocks of one depth-to-space launch
-    assert h["conv_igemm"] == 67 + (66 - 5) + 4 * 4 + 1
+    assert h["conv_igemm"] == (67 - pw_units) + (66 - 5 - pw_units) + 4 * 4 + 1
     assert "maxpool_fwd" not in h
 
 

@@ -21,6 +21,11 @@ from vision_toolbox import backbones
 from vision_toolbox.trainer import TrainStep
 
 
+# yardstick of the "excess" columns: the chip table of MI355X_MICROARCH.md -- dense bf16 MFMA 2.5 PFLOP/s, HBM 6.3 TB/s
+# achievable (8 TB/s spec)
+PEAK_FLOPS, PEAK_HBM = 2.5e15, 6.3e12
+
+
 def main():
     model = sys.argv[1] if len(sys.argv) > 1 else "cspdarknet53"
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
@@ -64,7 +69,7 @@ def main():
                             + d.B * d.Ho * d.Wo * d.Cout) + 2.0 * d.Cout * d.Cin * d.ntaps
                 if kind == N.OP_CONV_WGRAD:
                     nb = 2.0 * (d.B * d.Hi * d.Wi * d.Cin + d.B * d.Ho * d.Wo * d.Cout)
-                ideal = max(fl / 1.0e15, nb / 5.0e12) * 1e3  # ms: 1.0 PF/s practical MFMA, 5 TB/s HBM
+                ideal = max(fl / PEAK_FLOPS, nb / PEAK_HBM) * 1e3  # ms against the guide's peaks
                 work = f"{fl / ms / 1e9:7.1f} TF/s {nb / ms / 1e9:6.2f} TB/s ideal {ideal:6.3f} excess {ms - ideal:6.3f}"
                 excess.append((ms - ideal, phase, name, desc, ms, ideal))
             # bytes this decomposition moves when every operand is read / written exactly once (bf16 activations)
@@ -76,6 +81,20 @@ def main():
                 algo_bytes[name] += 2.0 * op.f[0] * op.i[2] * 2
             elif kind == N.OP_BN_BWD_APPLY:  # i: lddy ldz lddz C relu dtype | f: M
                 algo_bytes[name] += 2.0 * op.f[0] * op.i[3] * 3
+            elif kind in (N.OP_PW_STATS, N.OP_PW_APPLY, N.OP_PW_REDUCE, N.OP_PW_BWD):
+                # i: K ngroups relu C0 C1 ldx ... | f: M.  x once; y / dy once; residual / addend and dz where present
+                K, Nn, M_ = op.i[0], op.i[3] + op.i[4], op.f[0]
+                nb = 2.0 * M_ * K
+                if kind == N.OP_PW_APPLY:
+                    nb += 2.0 * M_ * Nn + sum(2.0 * M_ * op.i[3 + g] for g in range(2) if op.ptr[6 + g].base >= 0)
+                elif kind == N.OP_PW_REDUCE:
+                    nb += 2.0 * M_ * Nn
+                elif kind == N.OP_PW_BWD:
+                    nb += 2.0 * M_ * Nn + 2.0 * M_ * K * (2 if op.ptr[9].base >= 0 else 1)
+                    nb += sum(2.0 * M_ * op.i[3 + g] for g in range(2) if op.ptr[12 + g].base >= 0)
+                algo_bytes[name] += nb
+                desc = f"{K:4d}->{Nn:4d} M {int(M_)}"
+                work = f"{nb / ms / 1e9:6.2f} TB/s ideal {nb / PEAK_HBM * 1e3:6.3f} excess {ms - nb / PEAK_HBM * 1e3:6.3f}"
             elif kind == N.OP_STEM_BWD_REDUCE:  # i: dtype B H W C ...
                 algo_bytes[name] += 2.0 * op.i[1] * op.i[2] * op.i[3] * (8 + 2 * op.i[4])
             rows.append((ms, phase, idx, name, desc, work))
@@ -87,11 +106,14 @@ def main():
         print(f"  {phase} {name:16s} {v:8.3f} ms")
     print(f"-- bytes per step when every operand of this decomposition moves once: {sum(algo_bytes.values()) / 1e9:.2f} GB "
           + ", ".join(f"{k} {v / 1e9:.2f}" for k, v in sorted(algo_bytes.items(), key=lambda kv: -kv[1])))
+    print("-- pointwise ops (bytes = operands of the pass, once)")
+    for ms, phase, idx, name, desc, work in sorted([r for r in rows if r[3].startswith("pw_")], key=lambda r: -r[0])[:top]:
+        print(f"  {phase}[{idx:4d}] {name:11s} {desc}  {ms:7.4f} ms {work}")
     print("-- conv ops by time")
     conv = [r for r in rows if r[3].startswith("conv")]
     for ms, phase, idx, name, desc, work in sorted(conv, key=lambda r: -r[0])[:top]:
         print(f"  {phase}[{idx:4d}] {name:11s} {desc}  {ms:7.4f} ms {work}")
-    print("-- conv ops by excess over max(flops / 1.0 PF/s, bytes / 5 TB/s)")
+    print("-- conv ops by excess over max(flops / 2.5 PF/s, bytes / 6.3 TB/s)")
     agg2 = defaultdict(lambda: [0, 0.0, 0.0])
     for ex, phase, name, desc, ms, ideal in excess:
         a = agg2[(phase, name, desc)]

@@ -209,6 +209,41 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
             return vt_nchw_to_nhwc((const float*)P[0], P[1], I[0], I[1], I[2], I[3], I[4], I[5], st);
         case VT_OP_NHWC_TO_NCHW:  // ptr: y x | i: ldy B C H W dtype
             return vt_nhwc_to_nchw(P[0], I[0], (float*)P[1], I[1], I[2], I[3], I[4], I[5], st);
+        // pointwise units: i: K ngroups relu C0 C1 ldx ldw0 ldw1 + per-kind strides | f: M | ptr 0..2: x w0 w1
+        case VT_OP_PW_STATS:    // ptr: x w0 w1 stats0 stats1
+        case VT_OP_PW_APPLY:    // ptr: x w0 w1 coef y0 y1 res0 res1 | i[8..11]: ldy0 ldy1 ldr0 ldr1
+        case VT_OP_PW_REDUCE:   // ptr: x w0 w1 coef dy0 dy1 sums0 sums1 | i[8..9]: lddy0 lddy1
+        case VT_OP_PW_BWD: {    // ptr: x w0 w1 coef dy0 dy1 bcoef0 bcoef1 dx addend dw0 dw1 dz0 dz1
+                                // i[8..]: lddy0 lddy1 lddx ldadd lddw0 lddw1 lddz0 lddz1
+            vt_pw_desc d;
+            memset(&d, 0, sizeof(d));
+            d.dtype = VT_BF16;
+            d.K = I[0], d.ngroups = I[1], d.relu = I[2], d.C[0] = I[3], d.C[1] = I[4];
+            d.M = (int64_t)F[0];
+            d.x = P[0], d.ldx = I[5];
+            d.w[0] = P[1], d.w[1] = P[2], d.ldw[0] = I[6], d.ldw[1] = I[7];
+            if (op.kind == VT_OP_PW_STATS) {
+                float* st2[2] = {(float*)P[3], (float*)P[4]};
+                return vt_pw_fwd_stats(&d, st2, st);
+            }
+            if (op.kind == VT_OP_PW_APPLY) {
+                void* y2[2] = {P[4], P[5]};
+                const void* r2[2] = {P[6], P[7]};
+                const int32_t ldy2[2] = {I[8], I[9]}, ldr2[2] = {I[10], I[11]};
+                return vt_pw_fwd_apply(&d, (const float*)P[3], y2, ldy2, r2, ldr2, st);
+            }
+            const void* dy2[2] = {P[4], P[5]};
+            const int32_t lddy2[2] = {I[8], I[9]};
+            if (op.kind == VT_OP_PW_REDUCE) {
+                float* s2[2] = {(float*)P[6], (float*)P[7]};
+                return vt_pw_bwd_reduce(&d, (const float*)P[3], dy2, lddy2, s2, st);
+            }
+            const float* bc2[2] = {(const float*)P[6], (const float*)P[7]};
+            float* dw2[2] = {(float*)P[10], (float*)P[11]};
+            void* dz2[2] = {P[12], P[13]};
+            const int32_t lddw2[2] = {I[12], I[13]}, lddz2[2] = {I[14], I[15]};
+            return vt_pw_bwd_apply(&d, (const float*)P[3], dy2, lddy2, bc2, P[8], I[10], P[9], I[11], dw2, lddw2, dz2, lddz2, st);
+        }
         default:
             vt_set_error("vt_run_ops: unknown op kind %d (tag %d)", op.kind, op.tag);
             return VT_ERR_INVALID;

@@ -50,7 +50,7 @@ def stats_encode(buf, which: int, values, replica: int = 0):
     buf[replica, which, :, 1] += torch.round((v - hi * 4096.0) * float(1 << 33)).to(torch.int64)
 
 
-VT_OP_MAX_PTR, VT_OP_MAX_INT, VT_OP_MAX_FLT, VT_MAX_BASES = 12, 110, 8, 16
+VT_OP_MAX_PTR, VT_OP_MAX_INT, VT_OP_MAX_FLT, VT_MAX_BASES = 16, 110, 8, 16
 
 (
     OP_MEMSET,
@@ -84,7 +84,11 @@ VT_OP_MAX_PTR, VT_OP_MAX_INT, VT_OP_MAX_FLT, VT_MAX_BASES = 12, 110, 8, 16
     OP_STEM_BWD_REDUCE,
     OP_STEM_BWD_COMBINE,
     OP_FIXED_TO_F32,
-) = range(1, 32)
+    OP_PW_STATS,
+    OP_PW_APPLY,
+    OP_PW_REDUCE,
+    OP_PW_BWD,
+) = range(1, 36)
 OP_SIDE_STREAM = 0x10000  # OR-ed into Op.kind: enqueue on the side stream
 
 OP_NAMES = {
@@ -119,6 +123,10 @@ OP_NAMES = {
     OP_FIXED_TO_F32: "fixed_to_f32",
     OP_RESAMPLE_FWD: "resample_fwd",
     OP_RESAMPLE_BWD: "resample_bwd",
+    OP_PW_STATS: "pw_stats",
+    OP_PW_APPLY: "pw_apply",
+    OP_PW_REDUCE: "pw_reduce",
+    OP_PW_BWD: "pw_bwd",
 }
 
 
@@ -136,6 +144,19 @@ class ConvDesc(C.Structure):
         ("ldw", C.c_int32), ("ldr", C.c_int32), ("flags", C.c_int32), ("ntaps", C.c_int32),
         ("dh", C.c_int8 * VT_MAX_TAPS),
         ("dw", C.c_int8 * VT_MAX_TAPS),
+    ]  # fmt: skip
+
+
+class PwDesc(C.Structure):
+    """vt_pw_desc"""
+
+    _fields_ = [
+        ("dtype", C.c_int32), ("K", C.c_int32), ("ngroups", C.c_int32), ("relu", C.c_int32),
+        ("M", C.c_int64),
+        ("x", C.c_void_p), ("ldx", C.c_int32),
+        ("C", C.c_int32 * 2),
+        ("w", C.c_void_p * 2),
+        ("ldw", C.c_int32 * 2),
     ]  # fmt: skip
 
 
@@ -184,6 +205,12 @@ SYMBOLS = {
     "vt_stem_bn_bwd_reduce": (_i32, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
     "vt_stem_bn_bwd_combine": (_i32, [_i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "vt_bn_act_bwd_apply": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),
+    "vt_pw_supported": (_i32, [_i32, _i32, _i32, _i32]),
+    "vt_pw_fwd_stats": (_i32, [C.POINTER(PwDesc), C.POINTER(_vp), _vp]),
+    "vt_pw_fwd_apply": (_i32, [C.POINTER(PwDesc), _vp, C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_vp), C.POINTER(_i32), _vp]),
+    "vt_pw_bwd_reduce": (_i32, [C.POINTER(PwDesc), _vp, C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_vp), _vp]),
+    "vt_pw_bwd_apply": (_i32, [C.POINTER(PwDesc), _vp, C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_vp), _vp, _i32, _vp, _i32,
+                               C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_vp), C.POINTER(_i32), _vp]),
     "vt_maxpool3x3s2_fwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vt_maxpool3x3s2_bwd": (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vt_global_avgpool_fwd": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -98,8 +98,8 @@ class CSPDarknetStage(HipModule):
         width = self.out_conv.conv.in_channels
         half = self.conv1.conv.out_channels
         joined = b.act(o.B, o.H, o.W, width, name + ".cat")  # the tensor torch.cat would have produced
-        self.conv1._vt_emit(b, o, out=joined.sl(0, half), name=name + ".conv1")
-        t = self.conv2._vt_emit(b, o, name=name + ".conv2")
+        # conv1 and conv2 read the same tensor: one N = C launch per pass where the pointwise kernels apply
+        _, t = b.conv_unit_pair(o, (self.conv1, joined.sl(0, half), name + ".conv1"), (self.conv2, None, name + ".conv2"))
         _emit_chain(list(self.blocks), b, t, joined.sl(half, width - half), name + ".blocks")
         return self.out_conv._vt_emit(b, joined, out=out, name=name + ".out_conv")
 

@@ -254,6 +254,9 @@ class Builder:
         self.deterministic = (os.environ.get("VT_DETERMINISTIC", "0") != "0") if deterministic is None else bool(deterministic)
         self.wgrad_slab_mb = int(os.environ.get("VT_WGRAD_SLABS_MB", "48" if self.deterministic else "0"))  # 0 = atomics
         self._wgrad_slab = None
+        # 1x1 ConvNormAct units as four streaming passes that recompute z = W x instead of storing z and dz
+        # (vt_pointwise.hip); off in deterministic mode (its filter gradient leaves through float atomics)
+        self.pointwise = os.environ.get("VT_POINTWISE", "1") != "0" and not self.deterministic
         self._hoisted: list[N.Op] = []
         # SyncBatchNorm (configs/base.yaml:22): the trainer all-reduces every layer's statistics
         # between the kernel that accumulates them and the finalize kernel; the finalize kernels
@@ -525,6 +528,13 @@ class Builder:
         B = x.B
         M = B * Ho * Wo
 
+        if has_bn:
+            spec = (conv, norm, relu, residual, out, name)
+            if self._pw_ok(x, [spec]):
+                self.tag -= 1  # (pw_units takes its own tag)
+                self.n_units -= 1
+                return self.pw_units(x, [spec])[0]
+
         # ---- filter operand ---------------------------------------------------------
         w = conv.weight
         padded = x.C != Cin_w  # stem: 3 channels padded to one 16-byte chunk
@@ -683,6 +693,138 @@ class Builder:
 
             self.nodes.append(bwd)
         return y
+
+    # -- pointwise (1x1) units without stored pre-activations (vt_pointwise.hip) ------------------------------------
+    def _pw_ok(self, x: TRef, specs) -> int:
+        """0: the pointwise kernels do not apply to these units (reading the same x); 2: they do, filter gradient
+        included; 1: they do, with dz handed to the filter-gradient kernel (vt_pw_supported)."""
+        if not self.pointwise or self.dtype != N.VT_BF16 or not (1 <= len(specs) <= 2):
+            return 0
+        flags = set()
+        for conv, norm, relu, residual, out, _ in specs:
+            if (conv.kernel_size != (1, 1) or conv.stride != (1, 1) or conv.padding != (0, 0) or conv.dilation != (1, 1)
+                    or conv.groups != 1 or conv.bias is not None or not isinstance(norm, nn.BatchNorm2d)
+                    or norm.momentum is None or not norm.affine or not norm.track_running_stats):
+                return 0
+            if conv.in_channels != x.C or getattr(x, "logical_C", x.C) != x.C:
+                return 0
+            flags.add((bool(norm.training), bool(relu)))
+        if len(flags) != 1:
+            return 0
+        unit_training, _ = next(iter(flags))
+        if not unit_training and not self.need_grad:
+            return 0  # inference: one conv launch with the affine + ReLU epilogue is already a single pass
+        if self.need_grad and not x.needs_grad:
+            return 0  # (the backward kernel always forms dx)
+        cs = [sp[0].out_channels for sp in specs] + [0]
+        return int(N.lib().vt_pw_supported(self.dtype, x.C, cs[0], cs[1]))
+
+    def pw_units(self, x: TRef, specs) -> "list[TRef]":
+        """one or two 1x1 ConvNormAct units reading the same tensor x (components.py:26-44; two: CSPDarknetStage's
+        conv1 | conv2, darknet.py:46-47,53) as ONE launch per pass: statistics, normalise, backward reduction, backward
+        apply with the data gradient and (small shapes) the filter gradient.  z and dz are never stored."""
+        mode = self._pw_ok(x, specs)
+        assert mode in (1, 2)
+        self.tag += 1
+        self.n_units += len(specs)
+        dt = self.dtype
+        G = len(specs)
+        Cs = [sp[0].out_channels for sp in specs]
+        Ntot, K, M = sum(Cs), x.C, x.M
+        offs = [0, Cs[0]][:G]
+        relu = bool(specs[0][2])
+        unit_training = bool(specs[0][1].training)
+        convs, norms = [sp[0] for sp in specs], [sp[1] for sp in specs]
+        ys = []
+        for (conv, norm, _, residual, out, name), c in zip(specs, Cs):
+            if out is not None:
+                assert (out.B, out.H, out.W, out.C) == (x.B, x.H, x.W, c), "out geometry mismatch"
+            if residual is not None:
+                assert (residual.B, residual.H, residual.W, residual.C) == (x.B, x.H, x.W, c)
+            ys.append(out if out is not None else self.act(x.B, x.H, x.W, c, name + ".y"))
+        coef = self.f32(4 * Ntot, "bncoef4")  # scale | shift | mean | invstd over all groups' channels
+        cps = [[self.bp(coef, (i * Ntot + o) * 4) for i in range(4)] for o in offs]
+        wps = [self.pref(c.weight, mirror=True) for c in convs]
+        pad2 = lambda v, fill=None: list(v) + [fill] * (2 - len(v))
+        head_i = [K, G, int(relu)] + pad2(Cs, 0) + [x.ld] + pad2([K] * G, 0)
+        if unit_training:
+            stats = [self.zeroed_f32(N.stat_floats(c), "stats") for c in Cs]
+            self.emit(N.OP_PW_STATS, [x.addr(), *pad2(wps), *pad2([self.bp(s_) for s_ in stats])], head_i, [M])
+            for g, norm in enumerate(norms):
+                self.emit(N.OP_BN_FINALIZE,
+                          [self.bp(stats[g]), self.pref(norm.weight), self.pref(norm.bias), self.pref(norm.running_mean),
+                           self.pref(norm.running_var), self.pref(norm.num_batches_tracked), *cps[g]],
+                          [Cs[g]], [M * self.bn_world, norm.eps, norm.momentum])
+        else:
+            for g, norm in enumerate(norms):
+                self.emit(N.OP_BN_EVAL_COEFFS, [self.pref(norm.weight), self.pref(norm.bias), self.pref(norm.running_mean),
+                                                self.pref(norm.running_var), *cps[g]], [Cs[g]], [norm.eps])
+        ress = [sp[3] for sp in specs]
+        self.emit(N.OP_PW_APPLY,
+                  [x.addr(), *pad2(wps), self.bp(coef), *pad2([y.addr() for y in ys]),
+                   *pad2([r.addr() if r is not None else None for r in ress])],
+                  head_i + pad2([y.ld for y in ys], 0) + pad2([r.ld if r is not None else 0 for r in ress], 0), [M])
+        if self.need_grad:
+            tag = self.tag
+
+            def bwd():
+                self.tag = tag
+                dys = [self.grad_read(y) for y in ys]
+                if all(d is None for d in dys):
+                    return
+                for g in range(G):
+                    if dys[g] is None:  # a branch nothing back-propagates into: a zero gradient
+                        z_ = self.act(x.B, x.H, x.W, Cs[g], specs[g][5] + ".dy0")
+                        self.emit(N.OP_MEMSET, [z_.addr()], [0], [z_.buf.nbytes])
+                        dys[g] = z_
+                    if ress[g] is not None:
+                        self.grad_add(ress[g], dys[g])
+                sums = [self.zeroed_f32(N.stat_floats(c), "bwdsums") for c in Cs]
+                dy_p, dy_ld = pad2([d.addr() for d in dys]), pad2([d.ld for d in dys], 0)
+                self.emit(N.OP_PW_REDUCE, [x.addr(), *pad2(wps), self.bp(coef), *dy_p, *pad2([self.bp(s_) for s_ in sums])],
+                          head_i + dy_ld, [M])
+                bcoefs = [self.f32(3 * c, "bwdcoef") for c in Cs]
+                for g, norm in enumerate(norms):
+                    self.emit(N.OP_BN_BWD_FINALIZE,
+                              [self.bp(sums[g]), cps[g][0], cps[g][2], cps[g][3], self.pgrad(norm.weight), self.pgrad(norm.bias),
+                               self.bp(bcoefs[g])], [Cs[g], int(unit_training)], [M * self.bn_world, 1.0 / self.bn_world])
+                gx, res = self.grad_target(x)
+                want_dw = [c.weight.requires_grad for c in convs]
+                dws = [self.pgrad(c.weight) if (mode == 2 and w_) else None for c, w_ in zip(convs, want_dw)]
+                dzs = [self.act(x.B, x.H, x.W, c, sp[5] + ".dz") if (mode == 1 and w_) else None
+                       for c, sp, w_ in zip(Cs, specs, want_dw)]
+                self.emit(N.OP_PW_BWD,
+                          [x.addr(), *pad2(wps), self.bp(coef), *dy_p, *pad2([self.bp(b_) for b_ in bcoefs]), gx.addr(),
+                           res.addr() if res is not None else None, *pad2(dws),
+                           *pad2([d.addr() if d is not None else None for d in dzs])],
+                          head_i + dy_ld + [gx.ld, res.ld if res is not None else 0] + pad2([K] * G, 0) +
+                          pad2([d.ld if d is not None else 0 for d in dzs], 0), [M])
+                self.grad_written(x)
+                if mode == 1 and any(d is not None for d in dzs):
+                    # the filter gradient does not fit the kernel's accumulators: dz was written, the usual kernel takes it
+                    self.emit(N.OP_FORK)
+                    for g, conv in enumerate(convs):
+                        if dzs[g] is None:
+                            continue
+                        dfwd = self._conv_desc(x, Cs[g], x.H, x.W, 1, 0, 1, dzs[g].ld, K, 0)
+                        self.emit(N.OP_CONV_WGRAD, [x.addr(), dzs[g].addr(), self.pgrad(conv.weight), None], desc=dfwd,
+                                  extra_ints=[K, 0], side=True)
+
+            self.nodes.append(bwd)
+        return ys
+
+    def conv_unit_pair(self, x: TRef, a, b):
+        """two ConvNormAct units that read the same tensor (CSPDarknetStage.conv1 / conv2): one pointwise launch per
+        pass when the kernels cover the joint shape, else two independent units.  a, b = (ConvNormAct, out, name)."""
+        def spec(t):
+            m, out, name = t
+            norm = m.norm if isinstance(m.norm, nn.BatchNorm2d) else None
+            return (m.conv, norm, m._vt_relu(), None, out, name)
+
+        sa, sb = spec(a), spec(b)
+        if sa[1] is not None and sb[1] is not None and self._pw_ok(x, [sa, sb]):
+            return self.pw_units(x, [sa, sb])
+        return [a[0]._vt_emit(self, x, out=a[1], name=a[2]), b[0]._vt_emit(self, x, out=b[1], name=b[2])]
 
     def _dgrad(self, x: TRef, dz: TRef, wptr, w_dtype, ldw, Cout, k, s, pad, Ho, Wo):
         dt = self.dtype
