@@ -4,8 +4,10 @@
     python bench.py --gpus N --steps K --warmup W
 
 A step = forward + label-smoothing CE + backward + gradient all-reduce (N>1) + SGD(momentum)
-over one synthetic batch resident in HBM (BASELINE.json configs[1]: batch 256 per GPU,
-3x224x224, uniform [0,1) images, random-init weights; weak scaling for N>1).
+over one synthetic batch resident in HBM: 3x224x224, uniform [0,1) images, random-init weights.
+N = 1 runs BASELINE.json configs[1] (batch 256 on one GPU); N > 1 runs configs[2] (data parallel, 128 images
+per GPU = global 128*N, 1024 on 8 GPUs: the reference recipe's global batch, data.py:65-66) -- weak scaling at
+128 per GPU, whose 1-GPU denominator the N = 1 line carries as `n1_same_per_gpu_batch_ms`.  `--batch` overrides.
 Rank 0 prints ONE JSON line with the metric, the roofline of the dominant kernel
 (measured live, IN SITU: HIP events around that layer's launches inside the step's own forward
 list, on the launch stream) and the CPU baseline (the oracle, timed on the host cores on a
@@ -144,18 +146,21 @@ def host_cpu():
     return ncores, model
 
 
-def insitu_layer_times(ts, Cin, Cout, ntaps, HW, reps=4):
-    """HIP-event time of every forward launch of the conv layer shape (Cin -> Cout, ntaps, HW x HW, stride 1)
-    INSIDE the step's forward list: the list is run in pieces with events around those ops, so each launch
-    reads what the previous kernels of the step left behind a 20 GB arena (not a cache-resident toy).
+def insitu_layer_times(ts, Cin, Cout, ntaps, HW, reps=4, which="fwd"):
+    """HIP-event time of every launch of one conv layer shape (Cin -> Cout, ntaps, HW x HW, stride 1) INSIDE the step's own
+    launch lists: the list is run in pieces with events around those ops, so each launch reads what the previous kernels
+    of the step left behind a 20 GB arena (not a cache-resident toy).  which = "fwd" (forward list), "dgrad" (the data
+    gradient: a conv over dz in the backward list) or "wgrad" (filter gradient; run in line on the main stream here).
     Returns (mean ms, launches timed, kernel name chosen by the dispatcher)."""
     from vision_toolbox import _native as N
 
     p = ts.prog
+    ops, n = (p.fwd_ops, p.n_fwd) if which == "fwd" else (p.bwd_ops, p.n_bwd)
+    kind = N.OP_CONV_WGRAD if which == "wgrad" else N.OP_CONV_IGEMM
     idxs = []
-    for i in range(p.n_fwd):
-        op = p.fwd_ops[i]
-        if (op.kind & 0xFFFF) != N.OP_CONV_IGEMM:
+    for i in range(n):
+        op = ops[i]
+        if (op.kind & 0xFFFF) != kind:
             continue
         d = N.ConvDesc.from_buffer_copy(bytes(op.i)[: ctypes.sizeof(N.ConvDesc)])
         if (d.Cin, d.Cout, d.ntaps, d.Hi, d.Wi, d.sh) == (Cin, Cout, ntaps, HW, HW, 1):
@@ -166,28 +171,92 @@ def insitu_layer_times(ts, Cin, Cout, ntaps, HW, reps=4):
     side = int(ts._side.cuda_stream) if ts._side is not None else 0
     sz = ctypes.sizeof(N.Op)
 
-    def run(lo, hi):
+    def run(lst, lo, hi, use_side):
         if hi > lo:
-            sub = (N.Op * (hi - lo)).from_address(ctypes.addressof(p.fwd_ops) + lo * sz)
-            N.run_ops(sub, hi - lo, ts.bases, s, side=side)
+            sub = (N.Op * (hi - lo)).from_address(ctypes.addressof(lst) + lo * sz)
+            N.run_ops(sub, hi - lo, ts.bases, s, side=side if use_side else 0)
 
     pairs, name = [], ""
     for _ in range(reps):
         N.run_ops(ts.zero_ops, 1, ts.bases, s)
+        if which != "fwd":
+            run(p.fwd_ops, 0, p.n_fwd, True)
         lo = 0
         for i in idxs:
-            run(lo, i)
+            run(ops, lo, i, which == "fwd")
             e0, e1 = N.Event(), N.Event()
             e0.record(s)
-            run(i, i + 1)
+            run(ops, i, i + 1, False)
             e1.record(s)
             name = N.last_kernel_name()
             pairs.append((e0, e1))
             lo = i + 1
-        run(lo, p.n_fwd)
+        run(ops, lo, n, which == "fwd")
     torch.cuda.synchronize()
     ms = [a.elapsed_ms(b) for a, b in pairs]
     return sum(ms) / len(ms), len(ms), name
+
+
+def time_train_step(model, batch, image_size, steps, warmup, dev):
+    """ms per fused train step of `model` at per-GPU batch `batch` on this GPU alone (no process group)"""
+    from vision_toolbox import backbones
+    from vision_toolbox.trainer import TrainStep
+
+    torch.manual_seed(0)
+    ts = TrainStep(getattr(backbones, model)(), 1000, batch, image_size, torch.bfloat16, lr=0.05, momentum=0.9,
+                   weight_decay=2e-5, label_smoothing=0.1, device=dev, use_graphs=False, process_group=None)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    ts.images.copy_(torch.rand(ts.images.shape, device=dev, generator=g))
+    ts.labels.copy_(torch.randint(0, 1000, ts.labels.shape, device=dev, generator=g))
+    for _ in range(warmup):
+        ts.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ts.step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    loss = ts.loss()
+    del ts
+    torch.cuda.empty_cache()
+    return ms, loss
+
+
+def secondary_configs(dev):
+    """BASELINE.json configs[3] and configs[4] in the driver-timed line (secondary numbers)"""
+    from vision_toolbox import backbones
+
+    out = []
+    # configs[3]: VoVNet-39 forward+backward bf16, batch 256 (the same fused train step); 3 x 15.530 GFLOP per image
+    ms, loss = time_train_step("vovnet39", 256, 224, 8, 3, dev)
+    out.append({"config": "BASELINE configs[3]: VoVNet-39 train step (fwd+CE+bwd+SGD) bf16, batch 256 @224",
+                "ms": round(ms, 3), "images_per_sec": round(256 / ms * 1e3, 1),
+                "tflops": round(3 * 15.530 * 256 / ms, 1), "roofline_frac": round(3 * 15.530 * 256 / ms / PEAK_BF16_TFLOPS, 4),
+                "final_loss": round(loss, 4)})
+    # configs[4]: Darknet-YOLOv5x get_feature_maps() multi-scale forward, batch 64 @640 (module API, eval, no_grad)
+    torch.manual_seed(0)
+    m = backbones.darknet_yolov5x().to(dev).eval()
+    x = torch.rand(64, 3, 640, 640, device=dev)
+
+    def fwd():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return m.get_feature_maps(x)
+
+    for _ in range(3):
+        maps = fwd()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(8):
+        fwd()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 8 * 1e3
+    out.append({"config": "BASELINE configs[4]: Darknet-YOLOv5x get_feature_maps() bf16 forward, batch 64 @640",
+                "ms": round(ms, 3), "images_per_sec": round(64 / ms * 1e3, 1), "tflops": round(127.599 * 64 / ms, 1),
+                "roofline_frac": round(127.599 * 64 / ms / PEAK_BF16_TFLOPS, 4), "maps": [list(t.shape) for t in maps]})
+    del m, x, maps
+    torch.cuda.empty_cache()
+    return out
 
 
 def pmc_traffic_live(layer: str, kernel_substr: str, timeout_s: int = 150):
@@ -309,7 +378,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="per-GPU batch; default 256 on one GPU (BASELINE configs[1]), 128 per GPU on N > 1 "
+                         "(configs[2]: global 128*N = 1024 on 8 GPUs)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip configs[3] / configs[4] and the batch-128 step")
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "sharded"],
+                    help="gradient exchange: f32 all-reduce per bucket (default) or reduce-scatter -> sharded SGD -> "
+                         "bf16 all-gather of the weights (SURVEY 8e)")
     ap.add_argument("--model", default="cspdarknet53")
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--graphs", action="store_true",
@@ -334,6 +409,8 @@ def main():
                     help="(tests) build the launch lists and the bucket plan on the CPU, run the first collectives "
                          "over the given backend and exit: exercises the N>1 launch path without a GPU")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 256 if args.gpus == 1 else 128
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))  # before anything touches the GPU
@@ -354,20 +431,26 @@ def main():
     if args.plan_only:
         torch.manual_seed(0)
         ts = TrainStep(getattr(backbones, args.model)(), 1000, args.batch, args.image_size, torch.bfloat16,
-                       device="cpu", bucket_mb=args.bucket_mb, plan_only=True, sync_bn=args.sync_bn)
+                       device="cpu", bucket_mb=args.bucket_mb, plan_only=True, sync_bn=args.sync_bn, exchange=args.exchange)
         ts.store.pflat.add_(float(rank))  # ranks start different; the broadcast must make them equal
         ts.broadcast_parameters(0)
         ts.gflat.fill_(float(rank + 1))
         ts.bucketer.reduce_all()
         ts.bucketer.finish()
-        ok = bool((ts.gflat == world * (world + 1) / 2).all())
+        want = world * (world + 1) / 2
+        if args.exchange == "sharded":  # reduce-scatter: a rank holds the sums of its own slices
+            ok = all(bool((ts.gflat[a:b] == want).all()) for a, b in ts.bucketer.shards)
+        else:
+            ok = bool((ts.gflat == want).all())
         chk = torch.tensor([float(ts.store.pflat.double().sum())], dtype=torch.float64)
         lo, hi = chk.clone(), chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         if rank == 0:
             print(json.dumps({"plan_only": True, "n_gpus": world, "backend": backend, "buckets": len(ts.bucketer.buckets),
-                              "bwd_segments": len(ts.bwd_cuts), "allreduce_ok": ok,
+                              "bwd_segments": len(ts.bwd_cuts), "allreduce_ok": ok, "gradient_exchange": ts.exchange,
+                              "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                              "head_bucket_bytes": 4 * (ts.bucketer.buckets[-1][1] - ts.bucketer.buckets[-1][0]),
                               "params_equal": bool(lo.item() == hi.item())}), flush=True)
         dist.barrier()
         dist.destroy_process_group()
@@ -379,7 +462,7 @@ def main():
     bb = getattr(backbones, args.model)()
     ts = TrainStep(bb, 1000, args.batch, args.image_size, torch.bfloat16, lr=0.05, momentum=0.9, weight_decay=2e-5,
                    label_smoothing=0.1, device=dev, bucket_mb=args.bucket_mb, use_graphs=args.graphs,
-                   sync_bn=args.sync_bn, deterministic=True if args.deterministic else None)
+                   sync_bn=args.sync_bn, deterministic=True if args.deterministic else None, exchange=args.exchange)
     ts.broadcast_parameters(0)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
@@ -426,27 +509,33 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = args.batch * world * args.steps / elapsed
-        # Dominant kernel: the input-span implicit-GEMM conv (vt_igemm_span.hip) on the stride-1 3x3 convs and
-        # their data gradients.  Its roofline entry is measured IN SITU on the layer shape with the largest
-        # share of the step (cspdarknet53: 128 -> 128 3x3 @28x28, 8 instances): events around those launches
-        # inside the forward list.  `roofline_layers` keeps the standalone (back-to-back, cache-warm) numbers.
+        # Dominant kernel: the two-group + loader-wave span kernel (vt_igemm_span6.hip) on the stride-1 3x3 convs and
+        # their data gradients.  Every roofline entry of the three dominant 3x3 shapes (128 -> 128 @28x28 x8,
+        # 256 -> 256 @14x14 x8, 512 -> 512 @7x7 x4) is measured IN SITU: events around those launches inside the step's own
+        # forward / backward lists, for the forward conv, the data gradient and the filter gradient.
         scale = args.image_size / 224.0
-        dom_shape = (128, 128, 9, int(round(28 * scale))) if args.model in ("cspdarknet53", "darknet53") else None
-        insitu = None
-        if dom_shape is not None:
-            ms_l, n_l, kname = insitu_layer_times(ts, *dom_shape)
-            if ms_l:
-                fl = 2.0 * args.batch * dom_shape[3] ** 2 * dom_shape[1] * dom_shape[2] * dom_shape[0]
-                insitu = {"ms": ms_l, "n": n_l, "kernel": kname, "tflops": fl / ms_l / 1e9, "flops": fl,
-                          "shape": f"conv3x3 s1 {dom_shape[0]}->{dom_shape[1]} @{dom_shape[3]}x{dom_shape[3]} B={args.batch} "
-                                   f"(M={args.batch * dom_shape[3] ** 2} N={dom_shape[1]} K={dom_shape[2] * dom_shape[0]})"}
-        layers = [conv_roofline(args.batch, 128, 28, N.VT_BF16), conv_roofline(args.batch, 256, 14, N.VT_BF16),
-                  conv_roofline(args.batch, 512, 7, N.VT_BF16)]
-        standalone_name = None
-        conv_roofline(args.batch, 128, 28, N.VT_BF16, iters=1, warmup=0)
+        shapes = [(128, 128, 9, int(round(28 * scale)), 8), (256, 256, 9, int(round(14 * scale)), 8),
+                  (512, 512, 9, int(round(7 * scale)), 4)] if args.model in ("cspdarknet53", "darknet53") else []
+        layers, tot_fl, tot_ms, insitu = [], 0.0, 0.0, None
+        for (ci, co, nt, hw, cnt) in shapes:
+            fl = 2.0 * args.batch * hw * hw * co * nt * ci
+            row = {"layer": f"conv3x3 s1 {ci}->{co} @{hw}x{hw} B={args.batch} (M={args.batch * hw * hw} N={co} K={nt * ci})",
+                   "launches_per_step": cnt, "gflop": round(fl / 1e9, 2)}
+            for which in ("fwd", "dgrad", "wgrad"):
+                ms_l, n_l, kname = insitu_layer_times(ts, ci, co, nt, hw, reps=3, which=which)
+                if not ms_l:
+                    continue
+                row[which] = {"ms": round(ms_l, 4), "tflops": round(fl / ms_l / 1e9, 1),
+                              "frac": round(fl / ms_l / 1e9 / PEAK_BF16_TFLOPS, 4), "kernel": kname, "launches_timed": n_l}
+                tot_fl += cnt * fl
+                tot_ms += cnt * ms_l
+                if which == "fwd" and insitu is None:
+                    insitu = {"ms": ms_l, "n": n_l, "kernel": kname, "tflops": fl / ms_l / 1e9, "flops": fl, "shape": row["layer"]}
+            layers.append(row)
+        standalone = conv_roofline(args.batch, 128, 28, N.VT_BF16)
         standalone_name = N.last_kernel_name()
-        dom = insitu or {"ms": layers[0]["ms"], "n": 30, "kernel": standalone_name, "tflops": layers[0]["tflops"],
-                         "flops": layers[0]["flops"], "shape": layers[0]["shape"]}
+        dom = insitu or {"ms": standalone["ms"], "n": 30, "kernel": standalone_name, "tflops": standalone["tflops"],
+                         "flops": standalone["flops"], "shape": standalone["shape"]}
         traffic = None
         if world == 1 and not args.no_pmc:
             # (the rocprof rows are matched by the name the dispatcher reported for this layer, e.g. "span6_kernel")
@@ -454,6 +543,9 @@ def main():
         # HBM-bound layers of stages 0-2 (HBM fraction on the 1x1 and early-stage convs)
         hbm_layers = [conv_roofline(args.batch, 64, 112, N.VT_BF16, k=1), conv_roofline(args.batch, 128, 56, N.VT_BF16, k=1),
                       conv_roofline(args.batch, 8, 224, N.VT_BF16, k=3, Cout=32)]
+        cfg = ("BASELINE configs[1]" if (world == 1 and args.batch == 256) else
+               f"BASELINE configs[2] (data parallel over RCCL, {args.batch} images per GPU, global batch {args.batch * world})"
+               if world > 1 else f"single GPU, batch {args.batch}")
         out = {
             "metric": f"images/sec (node) {LABELS.get(args.model, args.model)} bf16 train step @{args.image_size}px",
             "value": round(value, 2),
@@ -468,12 +560,18 @@ def main():
             "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": f"{args.model} train step (fwd+CE+bwd+allreduce+SGD), batch {args.batch}/GPU, "
-                                   f"3x{args.image_size}x{args.image_size}, 1000 classes, BASELINE configs[1]",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                                   f"3x{args.image_size}x{args.image_size}, 1000 classes, {cfg}",
+                       "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": f"dp{world}",
+                       "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
+                       "backend": backend if world > 1 else None, "local_device": f"cuda:{local}",
+                       "gradient_exchange": args.exchange if world > 1 else None,
                        "hip_graphs": bool(args.graphs), "sync_bn": bool(args.sync_bn), "deterministic": bool(ts.deterministic),
                        "final_loss": round(loss, 4)},
             "roofline": {"bound": "mfma", "achieved": round(dom["tflops"], 1), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4),
+                         # MAC-weighted over the three dominant 3x3 shapes x {forward, data gradient, filter gradient}:
+                         # total FLOPs of those launches / their total in-situ time / peak -- not the best case
+                         "frac_fwd_dgrad_wgrad": round(tot_fl / tot_ms / 1e9 / PEAK_BF16_TFLOPS, 4) if tot_ms else None,
                          "traffic": traffic["bytes"] if traffic else None,
                          "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH x2 on gfx950) "
                                             "run by this bench on tools/bench_conv.py" if traffic else None),
@@ -481,8 +579,7 @@ def main():
                          "kernel": dom["kernel"], "launch_ms": round(dom["ms"], 4), "launches_timed": dom["n"],
                          "measured": "in situ (events around the layer's launches inside the step's forward list)"
                          if insitu else "standalone", "layer": dom["shape"]},
-            "roofline_layers": [{"layer": l["shape"], "ms": round(l["ms"], 4), "tflops": round(l["tflops"], 1),
-                                 "frac": round(l["tflops"] / PEAK_BF16_TFLOPS, 4)} for l in layers],
+            "roofline_layers": layers,
             "ms_per_step_p10_p50_p90": [round(float(v), 3) for v in
                                         _percentiles([marks[i].elapsed_ms(marks[i + 1]) for i in range(args.steps)])],
             "roofline_hbm_layers": [{"layer": l["shape"], "ms": round(l["ms"], 4), "gbs": round(l["gbs"], 1),
@@ -491,6 +588,16 @@ def main():
             "train_step_tflops": round(28.0e9 * (args.batch / 1.0) * world / (ms * 1e-3) / 1e12, 1)
             if args.model == "cspdarknet53" and args.image_size == 224 else None,
         }
+        if world == 1 and not args.no_secondary:
+            del ts
+            torch.cuda.empty_cache()
+            if args.batch != 128:
+                # the weak-scaling denominator of configs[2]: the same step at 128 images on this one GPU (and the
+                # place where host-issue limits would show: half the GPU time per step, the same 600 launches)
+                ms128, _ = time_train_step(args.model, 128, args.image_size, args.steps, args.warmup, dev)
+                out["n1_same_per_gpu_batch_ms"] = round(ms128, 3)
+                out["n1_same_per_gpu_batch_images_per_sec"] = round(128 / ms128 * 1e3, 1)
+            out["secondary"] = secondary_configs(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -145,6 +145,9 @@ int vt_bn_finalize(const float* stats, int32_t C, double count, const float* gam
                    const float* beta, float eps, float momentum, float* running_mean,
                    float* running_var, int64_t* num_batches_tracked, float* scale,
                    float* shift, float* mean, float* invstd, void* stream);
+/* Fold the VT_STAT_REPLICAS replicas of a statistics / sums buffer into replica 0 (exact integer adds) and zero the
+ * others: SyncBatchNorm then all-reduces 32*C bytes per layer instead of the whole buffer. */
+int vt_stat_fold(float* stats, int32_t C, void* stream);
 /* eval: coefficients from the running statistics. */
 int vt_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, int32_t C, float* scale,
@@ -205,7 +208,8 @@ int vt_stem_bn_bwd_combine(int32_t C, int32_t cin, const float* gzx, const float
  *   0 no;  2 yes;  1 yes, but the filter gradient does not fit the kernel's accumulators: vt_pw_bwd_apply then WRITES dz
  *   (pass `dz`) and the caller runs vt_conv_wgrad on it, `dw` must be NULL.
  * `coef` is float[4][N] = scale | shift | mean | invstd over all N = C[0] + C[1] channels (group 1 after group 0);
- * statistics / sums buffers and the vt_bn_bwd_finalize coefficients `bcoef` (float[3][C[g]]) are per group.
+ * statistics / sums buffers and the vt_bn_bwd_finalize coefficients `bcoef` (float[3][C[g]]) are per group;
+ * residual operands of vt_pw_fwd_apply: one for every group or none.
  * Arrays of per-group values have `ngroups` entries. */
 typedef struct vt_pw_desc {
     int32_t dtype; /* VT_BF16 */

@@ -150,3 +150,104 @@ def test_bench_launches_its_own_ranks_from_one_command():
     assert len(lines) == 1
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["allreduce_ok"] and rec["params_equal"] and rec["buckets"] >= 2
+
+
+def test_plan_buckets_head_bucket_and_alignment():
+    """the bucket that starts at 0 (BatchNorm / bias gradients, complete only when the stem's backward is)
+    is issued last and is the exposed tail of the step: it is exactly the requested head, and every boundary honours the
+    alignment the sharded exchange needs (64 * world)"""
+    for total, bucket, align, head in [(27_269_632, 4 << 20, 512, 65_536), (1 << 20, 1 << 16, 256, 40_000), (4096, 1024, 64, 100)]:
+        b = plan_buckets(total, bucket, align=align, head_elems=head)
+        s = sorted(b)
+        assert s[0][0] == 0 and s[-1][1] == total and all(x[1] == y[0] for x, y in zip(s, s[1:]))
+        assert b == sorted(b, reverse=True) and b[-1][0] == 0
+        assert all(v % align == 0 for pair in b for v in pair)
+        assert head <= b[-1][1] < head + align  # the head bucket: the requested size, rounded up to the alignment
+        assert all(e - s_ <= 2 * bucket for s_, e in b[:-1])
+    assert plan_buckets(64, 4096, head_elems=1000) == [(0, 64)]  # a head that swallows the buffer: one bucket
+
+
+def _cpu_sgd(ts):
+    """what the optimiser launch list does (vt_sgd_momentum: g' = g*grad_scale + wd*p; m = mu*m + g'; p -= lr*m;
+    mirror = bf16(p)), interpreted on CPU tensors"""
+    for k in range(ts.n_opt):
+        op = ts.opt_ops[k]
+        n, lr, mu, wd, gs = int(op.f[0]), *[torch.tensor(op.f[i], dtype=torch.float32) for i in (1, 2, 3, 4)]
+        lo = op.ptr[0].offset // 4
+        p, g, m = ts.store.pflat[lo:lo + n], ts.gflat[lo:lo + n], ts.mflat[lo:lo + n]
+        m.mul_(mu).add_(g * gs + wd * p)
+        p.sub_(lr * m)
+        ts.store.mirror[lo:lo + n].copy_(p)
+
+
+def _sharded_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    sys.path[:0] = [str(root / "vision-toolbox_amd"), str(root)]
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vision_toolbox import backbones
+        from vision_toolbox.trainer import TrainStep
+
+        steps = {}
+        for mode in ("allreduce", "sharded"):
+            torch.manual_seed(7)
+            ts = TrainStep(backbones.darknet_yolov5n(), 16, 2, 64, torch.bfloat16, device="cpu", plan_only=True,
+                           bucket_mb=0.5, exchange=mode, weight_decay=1e-3, lr=0.1)
+            ts.broadcast_parameters(0)
+            steps[mode] = ts
+        a, b = steps["allreduce"], steps["sharded"]
+        assert b.exchange == "sharded" and b.store.pflat.numel() % (64 * world) == 0
+        n = a.store.total
+        ok = torch.equal(a.store.pflat[:n], b.store.pflat[:n])
+        head = b.bucketer.buckets[b._head_bucket]
+        ok_head = head[0] == 0 and (head[1] - head[0]) * 4 <= (1 << 20) and b._head_bucket in [g_ for g_ in b.cut_buckets if g_][-1]
+        # the sharded optimiser touches exactly this rank's slices
+        touched = sorted((op.ptr[0].offset // 4, op.ptr[0].offset // 4 + int(op.f[0])) for op in (b.opt_ops[k] for k in range(b.n_opt)))
+        ok_own = all(any(s0 <= lo and hi <= s1 for s0, s1 in b.bucketer.shards) for lo, hi in touched) and \
+            sum(hi - lo for lo, hi in touched) <= sum(s1 - s0 for s0, s1 in b.bucketer.shards)
+        g = torch.Generator().manual_seed(1000 + rank)
+        for step in range(2):  # (two steps: the momentum of the first one takes part)
+            # integer-valued gradients (exact in f32 whatever the order of the ranks' contributions)
+            grad = torch.randint(-8, 9, (n,), generator=g).float()
+            for ts in (a, b):
+                ts.gflat.zero_()
+                ts.gflat[:n] = grad
+                ts.bucketer.reduce_all()
+                ts.bucketer.finish()
+                _cpu_sgd(ts)
+            b._gather_weights()
+            # what the kernels read next step is identical on both paths, bit for bit: bf16 weights everywhere, f32
+            # BatchNorm / bias parameters (head bucket)
+            ok &= torch.equal(a.store.mirror[:n].view(torch.int16), b.store.mirror[:n].view(torch.int16))
+            ok &= torch.equal(a.store.pflat[:head[1]], b.store.pflat[:head[1]])
+            for s0, s1 in b.bucketer.shards:  # the owner's f32 master values and momentum
+                s1 = min(s1, n)
+                ok &= torch.equal(a.store.pflat[s0:s1], b.store.pflat[s0:s1]) and torch.equal(a.mflat[s0:s1], b.mflat[s0:s1])
+        b.gather_master()
+        ok &= torch.equal(a.store.pflat[:n], b.store.pflat[:n]) and torch.equal(a.mflat[:n], b.mflat[:n])
+        q.put((rank, bool(ok), bool(ok_head), bool(ok_own)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_exchange_equals_the_allreduce_path_bit_for_bit(world):
+    """reduce-scatter -> sharded SGD -> bf16 all-gather (TrainStep(exchange="sharded")) against the f32
+    all-reduce path on the same gradients: the weights the next step reads are bit-identical on every rank"""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=400) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in results) == list(range(world))
+    for r in results:
+        assert all(r[1:]), r

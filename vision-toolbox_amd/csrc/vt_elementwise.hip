@@ -89,6 +89,19 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int C, doubl
     }
 }
 
+// replicas 1.. of int64[R][n] are added into replica 0 and zeroed (n = 2 * C * 2 limbs)
+__global__ void stat_fold_kernel(long long* __restrict__ q, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    long long acc = q[i];
+#pragma unroll 4
+    for (int r = 1; r < kStatReplicas; ++r) {
+        acc += q[(long)r * n + i];
+        q[(long)r * n + i] = 0;
+    }
+    q[i] = acc;
+}
+
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
                                       float eps, int C, float* scale, float* shift, float* mean, float* invstd) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -994,6 +1007,14 @@ int vt_bn_finalize(const float* stats, int32_t C, double count, const float* gam
                        1.0 / count, unbias, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked,
                        scale, shift, mean, invstd);
     VT_CHECK_LAUNCH("vt_bn_finalize");
+    return VT_OK;
+}
+
+int vt_stat_fold(float* stats, int32_t C, void* stream) {
+    VT_REQUIRE(stats && C > 0, VT_ERR_INVALID, "vt_stat_fold: bad argument");
+    const int n = 4 * C;
+    hipLaunchKernelGGL(stat_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (long long*)stats, n);
+    VT_CHECK_LAUNCH("vt_stat_fold");
     return VT_OK;
 }
 

@@ -53,6 +53,15 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 
 enum { PW_STATS = 0, PW_APPLY = 1, PW_REDUCE = 2, PW_BWD = 3 };
 
+// units prefetched ahead of the one being computed: as many as the registers take without costing a wave per SIMD
+constexpr int pw_depth(int N, int K, int mode) {
+#ifdef VT_PW_DEPTH
+    return VT_PW_DEPTH;
+#else
+    return 1;  // (deeper rings measured equal or slower: they cost a wave per SIMD)
+#endif
+}
+
 struct PwArgs {
     const bf16_t* x;
     int ldx;
@@ -95,18 +104,24 @@ struct PwGeom {
     static constexpr int COEF_OFF = W_BYTES;          // float [5][N]
     static constexpr int RED_OFF = COEF_OFF + 5 * N * 4;
     static constexpr bool kFull = N * K <= 4096;      // dW accumulated in registers inside the backward kernel
-    static constexpr bool kRegW = N * K <= 2048;      // W fragments held in registers (else re-read from LDS per tile)
+#ifndef VT_PW_REGW
+#define VT_PW_REGW 2048
+#endif
+    static constexpr bool kRegW = N * K <= VT_PW_REGW;  // W fragments held in registers (else re-read from LDS per tile)
     // scratch after the coefficients: statistics fold float [4 waves][2][N]; dW fold float [N][K]
     static constexpr int RED_BYTES = (kFull ? N * K * 4 : 0) > 4 * 2 * N * 4 ? N * K * 4 : 4 * 2 * N * 4;
     static constexpr int SMEM = RED_OFF + RED_BYTES;
 };
 
 // one workgroup = 4 independent waves; see the header for the lane mapping
-template <int N, int K, int MODE>
+// EX: the optional operand is present (APPLY: a residual for EVERY group; BWD: the addend of dx) -- compile time, so
+// that the loads of a unit are unconditional and the compiler can count them (s_waitcnt vmcnt(N) instead of 0)
+template <int N, int K, int MODE, bool EX>
 __global__ void __launch_bounds__(256) pw_kernel(const PwArgs a) {
     using G = PwGeom<N, K>;
     constexpr int NT = G::NT, NU = G::NU, KS = G::KS, CT = G::CT, KV = G::KV, PITCH = G::PITCH;
     constexpr bool kDW = (MODE == PW_BWD) && G::kFull;
+    constexpr int kDepth = pw_depth(N, K, MODE);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sW = smem;
     float* sCoef = (float*)(smem + G::COEF_OFF);
@@ -211,41 +226,34 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwArgs a) {
         uint4 dy[(MODE >= PW_REDUCE) ? NU : 1];
         uint4 ex[(MODE == PW_APPLY) ? NU : (MODE == PW_BWD ? KV : 1)];
     };
-    const bool has_res0 = MODE == PW_APPLY && a.res[0] != nullptr;
-    const bool has_res1 = MODE == PW_APPLY && a.res[1] != nullptr;
-    const bool has_add = MODE == PW_BWD && a.add != nullptr;
     auto group_of = [&](int u) -> int { return 32 * u >= N0; };
 
+    // (nothing here may READ a loaded register: a select on `ok` right behind the load made the compiler wait for the
+    // prefetch it had just issued -- vmcnt(0) at the head of every unit.  A pixel past the end loads the last pixel's
+    // rows; its contributions are masked where they are used.)
     auto load_unit = [&](Regs& r, int unit) {
         const long p = (long)unit * 16 + pl;
-        const bool ok = p < a.M;
-        const long pc = ok ? p : a.M - 1;
+        const long pc = p < a.M ? p : a.M - 1;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            r.x[s] = ldg16(a.x + pc * a.ldx + 32 * s + 8 * q);
-            if (!ok) r.x[s] = make_uint4(0, 0, 0, 0);
-        }
+        for (int s = 0; s < KS; ++s) r.x[s] = ldg16(a.x + pc * a.ldx + 32 * s + 8 * q);
         if constexpr (MODE >= PW_REDUCE) {
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const int g = group_of(u);
                 r.dy[u] = ldg16(a.dy[g] + pc * a.ldy[g] + (32 * u - (g ? N0 : 0)) + 8 * q);
-                if (!ok) r.dy[u] = make_uint4(0, 0, 0, 0);
             }
         }
         if constexpr (MODE == PW_APPLY) {
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const int g = group_of(u);
-                r.ex[u] = make_uint4(0, 0, 0, 0);
-                if (g ? has_res1 : has_res0) r.ex[u] = ldg16(a.res[g] + pc * a.ldr[g] + (32 * u - (g ? N0 : 0)) + 8 * q);
+                if constexpr (EX) r.ex[u] = ldg16(a.res[g] + pc * a.ldr[g] + (32 * u - (g ? N0 : 0)) + 8 * q);
             }
         }
         if constexpr (MODE == PW_BWD) {
+            if constexpr (EX) {
 #pragma unroll
-            for (int v = 0; v < KV; ++v) {
-                r.ex[v] = make_uint4(0, 0, 0, 0);
-                if (has_add) r.ex[v] = ldg16(a.add + pc * a.ldadd + 32 * v + 8 * q);
+                for (int v = 0; v < KV; ++v) r.ex[v] = ldg16(a.add + pc * a.ldadd + 32 * v + 8 * q);
             }
         }
     };
@@ -277,8 +285,9 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwArgs a) {
             if constexpr (MODE == PW_STATS) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    s1[u][e] += z[e];
-                    s2[u][e] = fmaf(z[e], z[e], s2[u][e]);
+                    const float zz = ok ? z[e] : 0.f;
+                    s1[u][e] += zz;
+                    s2[u][e] = fmaf(zz, zz, s2[u][e]);
                 }
             } else {
                 float sc[8], sf[8];
@@ -287,21 +296,23 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwArgs a) {
                 *(f32x4*)&sf[0] = *(const f32x4*)(sCoef + N + cb);
                 *(f32x4*)&sf[4] = *(const f32x4*)(sCoef + N + cb + 4);
                 if constexpr (MODE == PW_APPLY) {
+                    const int g = group_of(u);
                     float v[8], rr[8];
-                    VecIO<bf16_t>::unpack(r.ex[u], rr);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rr[e] = 0.f;
+                    if constexpr (EX) VecIO<bf16_t>::unpack(r.ex[u], rr);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         v[e] = fmaf(z[e], sc[e], sf[e]);
                         v[e] = a.relu ? fmaxf(v[e], 0.f) : v[e];
                         v[e] += rr[e];
                     }
-                    const int g = group_of(u);
                     if (ok) *(uint4*)(a.y[g] + p * a.ldy[g] + (32 * u - (g ? N0 : 0)) + 8 * q) = VecIO<bf16_t>::pack(v);
                 } else {
                     float gy[8];
                     VecIO<bf16_t>::unpack(r.dy[u], gy);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) gy[e] = (!a.relu || fmaf(z[e], sc[e], sf[e]) > 0.f) ? gy[e] : 0.f;
+                    for (int e = 0; e < 8; ++e) gy[e] = (ok && (!a.relu || fmaf(z[e], sc[e], sf[e]) > 0.f)) ? gy[e] : 0.f;
                     if constexpr (MODE == PW_REDUCE) {
                         float mu[8];
                         *(f32x4*)&mu[0] = *(const f32x4*)(sCoef + 2 * N + cb);
@@ -349,7 +360,9 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwArgs a) {
                     }
                 }
                 float o[8], ad[8];
-                VecIO<bf16_t>::unpack(r.ex[v], ad);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ad[e] = 0.f;
+                if constexpr (EX) VecIO<bf16_t>::unpack(r.ex[v], ad);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = xa[e >> 2][e & 3] + ad[e];
                 if (ok) *(uint4*)(a.dx + p * a.lddx + 32 * v + 8 * q) = VecIO<bf16_t>::pack(o);
@@ -381,17 +394,28 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwArgs a) {
         }
     };
 
-    // ---- the wave's units, one prefetched ahead ------------------------------------------------------------------
+    // ---- the wave's units, kDepth of them prefetched ahead ------------------------------------------------------------
+    // Every load of the steady-state loop is unconditional (a prefetch past the wave's last unit re-loads that unit), so
+    // the compiler waits with a counted vmcnt for exactly the unit it is about to use.
     const int stride = (int)gridDim.x * 4;
-    int unit = (int)blockIdx.x * 4 + wave;
-    Regs cur, nxt;
-    if (unit < a.nunits) load_unit(cur, unit);
-    while (unit < a.nunits) {
-        const int un = unit + stride;
-        if (un < a.nunits) load_unit(nxt, un);
-        compute_unit(cur, unit);
-        cur = nxt;
-        unit = un;
+    const int first = (int)blockIdx.x * 4 + wave;
+    const int T = first < a.nunits ? (a.nunits - first + stride - 1) / stride : 0;  // units of this wave
+    if (T > 0) {
+        auto unit_of = [&](int i) { return first + (i < T ? i : T - 1) * stride; };
+        Regs ring[kDepth + 1];
+#pragma unroll
+        for (int j = 0; j < kDepth; ++j) load_unit(ring[j], unit_of(j));
+        int i = 0;
+        for (; i + kDepth + 1 <= T; i += kDepth + 1) {
+#pragma unroll
+            for (int j = 0; j <= kDepth; ++j) {
+                load_unit(ring[(j + kDepth) % (kDepth + 1)], unit_of(i + j + kDepth));
+                compute_unit(ring[j], first + (i + j) * stride);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kDepth; ++j)  // the last T - i < kDepth + 1 units are already in ring[0 ..]
+            if (i + j < T) compute_unit(ring[j], first + (i + j) * stride);
     }
 
     // ---- per-channel sums: lanes -> wave (shuffles) -> workgroup (LDS, fixed order) -> fixed-point atomics -------
@@ -446,18 +470,20 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwArgs a) {
     }
 }
 
-template <int N, int K, int MODE>
+template <int N, int K, int MODE, bool EX>
 int launch_pw(const PwArgs& a, hipStream_t st, const char* who) {
     using G = PwGeom<N, K>;
-    auto kern = pw_kernel<N, K, MODE>;
+    auto kern = pw_kernel<N, K, MODE, EX>;
     constexpr int smem = G::SMEM;
     static_assert(smem <= 160 * 1024, "weights exceed the LDS of a CU");
     if (smem > 64 * 1024) {
         const int rc = vt_raise_dynamic_lds((const void*)kern, smem, who);
         if (rc != VT_OK) return rc;
     }
+    // every workgroup stages its own copy of W (up to 33 KiB): small tensors get fewer, longer workgroups
     const int target = VT_KNOB("VT_PW_BLOCKS", 1024);
-    long blocks = ((long)a.nunits + 3) / 4;
+    const int per_wave = VT_KNOB("VT_PW_UNITS_PER_WAVE", 8);
+    long blocks = ((long)a.nunits + 4 * per_wave - 1) / (4 * per_wave);
     if (blocks > target) blocks = target;
     if (blocks < 1) blocks = 1;
     vt_note_kernel("pw_kernel<%d,%d,%s>", N, K, MODE == PW_STATS ? "stats" : MODE == PW_APPLY ? "apply" : MODE == PW_REDUCE ? "reduce" : "bwd");
@@ -468,8 +494,14 @@ int launch_pw(const PwArgs& a, hipStream_t st, const char* who) {
 
 template <int MODE>
 int dispatch_pw(int N, int K, const PwArgs& a, hipStream_t st, const char* who) {
-#define VT_PW_CASE(n, k) \
-    if (N == n && K == k) return launch_pw<n, k, MODE>(a, st, who);
+    const bool ex = MODE == PW_APPLY ? a.res[0] != nullptr : (MODE == PW_BWD ? a.add != nullptr : false);
+#define VT_PW_CASE(n, k)                                                           \
+    if (N == n && K == k) {                                                        \
+        if constexpr (MODE == PW_APPLY || MODE == PW_BWD) {                        \
+            if (ex) return launch_pw<n, k, MODE, true>(a, st, who);                \
+        }                                                                          \
+        return launch_pw<n, k, MODE, false>(a, st, who);                           \
+    }
     VT_PW_CASE(32, 32)
     VT_PW_CASE(64, 64)
     VT_PW_CASE(32, 64)
@@ -548,7 +580,9 @@ int vt_pw_fwd_apply(const vt_pw_desc* d, const float* coef, void* const* y, cons
     if (rc != VT_OK) return rc;
     VT_REQUIRE(coef && y && ldy, VT_ERR_INVALID, "vt_pw_fwd_apply: null argument");
     a.coef = coef;
+    const bool any_res = res && (res[0] || (d->ngroups == 2 && res[1]));
     for (int g = 0; g < d->ngroups; ++g) {
+        VT_REQUIRE(!any_res || res[g], VT_ERR_UNSUPPORTED, "vt_pw_fwd_apply: a residual for every group or for none");
         if ((rc = check_rows("vt_pw_fwd_apply", "y", g, y[g], ldy[g], d->C[g], false)) != VT_OK) return rc;
         a.y[g] = (bf16_t*)y[g];
         a.ldy[g] = ldy[g];

@@ -97,6 +97,7 @@ class ParamStore:
         self.order_key = order_key  # optional grouping of the flat layout (stable sort key per parameter)
         self.device = None
         self.pflat = self.sflat = self.nflat = self.mirror = None
+        self.pad_multiple = 64  # the flat parameter buffer's length is a multiple of this (sharded exchange: 64 * world)
         self.index: dict[int, tuple[int, int, int]] = {}  # id(tensor owner) -> (base, elem offset, numel)
         self.params: list[nn.Parameter] = []
         self._ptrs: list[tuple[torch.Tensor, int]] = []
@@ -139,7 +140,8 @@ class ParamStore:
         for p in params:
             offs.append(total)
             total += _round_up(p.numel(), 64)
-        pflat = torch.zeros(max(total, 64), dtype=torch.float32, device=device)
+        self.total = total  # elements that belong to parameters (the rest of pflat is padding)
+        pflat = torch.zeros(_round_up(max(total, 64), self.pad_multiple), dtype=torch.float32, device=device)
         soffs, stotal = [], 0
         for _, _, b in fbufs:
             soffs.append(stotal)
@@ -257,6 +259,10 @@ class Builder:
         # 1x1 ConvNormAct units as four streaming passes that recompute z = W x instead of storing z and dz
         # (vt_pointwise.hip); off in deterministic mode (its filter gradient leaves through float atomics)
         self.pointwise = os.environ.get("VT_POINTWISE", "1") != "0" and not self.deterministic
+        # ... where the unit's input is at least this many MB: smaller tensors stay in the memory-side cache between the
+        # passes of the unfused path, which is then as fast (measured at batch 256, CSPDarknet-53: 22.40 ms with the 51 MB
+        # tensors of stage 2 included, 22.11 without; 23.32 with the pointwise path off)
+        self.pointwise_min_mb = float(os.environ.get("VT_PW_MIN_MB", "80"))
         self._hoisted: list[N.Op] = []
         # SyncBatchNorm (configs/base.yaml:22): the trainer all-reduces every layer's statistics
         # between the kernel that accumulates them and the finalize kernel; the finalize kernels
@@ -709,13 +715,15 @@ class Builder:
             if conv.in_channels != x.C or getattr(x, "logical_C", x.C) != x.C:
                 return 0
             flags.add((bool(norm.training), bool(relu)))
-        if len(flags) != 1:
+        if len(flags) != 1 or len({sp[3] is None for sp in specs}) != 1:  # (a residual for every group or for none)
             return 0
         unit_training, _ = next(iter(flags))
         if not unit_training and not self.need_grad:
             return 0  # inference: one conv launch with the affine + ReLU epilogue is already a single pass
         if self.need_grad and not x.needs_grad:
             return 0  # (the backward kernel always forms dx)
+        if x.M * x.C * 2 < self.pointwise_min_mb * 1e6:
+            return 0
         cs = [sp[0].out_channels for sp in specs] + [0]
         return int(N.lib().vt_pw_supported(self.dtype, x.C, cs[0], cs[1]))
 

@@ -30,7 +30,7 @@ from torch import nn
 
 from . import _native as N
 from . import engine as E
-from .distributed import GradBucketer, plan_buckets
+from .distributed import GradBucketer, ShardedExchange, plan_buckets
 from .program import Program, current_stream_handle
 
 _NORMS = (nn.modules.batchnorm._BatchNorm, nn.modules.instancenorm._InstanceNorm, nn.LayerNorm, nn.GroupNorm)
@@ -133,6 +133,8 @@ class TrainStep:
         mix: bool = False,
         freeze_bn: bool = False,
         deterministic: Optional[bool] = None,
+        exchange: str = "allreduce",
+        head_bucket_kb: float = 256.0,
     ):
         N.lib()
         self.device = torch.device(device if device is not None else "cuda")
@@ -161,6 +163,13 @@ class TrainStep:
 
         groups = param_groups(self.model)
         self.store = st = E.ParamStore(self.model, order_key=lambda p: groups[id(p)])
+        # gradient exchange: "allreduce" = one f32 all-reduce per bucket, every rank runs the whole optimiser;
+        # "sharded" = reduce-scatter -> SGD on the rank's slice of every bucket -> all-gather of the bf16 weights
+        if exchange not in ("allreduce", "sharded"):
+            raise ValueError(exchange)
+        self.exchange = exchange if self.dp else "allreduce"
+        self._align = 64 * self.world if self.exchange == "sharded" else 64
+        st.pad_multiple = self._align
         with self._dev_ctx():
             st.ensure(self.device)
             self.gflat = torch.zeros_like(st.pflat)
@@ -171,7 +180,7 @@ class TrainStep:
             self.images = torch.zeros(batch_size, 3, image_size, image_size, device=self.device)
             self.labels = torch.zeros(batch_size, dtype=torch.int64, device=self.device)
         self.lr = lr
-        total = st.pflat.numel()
+        total = st.pflat.numel()  # (padded to the exchange's alignment; parameters end at st.total)
 
         # ---- forward + loss + backward launch lists ---------------------------------------
         # deterministic=True (default: the VT_DETERMINISTIC environment variable): order-free filter gradients and bias
@@ -208,13 +217,8 @@ class TrainStep:
                 end = st.offsets[i] + E._round_up(p.numel(), 64)
                 self.segments.append((start, end, wd_of[gids[i]]))
                 start = end
-        ob = E.Builder(st, self.dtype, True, True, grad_base=E.GRADS)
-        for s0, s1, wd in self.segments:
-            ob.emit(N.OP_SGD,
-                    [(E.PARAMS, s0 * 4), (E.GRADS, s0 * 4), (E.MOMENTUM, s0 * 4),
-                     (E.MIRROR, s0 * 2) if self.dtype == N.VT_BF16 else None, (E.HYPER, 0)],
-                    [N.VT_BF16], [s1 - s0, lr, momentum, wd, 1.0 / self.world])
-        self.opt_ops, self.n_opt = E.ops_array(ob.fwd), len(ob.fwd)
+        self._momentum, self._lr0 = momentum, lr
+        self._emit_opt([(0, total)])
         zb = E.Builder(st, self.dtype, True, True)
         zb.emit(N.OP_MEMSET, [(E.GRADS, 0)], [0], [total * 4])
         self.zero_ops = E.ops_array(zb.fwd)
@@ -224,8 +228,19 @@ class TrainStep:
         self.bwd_cuts = [self.prog.n_bwd]  # op index after which each segment ends
         self.cut_buckets: list[list[int]] = [[]]
         if self.dp:
-            buckets = plan_buckets(total, int(bucket_mb * (1 << 20)) // 4)
-            self.bucketer = GradBucketer(self.gflat, buckets, self.pg)
+            # the bucket that starts at 0 (BatchNorm / bias gradients + the stem-side filters) completes last: keep it
+            # small, so that the exposed tail of the step is one latency-bound transfer (< 1 MiB)
+            nb_end = next((o for o, g_ in zip(st.offsets, gids) if g_ == GROUP_OTHER), total)  # end of the norm | bias region
+            head = max(int(head_bucket_kb * 1024) // 4, nb_end)
+            buckets = plan_buckets(total, int(bucket_mb * (1 << 20)) // 4, align=self._align, head_elems=head)
+            if self.exchange == "sharded":
+                self.bucketer = ShardedExchange(self.gflat, buckets, self.pg)
+                self._head_bucket = next((i for i, (b0, _) in enumerate(buckets) if b0 == 0), None)
+                assert self._head_bucket is not None and buckets[self._head_bucket][1] >= nb_end, \
+                    "the f32-read parameters (BatchNorm, biases) must sit in the head bucket"
+                self._emit_opt(self.bucketer.shards)  # the optimiser touches this rank's slices only
+            else:
+                self.bucketer = GradBucketer(self.gflat, buckets, self.pg)
             ready = [0] * len(buckets)  # last bwd op that writes into each bucket
             # an op names the START of the gradient it writes; the gradient extends over the whole
             # parameter, which may straddle a bucket boundary -- every bucket the parameter
@@ -261,6 +276,39 @@ class TrainStep:
         self._graphs = None
         self.steps_done = 0
 
+    def _emit_opt(self, ranges):
+        """optimiser launch list: one SGD launch per (element range, weight-decay segment) overlap"""
+        ob = E.Builder(self.store, self.dtype, True, True, grad_base=E.GRADS)
+        for r0, r1 in ranges:
+            for s0, s1, wd in self.segments:
+                lo, hi = max(r0, s0), min(r1, s1)
+                if hi > lo:
+                    ob.emit(N.OP_SGD,
+                            [(E.PARAMS, lo * 4), (E.GRADS, lo * 4), (E.MOMENTUM, lo * 4),
+                             (E.MIRROR, lo * 2) if self.dtype == N.VT_BF16 else None, (E.HYPER, 0)],
+                            [N.VT_BF16], [hi - lo, self._lr0, self._momentum, wd, 1.0 / self.world])
+        self.opt_ops, self.n_opt = E.ops_array(ob.fwd), len(ob.fwd)
+
+    def _gather_weights(self) -> None:
+        """sharded exchange: bring the updated weights of the other ranks' slices in -- the bf16 mirror the kernels
+        read; f32 for the head bucket (BatchNorm / bias parameters are read in f32), whose mirror is re-cast here"""
+        st, ex = self.store, self.bucketer
+        if self.dtype == N.VT_BF16:
+            rest = [i for i in range(len(ex.buckets)) if i != self._head_bucket]
+            ex.gather(st.mirror, rest)
+            ex.gather(st.pflat, [self._head_bucket])
+            h0, h1 = ex.buckets[self._head_bucket]
+            st.mirror[h0:h1].copy_(st.pflat[h0:h1])
+        else:
+            ex.gather(st.pflat)
+
+    def gather_master(self) -> None:
+        """sharded exchange: refresh the f32 master parameters and the momentum of the slices other ranks own (before a
+        checkpoint / state_dict); a no-op for the all-reduce exchange"""
+        if self.exchange == "sharded":
+            self.bucketer.gather(self.store.pflat)
+            self.bucketer.gather(self.mflat)
+
     @staticmethod
     def _sync_points(ops, n, kind):
         """[(op index of the finalize kernel, base id, byte offset, bytes of its [replicas][2][C] sums)]"""
@@ -272,9 +320,19 @@ class TrainStep:
         return pts
 
     def _sync_view(self, base, off, nbytes):
+        """the statistics of one BatchNorm as the all-reduce sees them: replica 0 of int64[replicas][2][C][2]"""
         start = {E.ZERO_F: self.prog.zf_off, E.ZERO_B: self.prog.zb_off}[base] + off
         # the sums are 64-bit fixed point (vt_amd.h, VT_STAT_REPLICAS): an integer all-reduce, exact and order-free
-        return self.arena[start : start + nbytes].view(torch.int64)
+        return self.arena[start : start + nbytes // N.VT_STAT_REPLICAS].view(torch.int64)
+
+    def _sync_stats(self, base, off, nbytes, stream):
+        """SyncBatchNorm exchange of one layer's sums: the 32 replicas the kernels spread their atomics
+        over are folded into replica 0 on the device first (vt_stat_fold), so the collective carries 32 C bytes --
+        the algorithmic payload -- instead of the raw 1 KiB x C buffer"""
+        start = {E.ZERO_F: self.prog.zf_off, E.ZERO_B: self.prog.zb_off}[base] + off
+        C_ = nbytes // (N.VT_STAT_REPLICAS * 32)
+        N.check(N.lib().vt_stat_fold(ctypes.c_void_p(self.arena.data_ptr() + start), C_, ctypes.c_void_p(stream)))
+        torch.distributed.all_reduce(self._sync_view(base, off, nbytes), group=self.pg)
 
     def _run_list(self, ops, n, sync, cuts, cut_buckets, s, side, keep_side_open=True):
         """run a launch list in segments: a segment ends before every finalize kernel whose statistics
@@ -295,7 +353,7 @@ class TrainStep:
                 sub = (N.Op * (hi - lo)).from_address(ctypes.addressof(ops) + lo * ctypes.sizeof(N.Op))
                 N.run_ops(sub, hi - lo, self.bases, s, side=side, leave_side_open=keep_side_open and hi != n)
             if hi in marks:  # stream-ordered: NCCL makes the launch stream wait, no host sync
-                torch.distributed.all_reduce(self._sync_view(*marks[hi][1]), group=self.pg)
+                self._sync_stats(*marks[hi][1], s)
             if hi in cut_buckets and cut_buckets[hi]:
                 if side and self._side is not None:
                     N.stream_wait(side, s)
@@ -398,6 +456,8 @@ class TrainStep:
                 self._graphs["opt"].launch(s)
             else:
                 N.run_ops(self.opt_ops, self.n_opt, self.bases, s)
+            if self.exchange == "sharded":
+                self._gather_weights()
         self.steps_done += 1
 
     def loss(self) -> float:
