@@ -347,3 +347,109 @@ def test_config5_yolov5x_feature_maps_batch64_at_640(golden_dir):
                 nrm = float(gm[f"darknet_yolov5x.cfg5.map{i}.img{img}.summary"][2])
                 assert mp[b].double().norm().item() == pytest.approx(nrm, rel=tol)
         del maps
+
+
+# ---- whole BLOCKS at batch 256 with train-mode BatchNorm in bf16: residual and concat gradient routing ---------------
+# A CSPDarknetStage(2, 64, 128) (stride-2 conv, the conv1 | conv2 pair as one two-group pointwise launch, two residual
+# blocks, concat elision, out_conv: reference backbones/darknet.py:39-55) and an OSABlock(128, 128, 5, 256) (five chained
+# 3x3 units whose outputs and the input are concatenated, reference backbones/vovnet.py:31-63) at 256 x 56 x 56 output
+# pixels: 802,816 samples per channel, where train-mode BatchNorm is well conditioned -- unlike the toy sizes of the
+# module tests, whose bounds must absorb a ~100x amplification of rounding noise.  The reference is float64 torch autograd
+# on the CPU over the reference's own wiring, with every tensor the bf16 path STORES rounded at that point (each unit's z
+# and output, each residual sum, each gradient handed from one unit to the next): what is left is one bf16 rounding of the
+# compared quantity plus summation order.  A sign or scale slip in a gradient routed through a residual add or a concat
+# slice would show at O(1); every output and EVERY parameter gradient is bounded at 4e-3.
+def _st(t, round_grad=True):
+    return _StoreBf16.apply(t, round_grad)
+
+
+def _ref_unit(x, p, k, s, residual=None):
+    """ConvNormAct (components.py:26-44) in float64 with the bf16 path's storage points: z, then the unit's output
+    (after the residual add, which the normalise pass folds in before its single rounding)"""
+    w, g, b = p
+    z = _st(F.conv2d(x, w, None, s, (k - s + 1) // 2 if k > 1 else 0))
+    y = torch.relu(F.batch_norm(z, None, None, g, b, True, 0.1, 1e-5))
+    return _st(y + residual if residual is not None else y)
+
+
+def _module_units(m):
+    from vision_toolbox.components import ConvNormAct
+
+    return [(n, u) for n, u in m.named_modules() if isinstance(u, ConvNormAct)]
+
+
+def _block_case(m, x, ref_forward):
+    """run module m (GPU, bf16, train mode) and the float64 storage-emulating reference on x with a random upstream
+    gradient; return relative L2 errors of the output, the input gradient and every parameter gradient"""
+    torch.manual_seed(3)
+    units = _module_units(m)
+    with torch.no_grad():
+        for _, u in units:
+            u.conv.weight.copy_(u.conv.weight.to(torch.bfloat16).float())
+            u.norm.weight.uniform_(0.5, 1.5)
+            u.norm.bias.uniform_(-0.3, 0.3)
+    params = {n: tuple(t.detach().double().requires_grad_(True) for t in (u.conv.weight, u.norm.weight, u.norm.bias))
+              for n, u in units}
+    xr = x.double().requires_grad_(True)
+    torch.set_num_threads(max(1, min(64, (torch.get_num_threads() or 1) * 4)))
+    yr = ref_forward(_st(xr), params)
+    gen = torch.Generator().manual_seed(4)
+    gy = (torch.randn(yr.shape, generator=gen) + 0.25).to(torch.bfloat16).float()
+    yr.backward(gy.double())
+
+    m = m.cuda().train()
+    m.compute_dtype = torch.bfloat16
+    xg = x.cuda().requires_grad_(True)
+    before = N.launch_count()
+    y = m(xg)
+    y.backward(gy.cuda().to(y.dtype))
+    torch.cuda.synchronize()
+    assert N.launch_count() > before
+
+    def rel(a, b):
+        return ((a.double().cpu() - b.double()).norm() / b.double().norm()).item()
+
+    errs = {"y": rel(y.detach().float(), yr.detach()), "dx": rel(xg.grad, xr.grad)}
+    for n, u in units:
+        w, g, b = params[n]
+        errs[n + ".dw"] = rel(u.conv.weight.grad, w.grad)
+        errs[n + ".dgamma"] = rel(u.norm.weight.grad, g.grad)
+        errs[n + ".dbeta"] = rel(u.norm.bias.grad, b.grad)
+    return errs
+
+
+def test_csp_stage_bf16_train_mode_gradients_at_batch_256_are_tight():
+    from vision_toolbox.backbones.darknet import CSPDarknetStage
+
+    torch.manual_seed(11)
+    m = CSPDarknetStage(2, 64, 128)
+    x = torch.randn(B, 64, 112, 112, generator=torch.Generator().manual_seed(12)).to(torch.bfloat16).float()
+
+    def ref(x, p):  # darknet.py:51-55
+        o = _ref_unit(x, p["conv"], 3, 2)
+        a = _ref_unit(o, p["conv1"], 1, 1)
+        t = _ref_unit(o, p["conv2"], 1, 1)
+        for i in range(2):  # DarknetBlock (darknet.py:27-28): x + conv2(conv1(x)), added after the ReLU
+            h = _ref_unit(t, p[f"blocks.{i}.conv1"], 1, 1)
+            t = _ref_unit(h, p[f"blocks.{i}.conv2"], 3, 1, residual=t)
+        return _ref_unit(torch.cat([a, t], 1), p["out_conv"], 1, 1)
+
+    errs = _block_case(m, x, ref)
+    assert max(errs.values()) < 4e-3, sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+
+
+def test_osa_block_bf16_train_mode_gradients_at_batch_256_are_tight():
+    from vision_toolbox.backbones.vovnet import OSABlock
+
+    torch.manual_seed(21)
+    m = OSABlock(128, 128, 5, 256, ese=False)
+    x = torch.randn(B, 128, 56, 56, generator=torch.Generator().manual_seed(22)).to(torch.bfloat16).float()
+
+    def ref(x, p):  # vovnet.py:50-63
+        feats = [x]
+        for i in range(5):
+            feats.append(_ref_unit(feats[-1], p[f"convs.{i}"], 3, 1))
+        return _ref_unit(torch.cat(feats, 1), p["out_conv"], 1, 1)
+
+    errs = _block_case(m, x, ref)
+    assert max(errs.values()) < 4e-3, sorted(errs.items(), key=lambda kv: -kv[1])[:6]

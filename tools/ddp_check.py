@@ -98,7 +98,11 @@ def main():
             d_got, d_ref = got[k].cpu() - init[k], sd[k].detach() - init[k]
             err = ((d_got - d_ref).norm() / d_ref.norm()).item()
             worst = max(worst, err)
-            assert d_ref.norm() > 0 and err < (0.25 if deep else 0.1), (k, err)
+            print(f"  update of {k}: rel err {err:.3e}", flush=True)
+            # the head (linear layer) sees one backward op: tight.  The deep conv weight sits behind train-mode BatchNorm over
+            # 2 x 2 maps at this toy size (rounding noise amplified ~100x per direction): looser
+            bound = (0.03 if k.startswith("3.") else 0.25) if deep else 0.1
+            assert d_ref.norm() > 0 and err < bound, (k, err, bound)
         if sync_bn:
             rv = [k for k in got if k.endswith("running_var")]
             for k in (rv[0], rv[-1]):
