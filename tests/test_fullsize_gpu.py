@@ -354,22 +354,37 @@ def test_config5_yolov5x_feature_maps_batch64_at_640(golden_dir):
 # blocks, concat elision, out_conv: reference backbones/darknet.py:39-55) and an OSABlock(128, 128, 5, 256) (five chained
 # 3x3 units whose outputs and the input are concatenated, reference backbones/vovnet.py:31-63) at 256 x 56 x 56 output
 # pixels: 802,816 samples per channel, where train-mode BatchNorm is well conditioned -- unlike the toy sizes of the
-# module tests, whose bounds must absorb a ~100x amplification of rounding noise.  The reference is float64 torch autograd
-# on the CPU over the reference's own wiring, with every tensor the bf16 path STORES rounded at that point (each unit's z
-# and output, each residual sum, each gradient handed from one unit to the next): what is left is one bf16 rounding of the
-# compared quantity plus summation order.  A sign or scale slip in a gradient routed through a residual add or a concat
-# slice would show at O(1); every output and EVERY parameter gradient is bounded at 4e-3.
+# module tests, whose bounds must absorb a ~100x amplification of rounding noise.
+#
+# Reference: float64 torch autograd on the CPU over the reference's own wiring, with every tensor the bf16 path STORES
+# rounded at that point (each unit's z and output, each residual sum, each gradient handed from one unit to the next).
+# What can be asserted, measured (tools/diag/unit_cond.py, tools/diag/block_errs.py):
+#   * ONE unit fed the reference's own operands agrees with that reference to 1e-4 in every gradient (the unit test
+#     above) -- but the storage-emulating reference itself sits 1.3e-2 .. 2.8e-2 from the pure-float64 one: 1.6e-3 of the
+#     pre-activations lie within half a bf16 ulp of the ReLU threshold and land on the other side of the mask.
+#   * Across a CHAIN of units two bf16 computations decorrelate at the ulp level (f32 against f64 accumulation moves
+#     3e-4 of the stored values by one ulp; two units later every stored value is an independent rounding), so their ReLU
+#     masks differ in ~1e-3 of the elements and every gradient carries a RANDOM relative error of 1.3e-2 .. 2.8e-2 --
+#     a property of the format (torch autocast would show it too), not of these kernels: the pointwise path and the
+#     unfused path, which share no kernel, show the same figures to three digits.
+# So the L2 distance is bounded by that noise floor -- measured in the test itself as the distance between the
+# storage-emulating and the pure-float64 reference, per tensor -- and what a routing bug would change is bounded TIGHTLY:
+# the regression slope <ours, ref> / <ref, ref> of every gradient tensor.  Random mask flips leave the slope at 1 +- 1e-3
+# (they are uncorrelated with the gradient: measured <= 9e-4 on every filter gradient and on dx); a wrong sign, a missing
+# or doubled contribution of a residual add or of a
+# concat slice, a wrong 1/count or a wrong group in the two-group pointwise launch moves it by the size of the slip.
 def _st(t, round_grad=True):
     return _StoreBf16.apply(t, round_grad)
 
 
-def _ref_unit(x, p, k, s, residual=None):
-    """ConvNormAct (components.py:26-44) in float64 with the bf16 path's storage points: z, then the unit's output
-    (after the residual add, which the normalise pass folds in before its single rounding)"""
+def _ref_unit(x, p, k, s, residual=None, store=True):
+    """ConvNormAct (components.py:26-44) in float64; store=True: with the bf16 path's storage points -- z, then the
+    unit's output (after the residual add, which the normalise pass folds in before its single rounding)"""
+    st = _st if store else (lambda t: t)
     w, g, b = p
-    z = _st(F.conv2d(x, w, None, s, (k - s + 1) // 2 if k > 1 else 0))
+    z = st(F.conv2d(x, w, None, s, (k - s + 1) // 2 if k > 1 else 0))
     y = torch.relu(F.batch_norm(z, None, None, g, b, True, 0.1, 1e-5))
-    return _st(y + residual if residual is not None else y)
+    return st(y + residual if residual is not None else y)
 
 
 def _module_units(m):
@@ -379,8 +394,9 @@ def _module_units(m):
 
 
 def _block_case(m, x, ref_forward):
-    """run module m (GPU, bf16, train mode) and the float64 storage-emulating reference on x with a random upstream
-    gradient; return relative L2 errors of the output, the input gradient and every parameter gradient"""
+    """run module m (GPU, bf16, train mode) and the float64 references on x with a random upstream gradient; returns
+    {tensor: (rel L2 error vs the storage-emulating reference, regression slope, elements, rel L2 distance of that
+    reference from the pure-float64 one)} for the output, the input gradient and every parameter gradient"""
     torch.manual_seed(3)
     units = _module_units(m)
     with torch.no_grad():
@@ -388,14 +404,23 @@ def _block_case(m, x, ref_forward):
             u.conv.weight.copy_(u.conv.weight.to(torch.bfloat16).float())
             u.norm.weight.uniform_(0.5, 1.5)
             u.norm.bias.uniform_(-0.3, 0.3)
-    params = {n: tuple(t.detach().double().requires_grad_(True) for t in (u.conv.weight, u.norm.weight, u.norm.bias))
-              for n, u in units}
-    xr = x.double().requires_grad_(True)
     torch.set_num_threads(max(1, min(64, (torch.get_num_threads() or 1) * 4)))
-    yr = ref_forward(_st(xr), params)
     gen = torch.Generator().manual_seed(4)
-    gy = (torch.randn(yr.shape, generator=gen) + 0.25).to(torch.bfloat16).float()
-    yr.backward(gy.double())
+    gy = None
+    refs = {}
+    for store in (True, False):
+        params = {n: tuple(t.detach().double().requires_grad_(True) for t in (u.conv.weight, u.norm.weight, u.norm.bias))
+                  for n, u in units}
+        xr = x.double().requires_grad_(True)
+        yr = ref_forward(_st(xr) if store else xr, params, store)
+        if gy is None:
+            gy = (torch.randn(yr.shape, generator=gen) + 0.25).to(torch.bfloat16).float()
+        yr.backward(gy.double())
+        r = {"y": yr.detach(), "dx": xr.grad}
+        for n, _ in units:
+            w, g, b = params[n]
+            r[n + ".dw"], r[n + ".dgamma"], r[n + ".dbeta"] = w.grad, g.grad, b.grad
+        refs[store] = r
 
     m = m.cuda().train()
     m.compute_dtype = torch.bfloat16
@@ -405,17 +430,34 @@ def _block_case(m, x, ref_forward):
     y.backward(gy.cuda().to(y.dtype))
     torch.cuda.synchronize()
     assert N.launch_count() > before
-
-    def rel(a, b):
-        return ((a.double().cpu() - b.double()).norm() / b.double().norm()).item()
-
-    errs = {"y": rel(y.detach().float(), yr.detach()), "dx": rel(xg.grad, xr.grad)}
+    ours = {"y": y.detach().float(), "dx": xg.grad}
     for n, u in units:
-        w, g, b = params[n]
-        errs[n + ".dw"] = rel(u.conv.weight.grad, w.grad)
-        errs[n + ".dgamma"] = rel(u.norm.weight.grad, g.grad)
-        errs[n + ".dbeta"] = rel(u.norm.bias.grad, b.grad)
-    return errs
+        ours[n + ".dw"], ours[n + ".dgamma"], ours[n + ".dbeta"] = u.conv.weight.grad, u.norm.weight.grad, u.norm.bias.grad
+
+    out = {}
+    for k, ref in refs[True].items():
+        a, b = ours[k].double().cpu().reshape(-1), ref.double().reshape(-1)
+        f = refs[False][k].double().reshape(-1)
+        out[k] = ((a - b).norm().item() / b.norm().item(), (a @ b).item() / (b @ b).item(), b.numel(),
+                  (b - f).norm().item() / f.norm().item())
+    return out
+
+
+def _assert_block(errs):
+    bad = []
+    for k, (rel, slope, n, floor) in errs.items():
+        if k == "y":
+            ok = rel < 4e-3  # one bf16 rounding of the output
+        else:
+            # L2: inside the format's noise floor -- closer to the storage-emulating reference than float64 itself is
+            # (measured: 1.2e-2 .. 5e-2 against a floor of 5e-2 .. 1.7e-1; the BatchNorm gradients of the LAST unit, which
+            # no mask flip has reached yet, agree to 1e-4);
+            # slope: 2e-3 (measured <= 9e-4); 2e-2 for the per-channel vectors of 64 .. 256 elements, whose slope estimate
+            # is itself noisy at that size (measured <= 9.6e-3)
+            ok = rel < floor + 1e-3 and abs(slope - 1.0) < (2e-3 if n >= 1024 else 2e-2)
+        if not ok:
+            bad.append((k, rel, slope, n, floor))
+    assert not bad, bad
 
 
 def test_csp_stage_bf16_train_mode_gradients_at_batch_256_are_tight():
@@ -425,17 +467,16 @@ def test_csp_stage_bf16_train_mode_gradients_at_batch_256_are_tight():
     m = CSPDarknetStage(2, 64, 128)
     x = torch.randn(B, 64, 112, 112, generator=torch.Generator().manual_seed(12)).to(torch.bfloat16).float()
 
-    def ref(x, p):  # darknet.py:51-55
-        o = _ref_unit(x, p["conv"], 3, 2)
-        a = _ref_unit(o, p["conv1"], 1, 1)
-        t = _ref_unit(o, p["conv2"], 1, 1)
+    def ref(x, p, store):  # darknet.py:51-55
+        o = _ref_unit(x, p["conv"], 3, 2, store=store)
+        a = _ref_unit(o, p["conv1"], 1, 1, store=store)
+        t = _ref_unit(o, p["conv2"], 1, 1, store=store)
         for i in range(2):  # DarknetBlock (darknet.py:27-28): x + conv2(conv1(x)), added after the ReLU
-            h = _ref_unit(t, p[f"blocks.{i}.conv1"], 1, 1)
-            t = _ref_unit(h, p[f"blocks.{i}.conv2"], 3, 1, residual=t)
-        return _ref_unit(torch.cat([a, t], 1), p["out_conv"], 1, 1)
+            h = _ref_unit(t, p[f"blocks.{i}.conv1"], 1, 1, store=store)
+            t = _ref_unit(h, p[f"blocks.{i}.conv2"], 3, 1, residual=t, store=store)
+        return _ref_unit(torch.cat([a, t], 1), p["out_conv"], 1, 1, store=store)
 
-    errs = _block_case(m, x, ref)
-    assert max(errs.values()) < 4e-3, sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    _assert_block(_block_case(m, x, ref))
 
 
 def test_osa_block_bf16_train_mode_gradients_at_batch_256_are_tight():
@@ -445,11 +486,10 @@ def test_osa_block_bf16_train_mode_gradients_at_batch_256_are_tight():
     m = OSABlock(128, 128, 5, 256, ese=False)
     x = torch.randn(B, 128, 56, 56, generator=torch.Generator().manual_seed(22)).to(torch.bfloat16).float()
 
-    def ref(x, p):  # vovnet.py:50-63
+    def ref(x, p, store):  # vovnet.py:50-63
         feats = [x]
         for i in range(5):
-            feats.append(_ref_unit(feats[-1], p[f"convs.{i}"], 3, 1))
-        return _ref_unit(torch.cat(feats, 1), p["out_conv"], 1, 1)
+            feats.append(_ref_unit(feats[-1], p[f"convs.{i}"], 3, 1, store=store))
+        return _ref_unit(torch.cat(feats, 1), p["out_conv"], 1, 1, store=store)
 
-    errs = _block_case(m, x, ref)
-    assert max(errs.values()) < 4e-3, sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    _assert_block(_block_case(m, x, ref))
