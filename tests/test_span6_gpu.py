@@ -31,6 +31,8 @@ SHAPES = [
     (12, 64, 384, 41, 52),    # three filter tiles (do not divide the 32 workgroups of an XCD)
     (128, 160, 160, 28, 28),  # VoVNet-39 stage 2
     (33, 64, 256, 29, 71),    # odd batch, two filter tiles
+    (6, 64, 128, 112, 112),   # a map wider than 96: the tile height drops to 6 units so that the span still fits (VoVNet-39 stem)
+    (8, 64, 128, 60, 140),    # ... and to 5 units at Wp = 141
     (256, 32, 128, 28, 28),   # a single channel chunk: NOT taken by span6 (must fall through unharmed)
 ]
 MODES = [("stats", N.VT_CONV_STATS), ("plain", 0), ("residual", N.VT_CONV_RESIDUAL),
