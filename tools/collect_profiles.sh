@@ -15,7 +15,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_prof_bench" -- \
-    python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-pmc > "$OUT/${TAG}_prof_bench.log" 2>&1
+    python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-secondary > "$OUT/${TAG}_prof_bench.log" 2>&1
 echo "bench profile exit $?"
 
 LAYERS="128,128,3,1,28 256,256,3,1,14 512,512,3,1,7"

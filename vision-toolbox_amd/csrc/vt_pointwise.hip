@@ -481,7 +481,9 @@ int launch_pw(const PwArgs& a, hipStream_t st, const char* who) {
         if (rc != VT_OK) return rc;
     }
     // every workgroup stages its own copy of W (up to 33 KiB): small tensors get fewer, longer workgroups
-    const int target = VT_KNOB("VT_PW_BLOCKS", 1024);
+    // (the backward kernel that carries dW flushes N x K floats per workgroup through LDS and global atomics: one workgroup
+    // per resident slot -- 2 per CU at its register count -- measured best: 64 x 64 at 0.8 M pixels 170 -> 117 us)
+    const int target = VT_KNOB("VT_PW_BLOCKS", (MODE == PW_BWD && G::kFull) ? 512 : 1024);
     const int per_wave = VT_KNOB("VT_PW_UNITS_PER_WAVE", 8);
     long blocks = ((long)a.nunits + 4 * per_wave - 1) / (4 * per_wave);
     if (blocks > target) blocks = target;
