@@ -48,6 +48,7 @@ extern "C" {
 #define VT_CONV_STATS 2    /* accumulate per-channel sum / sum-of-squares       */
 #define VT_CONV_RESIDUAL 4 /* y += residual (after relu)                        */
 #define VT_CONV_AFFINE 8   /* y = y*scale[c] + shift[c]; scale==NULL means 1    */
+#define VT_CONV_NOSTORE 32 /* with VT_CONV_STATS: only the statistics, y is not written (y may be NULL); RGB stem only */
 #define VT_CONV_D2S 16     /* depth-to-space 2x2: the Cout = 4*C' columns of grid pixel (i, j) are the output pixels
                             * (2i+a, 2j+b) x C' channels, column = (2a+b)*C' + c; needs oHs = oWs = 2, oh0 = ow0 = 0,
                             * oH = 2*Ho, oW = 2*Wo, no STATS / AFFINE / RELU.  One launch then forms the whole data
@@ -193,6 +194,13 @@ int vt_stem_bn_bwd_reduce(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_
                           float* sums, float* gzx, int32_t fixed, void* stream);
 int vt_stem_bn_bwd_combine(int32_t C, int32_t cin, const float* gzx, const float* coef, float* dw,
                            int32_t fixed, void* stream);
+/* `fixed` bit 1 of vt_stem_bn_bwd_reduce: `z` holds the unit's OUTPUT y = relu(z*scale + shift) (the pre-activation was
+ * never stored: forward = a VT_CONV_STATS|VT_CONV_NOSTORE pass + a pass with the affine/ReLU epilogue).  The mask is
+ * y > 0, z is recovered as (y - shift) / scale where the mask is on, and the 32 z rows of gzx hold the correlations of the
+ * 27 im2col patch values with the tap-shifted x instead; vt_stem_bn_bwd_combine_y then forms Z = W P with `w` the bf16
+ * filter image [C][9][8] the forward conv read, and adds dW like vt_stem_bn_bwd_combine. */
+int vt_stem_bn_bwd_combine_y(int32_t C, int32_t cin, const float* gzx, const float* coef, const void* w, float* dw,
+                             int32_t fixed, void* stream);
 
 /* ---- pointwise (1x1) ConvNormAct unit without materialised pre-activations (vt_pointwise.hip) ---------------
  * A 1x1 `ConvNormAct` (components.py:26-44: nn.Conv2d(k=1, bias=False) -> nn.BatchNorm2d -> nn.ReLU) and its autograd

@@ -59,6 +59,30 @@ def _pad(k, s):
     return -((s - k) // 2)
 
 
+@pytest.mark.parametrize("case", [(2, 8, 32, 3, 1, 20, 13), (3, 8, 24, 3, 1, 17, 17), (2, 8, 32, 3, 1, 224, 224)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_stem_statistics_only_pass(case):
+    """VT_CONV_STATS | VT_CONV_NOSTORE (RGB stem kernel): the same sums as the storing pass, bit for bit in fixed point,
+    and y (NULL here) is never touched; anywhere else the flag is refused."""
+    B, Cin, Cout, k, s, H, W = case
+    x = filler.tensor(f"x{case}", (B, Cin, H, W))
+    w = filler.tensor(f"w{case}", (Cout, Cin, k, k), scale=(2.0 / (Cin * k * k)) ** 0.5)
+    xd, wd = nhwc(x, N.VT_BF16), krsc(w, N.VT_BF16)
+    y = torch.empty((B, H, W, Cout), device="cuda", dtype=torch.bfloat16)
+    st_a, st_b = N.stats_buffer(Cout), N.stats_buffer(Cout)
+    d = conv_desc(N.VT_BF16, xd, Cin, Cout, k, s, 1, Cout, flags=N.VT_CONV_STATS)
+    N.check(N.lib().vt_conv_igemm(C.byref(d), vp(xd), vp(wd), vp(y), None, None, None, vp(st_a), stream()))
+    d = conv_desc(N.VT_BF16, xd, Cin, Cout, k, s, 1, Cout, flags=N.VT_CONV_STATS | N.VT_CONV_NOSTORE)
+    N.check(N.lib().vt_conv_igemm(C.byref(d), vp(xd), vp(wd), None, None, None, None, vp(st_b), stream()))
+    assert torch.equal(N.stats_decode(st_a), N.stats_decode(st_b))
+    # not the stem shape class: refused, not silently stored
+    x2 = nhwc(filler.tensor("xns", (1, 16, 8, 8)), N.VT_BF16)
+    w2 = krsc(filler.tensor("wns", (16, 16, 3, 3)), N.VT_BF16)
+    d = conv_desc(N.VT_BF16, x2, 16, 16, 3, 1, 1, 16, flags=N.VT_CONV_STATS | N.VT_CONV_NOSTORE)
+    assert N.lib().vt_conv_igemm(C.byref(d), vp(x2), vp(w2), None, None, None, None, vp(N.stats_buffer(16)),
+                                 stream()) == N.VT_ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=DNAME.get)
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv_forward_and_stats(dtype, case):

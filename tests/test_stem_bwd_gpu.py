@@ -80,6 +80,58 @@ def test_stem_backward_matches_float64(B, H, W, lddy, ldz, relu, fixed):
     assert err < 2e-5, err
 
 
+@pytest.mark.parametrize("fixed", [0, 1], ids=["f32_atomics", "fixed_point"])
+@pytest.mark.parametrize("B,H,W,lddy,ldz,relu", CASES)
+def test_stem_backward_from_the_units_output(B, H, W, lddy, ldz, relu, fixed):
+    """`fixed` bit 1: the pass reads y = relu(z*scale + shift) (bf16) instead of z, which the forward pass never stored.
+    Mask = y > 0; the BatchNorm sums use z recovered from y; the b*Z term of dW uses the EXACT z = W * patch (Z = W P with
+    P the patch / tap-shifted-x correlations), so the float64 reference takes z from a float64 conv of the bf16 operands."""
+    torch.manual_seed(B * 1000 + W + 7)
+    dev = "cuda"
+    Cc = 32
+    x = torch.zeros(B, H, W, 8, device=dev, dtype=torch.bfloat16)
+    x[..., :3] = torch.randn(B, H, W, 3, device=dev).to(torch.bfloat16)
+    wq = torch.zeros(Cc, 9, 8, device=dev, dtype=torch.bfloat16)  # the forward conv's filter image
+    wq[..., :3] = (torch.randn(Cc, 9, 3, device=dev) * 0.3).to(torch.bfloat16)
+    z_true = F.conv2d(x[..., :3].double().permute(0, 3, 1, 2),
+                      wq[..., :3].double().reshape(Cc, 3, 3, 3).permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    sc = torch.randn(Cc, device=dev) * 0.8
+    sc = torch.where(sc.abs() < 0.05, torch.full_like(sc, 0.05), sc)
+    sf = torch.randn(Cc, device=dev) * 0.5
+    yv = z_true.float() * sc + sf
+    yw = torch.randn(B, H, W, ldz, device=dev).to(torch.bfloat16)
+    off_dy, off_y = (lddy - Cc), (ldz - Cc) // 2 // 8 * 8
+    yw[..., off_y:off_y + Cc] = (yv.clamp_min(0) if relu else yv).to(torch.bfloat16)
+    dyw = torch.randn(B, H, W, lddy, device=dev).to(torch.bfloat16)
+    dy, y = dyw[..., off_dy:off_dy + Cc], yw[..., off_y:off_y + Cc]
+    mu = torch.randn(Cc, device=dev) * 0.3
+    istd = torch.rand(Cc, device=dev) + 0.5
+    coef = torch.randn(3, Cc, device=dev) * torch.tensor([[1.0], [0.05], [0.02]], device=dev)
+    sums = N.stats_buffer(Cc)
+    lib = N.lib()
+    gzx = torch.zeros(lib.vt_stem_bn_bwd_scratch_bytes(Cc) // 4, device=dev)
+    dw = torch.full((Cc, 9, 3), 0.25, device=dev)
+    st = stream()
+    N.check(lib.vt_stem_bn_bwd_reduce(N.VT_BF16, B, H, W, Cc, vp(x), vp(dy), lddy, vp(y), ldz, vp(sc), vp(sf), vp(mu),
+                                      vp(istd), relu, vp(sums), vp(gzx), fixed | 2, st))
+    N.check(lib.vt_stem_bn_bwd_combine_y(Cc, 3, vp(gzx), vp(coef), vp(wq), vp(dw), fixed, st))
+    torch.cuda.synchronize()
+    on = (y.float() > 0) if relu else torch.ones_like(y, dtype=torch.bool)
+    g = torch.where(on, dy.double(), torch.zeros_like(dy, dtype=torch.float64))
+    z_rec = (y.double() - sf.double()) * (1.0 / sc).double()
+    ref_s = torch.stack([g.sum((0, 1, 2)), (g * (z_rec - mu.double())).sum((0, 1, 2)) * istd.double()])
+    a, b, d = (coef[i].double() for i in range(3))
+    dz = a * g - b * z_true + d
+    w = torch.zeros(32, 3, 3, 3, dtype=torch.float64, device=dev, requires_grad=True)
+    F.conv2d(x[..., :3].double().permute(0, 3, 1, 2), w, padding=1).backward(dz.permute(0, 3, 1, 2))
+    ref_dw = w.grad.permute(0, 2, 3, 1).reshape(32, 9, 3)
+    got_s = N.stats_decode(sums)
+    scale_s = ref_s.abs().max(dim=1, keepdim=True).values
+    assert ((got_s - ref_s).abs() / scale_s).max().item() < 2e-5
+    err = ((dw.double() - 0.25) - ref_dw).abs().max().item() / ref_dw.abs().max().item()
+    assert err < 2e-5, err
+
+
 def test_stem_backward_rejects_what_it_has_no_kernel_for():
     lib = N.lib()
     t = torch.zeros(64, device="cuda")

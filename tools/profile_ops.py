@@ -44,6 +44,7 @@ def main():
     rows = []
     excess = []
     algo_bytes = defaultdict(float)
+    by_pix = defaultdict(lambda: [0.0, 0])
     reps = 5
     for phase, ops, n in (("fwd", p.fwd_ops, p.n_fwd), ("bwd", p.bwd_ops, p.n_bwd)):
         for idx in range(n):
@@ -97,6 +98,17 @@ def main():
                 work = f"{nb / ms / 1e9:6.2f} TB/s ideal {nb / PEAK_HBM * 1e3:6.3f} excess {ms - nb / PEAK_HBM * 1e3:6.3f}"
             elif kind == N.OP_STEM_BWD_REDUCE:  # i: dtype B H W C ...
                 algo_bytes[name] += 2.0 * op.i[1] * op.i[2] * op.i[3] * (8 + 2 * op.i[4])
+            # rows (pixels) the op works on: the stage it belongs to
+            if kind in (N.OP_CONV_IGEMM, N.OP_CONV_WGRAD):
+                npix = d.B * max(d.Ho * d.Wo, d.oH * d.oW if kind == N.OP_CONV_IGEMM else 0)
+            elif kind in (N.OP_BN_ACT_APPLY, N.OP_BN_BWD_REDUCE, N.OP_BN_BWD_APPLY, N.OP_PW_STATS, N.OP_PW_APPLY, N.OP_PW_REDUCE, N.OP_PW_BWD):
+                npix = int(op.f[0])
+            elif kind == N.OP_STEM_BWD_REDUCE:
+                npix = op.i[1] * op.i[2] * op.i[3]
+            else:
+                npix = 0
+            by_pix[npix][0] += ms
+            by_pix[npix][1] += 1
             rows.append((ms, phase, idx, name, desc, work))
     tot = defaultdict(float)
     for ms, phase, idx, name, desc, work in rows:
@@ -106,6 +118,9 @@ def main():
         print(f"  {phase} {name:16s} {v:8.3f} ms")
     print(f"-- bytes per step when every operand of this decomposition moves once: {sum(algo_bytes.values()) / 1e9:.2f} GB "
           + ", ".join(f"{k} {v / 1e9:.2f}" for k, v in sorted(algo_bytes.items(), key=lambda kv: -kv[1])))
+    print("-- time by the number of pixels an op works on (0: per-channel / plumbing kernels)")
+    for npix, (ms_, cnt) in sorted(by_pix.items(), key=lambda kv: -kv[0]):
+        print(f"  {npix:10d} pixels: {cnt:4d} ops {ms_:7.3f} ms")
     print("-- pointwise ops (bytes = operands of the pass, once)")
     for ms, phase, idx, name, desc, work in sorted([r for r in rows if r[3].startswith("pw_")], key=lambda r: -r[0])[:top]:
         print(f"  {phase}[{idx:4d}] {name:11s} {desc}  {ms:7.4f} ms {work}")

@@ -443,7 +443,9 @@ int launch(IgemmArgs& a, hipStream_t st) {
 extern "C" int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w, void* y,
                              const float* scale, const float* shift, const void* residual,
                              float* stats, void* stream) {
-    VT_REQUIRE(d && x && w && y, VT_ERR_INVALID, "vt_conv_igemm: null argument");
+    VT_REQUIRE(d && x && w && (y || (d->flags & VT_CONV_NOSTORE)), VT_ERR_INVALID, "vt_conv_igemm: null argument");
+    VT_REQUIRE(!(d->flags & VT_CONV_NOSTORE) || (d->flags & VT_CONV_STATS), VT_ERR_INVALID,
+               "vt_conv_igemm: NOSTORE is the statistics-only pass");
     VT_REQUIRE(d->dtype == VT_F32 || d->dtype == VT_BF16, VT_ERR_UNSUPPORTED,
                "vt_conv_igemm: dtype %d", d->dtype);
     const int epc = vt_epc(d->dtype);
@@ -510,6 +512,7 @@ extern "C" int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w
         const int rc = vt_stem_dispatch(a, d->dtype, stream);  // RGB stem
         if (rc >= 0) return rc;
     }
+    VT_REQUIRE(!(d->flags & VT_CONV_NOSTORE), VT_ERR_UNSUPPORTED, "vt_conv_igemm: NOSTORE outside the RGB stem kernel");
     if (!d2s) {  // (these kernels write dense rows only)
         const int rc = vt_span6_dispatch(a, d->dtype, stream);  // MFMA-bound 3x3 stride-1 layers: two-group + loader kernel
         if (rc >= 0) return rc;

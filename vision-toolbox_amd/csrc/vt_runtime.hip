@@ -166,7 +166,10 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
             return vt_stem_bn_bwd_reduce(I[0], I[1], I[2], I[3], I[4], P[0], P[1], I[5], P[2], I[6], (const float*)P[3],
                                          (const float*)P[4], (const float*)P[5], (const float*)P[6], I[7], (float*)P[7],
                                          (float*)P[8], I[8], st);
-        case VT_OP_STEM_BWD_COMBINE:  // ptr: gzx coef dw | i: C cin fixed
+        case VT_OP_STEM_BWD_COMBINE:  // ptr: gzx coef dw [w: the reduction read y, not z] | i: C cin fixed
+            if (P[3])
+                return vt_stem_bn_bwd_combine_y(I[0], I[1], (const float*)P[0], (const float*)P[1], P[3], (float*)P[2], I[2],
+                                                st);
             return vt_stem_bn_bwd_combine(I[0], I[1], (const float*)P[0], (const float*)P[1], (float*)P[2], I[2], st);
         case VT_OP_MAXPOOL_FWD:  // ptr: x y argmax | i: ldx ldy B H W C dtype
             return vt_maxpool3x3s2_fwd(P[0], I[0], P[1], I[1], (uint8_t*)P[2], I[2], I[3], I[4], I[5], I[6], st);

@@ -147,6 +147,7 @@ __global__ void __launch_bounds__(256) stem_kernel(const IgemmArgs p, const int 
     const bool affine = p.flags & VT_CONV_AFFINE;
     const bool relu = p.flags & VT_CONV_RELU;
     const bool stats = p.flags & VT_CONV_STATS;
+    const bool store = !(p.flags & VT_CONV_NOSTORE);  // statistics-only pass: z is rounded to bf16 for the sums, not kept
     bf* __restrict__ yg = (bf*)p.y;
     float sc[FN], sf[FN], s1[FN], s2[FN];
 #pragma unroll
@@ -169,12 +170,13 @@ __global__ void __launch_bounds__(256) stem_kernel(const IgemmArgs p, const int 
                 if (affine) v = fmaf(v, sc[j], sf[j]);
                 if (relu) v = fmaxf(v, 0.f);
                 const bf tv = from_float<bf>(v);
-                sWin[(4 * q + r) * PITCH + j * 16 + u] = tv;
+                if (store) sWin[(4 * q + r) * PITCH + j * 16 + u] = tv;
                 const float fv = (float)tv;
                 s1[j] += fv;
                 s2[j] = fmaf(fv, fv, s2[j]);
             }
         }
+        if (!store) continue;
         lds_fence();
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {

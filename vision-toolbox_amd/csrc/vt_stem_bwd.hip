@@ -85,8 +85,16 @@ constexpr int kGzxReplicas = 8;
 constexpr int kCols = 96;  // 3 filter rows x 4 pixels x 8 channels
 
 // FA = C / 16 (2 or 4)
-template <int FA>
+// FROM_Y (round 3): the unit's OUTPUT y = relu(z*scale + shift) is read instead of the pre-activation z, which the forward
+// pass then never stores (the stem conv runs twice: a statistics-only pass and a pass with the normalise + ReLU epilogue).
+//   * mask: y > 0;  z = (y - shift) / scale wherever the mask is on (all the reduction needs);
+//   * the correlation Z = sum z * x(p+t), which needs z everywhere, is replaced by P = sum patch(p) * x(p+t) with
+//     patch(p) the 27 input values under the 3x3 window -- z is LINEAR in the patch, so Z = W P (vt_stem_bn_bwd_combine_y).
+//     The 32-column block that held z holds the patch (27 values + 5 zeros), gathered from the x ring: same fragments,
+//     same MFMA count.
+template <int FA, bool FROM_Y>
 __global__ void __launch_bounds__(256, 2) stem_bwd_kernel(const SbArgs p) {
+    static_assert(!FROM_Y || FA == 2, "the patch block is 32 columns wide");
     constexpr int C = 16 * FA;
     constexpr int CPR = C / 8;            // 16-byte chunks per dy / z row
     constexpr int NIT = CPR / 4;          // (position, chunk) items per thread and step
@@ -96,8 +104,8 @@ __global__ void __launch_bounds__(256, 2) stem_bwd_kernel(const SbArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sG = smem;                 // [2][64][PITCH]
     char* sZ = smem + 2 * TILE;      // [2][64][PITCH]  (channels C.. = flag block)
-    float* sCoef = (float*)(smem + 4 * TILE);  // [3][C]: scale | shift | mean
-    char* sX = smem + 4 * TILE + 3 * C * 4;    // [rx][16 B]
+    float* sCoef = (float*)(smem + 4 * TILE);  // [4][C]: scale | shift | mean | 1 / scale
+    char* sX = smem + 4 * TILE + 4 * C * 4;    // [rx][16 B]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,6 +118,7 @@ __global__ void __launch_bounds__(256, 2) stem_bwd_kernel(const SbArgs p) {
     // ---- zero the tiles once (the unused / flag blocks stay zero) ----------------------------------
     for (int i = tid; i < 4 * TILE / 16; i += 256) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
     if (tid < 3 * C) sCoef[tid] = (tid < C ? p.scale : tid < 2 * C ? p.shift - C : p.mean - 2 * C)[tid];
+    if (tid < C) sCoef[3 * C + tid] = p.scale[tid] != 0.f ? 1.f / p.scale[tid] : 0.f;
 
     // ---- ring prologue: rows [Pbeg - halo, Pbeg + halo) ---------------------------------------------
     {
@@ -126,6 +135,14 @@ __global__ void __launch_bounds__(256, 2) stem_bwd_kernel(const SbArgs p) {
 
     // ---- per-thread streams -------------------------------------------------------------------------
     const int chunk = tid % CPR;
+    // FROM_Y: column 8*chunk + e of the patch block is input channel i % 3 under tap i / 3 (i = 8*chunk + e < 27)
+    int pat_row[8], pat_byte[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int i = 8 * chunk + e, t = i / 3, c = i - 3 * t;
+        pat_row[e] = i < 27 ? (t / 3 - 1) * p.PW + (t % 3 - 1) : 0;
+        pat_byte[e] = i < 27 ? 2 * c : -1;
+    }
     int ipos[NIT];
     Pos ps[NIT];
 #pragma unroll
@@ -202,7 +219,7 @@ __global__ void __launch_bounds__(256, 2) stem_bwd_kernel(const SbArgs p) {
         // ---- elementwise: g, partial sums, park the rows --------------------------------------------
         char* tg_ = sG + (s & 1) * TILE;
         char* tz_ = sZ + (s & 1) * TILE;
-        float sc[8], sf[8], mu[8];  // re-read every step: 24 registers that the MFMA phase gets back
+        float sc[8], sf[8], mu[8], rs[8];  // re-read every step: registers that the MFMA phase gets back
 #pragma unroll
         for (int h4 = 0; h4 < 2; ++h4) {
             const f32x4 a4 = *(const volatile f32x4*)(sCoef + chunk * 8 + 4 * h4);
@@ -211,6 +228,10 @@ __global__ void __launch_bounds__(256, 2) stem_bwd_kernel(const SbArgs p) {
             sc[4 * h4] = a4[0], sc[4 * h4 + 1] = a4[1], sc[4 * h4 + 2] = a4[2], sc[4 * h4 + 3] = a4[3];
             sf[4 * h4] = b4[0], sf[4 * h4 + 1] = b4[1], sf[4 * h4 + 2] = b4[2], sf[4 * h4 + 3] = b4[3];
             mu[4 * h4] = c4[0], mu[4 * h4 + 1] = c4[1], mu[4 * h4 + 2] = c4[2], mu[4 * h4 + 3] = c4[3];
+            if constexpr (FROM_Y) {
+                const f32x4 d4 = *(const volatile f32x4*)(sCoef + 3 * C + chunk * 8 + 4 * h4);
+                rs[4 * h4] = d4[0], rs[4 * h4 + 1] = d4[1], rs[4 * h4 + 2] = d4[2], rs[4 * h4 + 3] = d4[3];
+            }
         }
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
@@ -220,11 +241,19 @@ __global__ void __launch_bounds__(256, 2) stem_bwd_kernel(const SbArgs p) {
             unsigned keep[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const bool on = !p.relu || fmaf(fz[e], sc[e], sf[e]) > 0.f;
+                bool on;
+                float zv;
+                if constexpr (FROM_Y) {
+                    on = !p.relu || fz[e] > 0.f;          // fz holds y
+                    zv = (fz[e] - sf[e]) * rs[e];          // z wherever the mask is on
+                } else {
+                    on = !p.relu || fmaf(fz[e], sc[e], sf[e]) > 0.f;
+                    zv = fz[e];
+                }
                 const float gg = on ? fg[e] : 0.f;
                 keep[e] = on ? 0xffffu : 0u;
                 s1[e] += gg;
-                s2[e] = fmaf(gg, fz[e] - mu[e], s2[e]);
+                s2[e] = fmaf(gg, zv - mu[e], s2[e]);
             }
             uint4 m;
             m.x = keep[0] | (keep[1] << 16), m.y = keep[2] | (keep[3] << 16);
@@ -233,7 +262,23 @@ __global__ void __launch_bounds__(256, 2) stem_bwd_kernel(const SbArgs p) {
             go.x &= m.x, go.y &= m.y, go.z &= m.z, go.w &= m.w;
             const int row = ipos[k];
             *(uint4*)(tg_ + row * PITCH + chunk * 16) = go;
-            *(uint4*)(tz_ + row * PITCH + chunk * 16) = vz[slot][k];
+            if constexpr (FROM_Y) {
+                // the patch of this position from the x ring (rows written at least one step ago: halo >= PW + 3 + 64)
+                unsigned short pv[8];
+                const int P = (int)(Pbeg + 64l * s) + row;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    pv[e] = 0;
+                    if (pat_byte[e] >= 0 && ok[slot][k])
+                        pv[e] = *(const unsigned short*)(sX + ((((unsigned)(P + pat_row[e])) & xmask) << 4) + pat_byte[e]);
+                }
+                uint4 pk;
+                pk.x = pv[0] | ((unsigned)pv[1] << 16), pk.y = pv[2] | ((unsigned)pv[3] << 16);
+                pk.z = pv[4] | ((unsigned)pv[5] << 16), pk.w = pv[6] | ((unsigned)pv[7] << 16);
+                *(uint4*)(tz_ + row * PITCH + chunk * 16) = pk;
+            } else {
+                *(uint4*)(tz_ + row * PITCH + chunk * 16) = vz[slot][k];
+            }
             if (chunk == 0) *(uint4*)(tz_ + row * PITCH + 2 * C) = make_uint4(ok[slot][k] ? 0x3f80u : 0u, 0, 0, 0);
         }
         if (wave == 0) {
@@ -343,6 +388,37 @@ __global__ void stem_bwd_combine_kernel(const float* __restrict__ gzx, const flo
     dw[idx] += (float)v;
 }
 
+// the same for the FROM_Y reduction: rows [C, C + 27) of gzx hold P[i][col] = sum patch_i * x(p+t) and
+// Z[n][col] = sum_i w[n][i] P[i][col] with w the bf16 filter image [C][9][8] the forward conv read (z is linear in the patch)
+__global__ void stem_bwd_combine_y_kernel(const float* __restrict__ gzx, const float* __restrict__ coef,
+                                          const bf16_t* __restrict__ w, int C, int cin, float* __restrict__ dw, int fixed) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= C * 9 * cin) return;
+    const int c = idx % cin, t = (idx / cin) % 9, n = idx / (9 * cin);
+    const int col = (t / 3) * 32 + (t % 3) * 8 + c;
+    const int rows = 2 * C + 16;
+    auto entry = [&](int row) -> double {
+        double v = 0.0;
+        if (fixed) {
+            const long long* q = (const long long*)gzx;
+            long long h = 0, l = 0;
+            for (int r = 0; r < kGzxReplicas; ++r) {
+                const long e = (long)r * rows * kCols + (long)row * kCols + col;
+                h += q[2 * e], l += q[2 * e + 1];
+            }
+            v = (double)h * 4096.0 + (double)l * (1.0 / 8589934592.0);
+        } else {
+            for (int r = 0; r < kGzxReplicas; ++r) v += (double)gzx[(long)r * rows * kCols + (long)row * kCols + col];
+        }
+        return v;
+    };
+    const double G = entry(n), X = entry(2 * C);
+    double Z = 0.0;
+    for (int i = 0; i < 27; ++i) Z += (double)(float)w[(long)n * 72 + (i / 3) * 8 + (i % 3)] * entry(C + i);
+    const double v = (double)coef[n] * G - (double)coef[C + n] * Z + (double)coef[2 * C + n] * X;
+    dw[idx] += (float)v;
+}
+
 }  // namespace
 
 extern "C" {
@@ -363,7 +439,8 @@ int vt_stem_bn_bwd_reduce(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_
     a.x = (const bf16_t*)x, a.dy = (const bf16_t*)dy, a.z = (const bf16_t*)z;
     a.scale = scale, a.shift = shift, a.mean = mean, a.invstd = invstd, a.sums = sums, a.gzx = gzx;
     a.B = B, a.H = H, a.W = W, a.C = C, a.lddy = lddy, a.ldz = ldz, a.relu = relu;
-    a.fixed = fixed ? 1 : 0;
+    const bool from_y = (fixed & 2) != 0;  // bit 1 of `fixed`: `z` is the unit's output y (see the kernel's header)
+    a.fixed = (fixed & 1) ? 1 : 0;
     a.PW = W + 1, a.PH = H + 1, a.S = a.PW * a.PH;
     const long NP = (long)B * a.S;
     VT_REQUIRE(NP <= 0x7fff0000L, VT_ERR_UNSUPPORTED, "vt_stem_bn_bwd_reduce: more than 2^31 positions");
@@ -371,11 +448,12 @@ int vt_stem_bn_bwd_reduce(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_
     a.magic_pw = (unsigned)((0x100000000ull + a.PW - 1) / a.PW);
     a.magic_ph = (unsigned)((0x100000000ull + a.PH - 1) / a.PH);
     a.halo = (a.PW + 3 + 63) / 64 * 64;  // rows [P - PW - 1, P + 63 + PW + 3] of a step must be in the ring
+    if (from_y) a.halo += 64;            // ... one step EARLIER: the patch gather of a step reads the ring before its barrier
     int rx = 256;
     while (rx < 2 * a.halo + 192) rx *= 2;
     a.rx = rx;
     const int pitch = 2 * C + 32;
-    const int smem = 4 * 64 * pitch + 3 * C * 4 + rx * 16;
+    const int smem = 4 * 64 * pitch + 4 * C * 4 + rx * 16;
     VT_REQUIRE(smem <= 64 * 1024, VT_ERR_UNSUPPORTED, "vt_stem_bn_bwd_reduce: image too wide for the LDS ring");
     // two workgroups' worth of positions per CU slot; a chunk must dwarf the ring warm-up (2*halo rows)
     const int target = VT_KNOB("VT_STEM_BWD_WGS", 1024);
@@ -386,8 +464,11 @@ int vt_stem_bn_bwd_reduce(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_
     a.chunk = (int)chunk;
     const long blocks = (NP + chunk - 1) / chunk;
     hipStream_t st = (hipStream_t)stream;
-    vt_note_kernel("stem_bwd_kernel<%d>", C / 16);
-    hipLaunchKernelGGL(stem_bwd_kernel<2>, dim3((unsigned)blocks), dim3(256), smem, st, a);
+    vt_note_kernel("stem_bwd_kernel<%d%s>", C / 16, from_y ? ",y" : "");
+    if (from_y)
+        hipLaunchKernelGGL((stem_bwd_kernel<2, true>), dim3((unsigned)blocks), dim3(256), smem, st, a);
+    else
+        hipLaunchKernelGGL((stem_bwd_kernel<2, false>), dim3((unsigned)blocks), dim3(256), smem, st, a);
     VT_CHECK_LAUNCH("vt_stem_bn_bwd_reduce");
     return VT_OK;
 }
@@ -400,6 +481,17 @@ int vt_stem_bn_bwd_combine(int32_t C, int32_t cin, const float* gzx, const float
     hipLaunchKernelGGL(stem_bwd_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, gzx, coef, C,
                        cin, dw, fixed ? 1 : 0);
     VT_CHECK_LAUNCH("vt_stem_bn_bwd_combine");
+    return VT_OK;
+}
+
+int vt_stem_bn_bwd_combine_y(int32_t C, int32_t cin, const float* gzx, const float* coef, const void* w, float* dw,
+                             int32_t fixed, void* stream) {
+    VT_REQUIRE(C == 32 && cin >= 1 && cin <= 8 && gzx && coef && w && dw, VT_ERR_INVALID,
+               "vt_stem_bn_bwd_combine_y: bad argument");
+    const int n = C * 9 * cin;
+    hipLaunchKernelGGL(stem_bwd_combine_y_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, gzx, coef,
+                       (const bf16_t*)w, C, cin, dw, (fixed & 1) ? 1 : 0);
+    VT_CHECK_LAUNCH("vt_stem_bn_bwd_combine_y");
     return VT_OK;
 }
 

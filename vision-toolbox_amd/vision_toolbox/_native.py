@@ -17,7 +17,7 @@ LIB_PATH = Path(os.environ.get("VT_AMD_LIB", _HERE.parent / "csrc" / "libvt_amd.
 VT_OK, VT_ERR_INVALID, VT_ERR_UNSUPPORTED, VT_ERR_HIP = 0, 1, 2, 3
 VT_F32, VT_BF16 = 0, 1
 VT_MAX_TAPS = 36
-VT_CONV_RELU, VT_CONV_STATS, VT_CONV_RESIDUAL, VT_CONV_AFFINE, VT_CONV_D2S = 1, 2, 4, 8, 16
+VT_CONV_RELU, VT_CONV_STATS, VT_CONV_RESIDUAL, VT_CONV_AFFINE, VT_CONV_D2S, VT_CONV_NOSTORE = 1, 2, 4, 8, 16, 32
 VT_STAT_REPLICAS = 32
 # a statistics buffer is int64[VT_STAT_REPLICAS][2][C][2]: value = hi * 2^12 + lo / 2^33 (vt_amd.h)
 
@@ -205,6 +205,7 @@ SYMBOLS = {
     "vt_stem_bn_bwd_scratch_bytes": (_i64, [_i32]),
     "vt_stem_bn_bwd_reduce": (_i32, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
     "vt_stem_bn_bwd_combine": (_i32, [_i32, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "vt_stem_bn_bwd_combine_y": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "vt_bn_act_bwd_apply": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "vt_pw_supported": (_i32, [_i32, _i32, _i32, _i32]),
     "vt_pw_fwd_stats": (_i32, [C.POINTER(PwDesc), C.POINTER(_vp), _vp]),

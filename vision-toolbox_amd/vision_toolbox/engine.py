@@ -246,6 +246,9 @@ class Builder:
         self.fork_split = os.environ.get("VT_FORK_SPLIT", "0") != "0"
         # stem unit (3 -> 32, s1): BatchNorm-backward reduction and filter gradient in one pass, dz never formed
         self.stem_fused_bwd = os.environ.get("VT_STEM_FUSED_BWD", "1") != "0"
+        # ... and its pre-activation z (B x 224 x 224 x 32, the largest tensor of a step) is never stored: the conv runs
+        # twice (statistics only, then with the normalise + ReLU epilogue) and backward recovers z from y
+        self.stem_from_y = os.environ.get("VT_STEM_FROM_Y", "1") != "0"
         # 3x3 stride-2 data gradients whose dz has at most this many channels (the HBM-bound ones) run as ONE
         # depth-to-space launch instead of four parity-class launches that each re-read dz
         self.dgrad_d2s_maxc = int(os.environ.get("VT_DGRAD_D2S_MAXC", "64"))
@@ -569,6 +572,10 @@ class Builder:
         y = out if out is not None else self.act(B, Ho, Wo, Cout, name + ".y")
         z = None
         coef = None
+        stem_fused = (self.stem_fused_bwd and track and padded and has_bn and not fused and residual is None and
+                      not x.needs_grad and w.requires_grad and dt == N.VT_BF16 and Cout == 32 and k == 3 and s == 1 and
+                      pad == 1 and x.C == 8 and x.ld == 8 and x.W <= 896 and B * (x.H + 1) * (x.W + 1) < 0x7fff0000)  # (ring in LDS)
+        stem_y = stem_fused and unit_training and self.stem_from_y and x.W <= 832
         if has_bn:
             coef = self.f32(4 * Cout, "bncoef")  # scale, shift, mean, invstd
             cp = [self.bp(coef, i * Cout * 4) for i in range(4)]
@@ -580,6 +587,15 @@ class Builder:
             d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, y.ld, ldw, flags, residual.ld if residual else 0)
             self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, y.addr(), cp[0], cp[1],
                                         residual.addr() if residual else None, None], desc=d)
+        elif stem_y:
+            stats = self.zeroed_f32(N.stat_floats(Cout), "stats")
+            d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, y.ld, ldw, N.VT_CONV_STATS | N.VT_CONV_NOSTORE)
+            self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, None, None, None, None, self.bp(stats)], desc=d)
+            self.emit(N.OP_BN_FINALIZE,
+                      [self.bp(stats), g, b_, rm, rv, self.pref(norm.num_batches_tracked), *cp],
+                      [Cout], [M * self.bn_world, norm.eps, norm.momentum])
+            d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, y.ld, ldw, N.VT_CONV_AFFINE | (N.VT_CONV_RELU if relu else 0))
+            self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, y.addr(), cp[0], cp[1], None, None], desc=d)
         elif has_bn:
             z = self.act(B, Ho, Wo, Cout, name + ".z")
             if unit_training:
@@ -604,9 +620,6 @@ class Builder:
                       [x.addr(), wptr, y.addr(), None, self.pref(conv.bias) if conv.bias is not None else None,
                        residual.addr() if residual else None, None], desc=d)
 
-        stem_fused = (self.stem_fused_bwd and track and padded and has_bn and not fused and residual is None and
-                      not x.needs_grad and w.requires_grad and dt == N.VT_BF16 and Cout == 32 and k == 3 and s == 1 and
-                      pad == 1 and x.C == 8 and x.ld == 8 and x.W <= 896 and B * (x.H + 1) * (x.W + 1) < 0x7fff0000)  # (ring in LDS)
         if track:
             tag = self.tag
             training = unit_training
@@ -624,14 +637,15 @@ class Builder:
                     # small kernel finishes dW = a*G - b*Z + d*X once (a, b, d) exist (vt_stem_bwd.hip)
                     sums = self.zeroed_f32(N.stat_floats(Cout), "bwdsums")
                     gzx = self.zeroed_f32(N.lib().vt_stem_bn_bwd_scratch_bytes(Cout) // 4, "stem_gzx")
+                    zy = y if stem_y else z
                     self.emit(N.OP_STEM_BWD_REDUCE,
-                              [x.addr(), dy.addr(), z.addr(), cp[0], cp[1], cp[2], cp[3], self.bp(sums), self.bp(gzx)],
-                              [dt, B, x.H, x.W, Cout, dy.ld, z.ld, int(relu), int(self.deterministic)])
+                              [x.addr(), dy.addr(), zy.addr(), cp[0], cp[1], cp[2], cp[3], self.bp(sums), self.bp(gzx)],
+                              [dt, B, x.H, x.W, Cout, dy.ld, zy.ld, int(relu), int(self.deterministic) | (2 if stem_y else 0)])
                     bcoef = self.f32(3 * Cout, "bwdcoef")
                     self.emit(N.OP_BN_BWD_FINALIZE,
                               [self.bp(sums), cp[0], cp[2], cp[3], self.pgrad(norm.weight), self.pgrad(norm.bias),
                                self.bp(bcoef)], [Cout, int(training)], [M * self.bn_world, 1.0 / self.bn_world])
-                    self.emit(N.OP_STEM_BWD_COMBINE, [self.bp(gzx), self.bp(bcoef), self.pgrad(w)],
+                    self.emit(N.OP_STEM_BWD_COMBINE, [self.bp(gzx), self.bp(bcoef), self.pgrad(w), wptr if stem_y else None],
                               [Cout, Cin_w, int(self.deterministic)])
                     return
                 if has_bn:
