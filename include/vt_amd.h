@@ -48,7 +48,8 @@ extern "C" {
 #define VT_CONV_STATS 2    /* accumulate per-channel sum / sum-of-squares       */
 #define VT_CONV_RESIDUAL 4 /* y += residual (after relu)                        */
 #define VT_CONV_AFFINE 8   /* y = y*scale[c] + shift[c]; scale==NULL means 1    */
-#define VT_CONV_NOSTORE 32 /* with VT_CONV_STATS: only the statistics, y is not written (y may be NULL); RGB stem only */
+#define VT_CONV_NOSTORE 32 /* with VT_CONV_STATS: only the statistics -- of the f32 accumulator, not of a rounded copy --,
+                            * y is not written (y may be NULL); RGB stem only */
 #define VT_CONV_D2S 16     /* depth-to-space 2x2: the Cout = 4*C' columns of grid pixel (i, j) are the output pixels
                             * (2i+a, 2j+b) x C' channels, column = (2a+b)*C' + c; needs oHs = oWs = 2, oh0 = ow0 = 0,
                             * oH = 2*Ho, oW = 2*Wo, no STATS / AFFINE / RELU.  One launch then forms the whole data

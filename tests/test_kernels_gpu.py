@@ -59,22 +59,69 @@ def _pad(k, s):
     return -((s - k) // 2)
 
 
-@pytest.mark.parametrize("case", [(2, 8, 32, 3, 1, 20, 13), (3, 8, 24, 3, 1, 17, 17), (2, 8, 32, 3, 1, 224, 224)],
-                         ids=lambda c: "x".join(map(str, c)))
-def test_stem_statistics_only_pass(case):
-    """VT_CONV_STATS | VT_CONV_NOSTORE (RGB stem kernel): the same sums as the storing pass, bit for bit in fixed point,
-    and y (NULL here) is never touched; anywhere else the flag is refused."""
+STEM_CASES = [(2, 8, 32, 3, 1, 20, 13), (3, 8, 24, 3, 1, 17, 17), (2, 8, 32, 3, 1, 224, 224), (5, 8, 32, 3, 1, 31, 67),
+              (1, 8, 16, 3, 1, 300, 500), (3, 8, 32, 3, 1, 2, 700)]
+
+
+@pytest.mark.parametrize("tiles", [4, 2])
+@pytest.mark.parametrize("case", STEM_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_stem_tile_kernels_agree_with_the_one_tile_kernel(case, tiles):
+    """vt_stem.hip: T tiles per workgroup + transposed product (round 3) against the round-1 kernel (VT_STEM_TILES=0), both
+    passes: raw conv + statistics, and affine + ReLU.  Same MFMA dot products -> y bit-equal; the statistics are float
+    sums of the same bf16 values in another order."""
     B, Cin, Cout, k, s, H, W = case
     x = filler.tensor(f"x{case}", (B, Cin, H, W))
     w = filler.tensor(f"w{case}", (Cout, Cin, k, k), scale=(2.0 / (Cin * k * k)) ** 0.5)
     xd, wd = nhwc(x, N.VT_BF16), krsc(w, N.VT_BF16)
-    y = torch.empty((B, H, W, Cout), device="cuda", dtype=torch.bfloat16)
-    st_a, st_b = N.stats_buffer(Cout), N.stats_buffer(Cout)
-    d = conv_desc(N.VT_BF16, xd, Cin, Cout, k, s, 1, Cout, flags=N.VT_CONV_STATS)
-    N.check(N.lib().vt_conv_igemm(C.byref(d), vp(xd), vp(wd), vp(y), None, None, None, vp(st_a), stream()))
-    d = conv_desc(N.VT_BF16, xd, Cin, Cout, k, s, 1, Cout, flags=N.VT_CONV_STATS | N.VT_CONV_NOSTORE)
-    N.check(N.lib().vt_conv_igemm(C.byref(d), vp(xd), vp(wd), None, None, None, None, vp(st_b), stream()))
-    assert torch.equal(N.stats_decode(st_a), N.stats_decode(st_b))
+    sc = filler.tensor("stem_sc", (Cout,)).cuda().float().abs() + 0.5
+    sf = filler.tensor("stem_sf", (Cout,)).cuda().float()
+    ldy = Cout + 8  # a channel slice of a wider buffer
+    out = {}
+    try:
+        for t in (0, tiles):
+            N.set_knob("VT_STEM_TILES", t)
+            yb = torch.full((B, H, W, ldy), 7.0, device="cuda", dtype=torch.bfloat16)
+            ya = torch.full((B, H, W, ldy), 7.0, device="cuda", dtype=torch.bfloat16)
+            st = N.stats_buffer(Cout)
+            d = conv_desc(N.VT_BF16, xd, Cin, Cout, k, s, 1, ldy, flags=N.VT_CONV_STATS)
+            N.check(N.lib().vt_conv_igemm(C.byref(d), vp(xd), vp(wd), vp(yb), None, None, None, vp(st), stream()))
+            name_s = N.last_kernel_name()
+            d = conv_desc(N.VT_BF16, xd, Cin, Cout, k, s, 1, ldy, flags=N.VT_CONV_AFFINE | N.VT_CONV_RELU)
+            N.check(N.lib().vt_conv_igemm(C.byref(d), vp(xd), vp(wd), vp(ya), vp(sc), vp(sf), None, None, stream()))
+            torch.cuda.synchronize()
+            out[t] = (yb, ya, N.stats_decode(st), name_s)
+    finally:
+        N.set_knob("VT_STEM_TILES", 4)
+    assert "stem_kernel" in out[0][3] and f"stem_t_kernel<{tiles}" in out[tiles][3]
+    assert torch.equal(out[0][0], out[tiles][0]) and torch.equal(out[0][1], out[tiles][1])
+    assert (out[0][0][..., Cout:] == 7.0).all() and (out[tiles][1][..., Cout:] == 7.0).all()  # nothing outside the slice
+    a, b = out[0][2], out[tiles][2]
+    assert ((a - b).abs() / (a.abs() + 1.0)).max().item() < 1e-5
+
+
+@pytest.mark.parametrize("case", [(2, 8, 32, 3, 1, 20, 13), (3, 8, 24, 3, 1, 17, 17), (2, 8, 32, 3, 1, 224, 224)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_stem_statistics_only_pass(case):
+    """VT_CONV_STATS | VT_CONV_NOSTORE (RGB stem kernels): the sums of the f32 accumulator (nothing is rounded because
+    nothing is stored), against float64 on the bf16 operands; y (NULL here) is never touched; anywhere else the flag is
+    refused."""
+    B, Cin, Cout, k, s, H, W = case
+    x = filler.tensor(f"x{case}", (B, Cin, H, W))
+    w = filler.tensor(f"w{case}", (Cout, Cin, k, k), scale=(2.0 / (Cin * k * k)) ** 0.5)
+    ref = F.conv2d(rounded(x, N.VT_BF16).double(), rounded(w, N.VT_BF16).double(), None, s, 1)
+    r1, r2 = ref.sum((0, 2, 3)), (ref * ref).sum((0, 2, 3))
+    xd, wd = nhwc(x, N.VT_BF16), krsc(w, N.VT_BF16)
+    try:
+        for tiles in (4, 0):
+            N.set_knob("VT_STEM_TILES", tiles)
+            st = N.stats_buffer(Cout)
+            d = conv_desc(N.VT_BF16, xd, Cin, Cout, k, s, 1, Cout, flags=N.VT_CONV_STATS | N.VT_CONV_NOSTORE)
+            N.check(N.lib().vt_conv_igemm(C.byref(d), vp(xd), vp(wd), None, None, None, None, vp(st), stream()))
+            got = N.stats_decode(st).cpu()
+            np.testing.assert_allclose(got[0], r1, rtol=1e-5, atol=1e-5 * float(r2.max()) ** 0.5 * (B * H * W) ** 0.5)
+            np.testing.assert_allclose(got[1], r2, rtol=1e-5)
+    finally:
+        N.set_knob("VT_STEM_TILES", 4)
     # not the stem shape class: refused, not silently stored
     x2 = nhwc(filler.tensor("xns", (1, 16, 8, 8)), N.VT_BF16)
     w2 = krsc(filler.tensor("wns", (16, 16, 3, 3)), N.VT_BF16)
