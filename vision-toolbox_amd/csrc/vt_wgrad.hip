@@ -35,6 +35,7 @@ struct WgradArgs {
     float* dw;
     int B, Hi, Wi, Cin, ldx, Ho, Wo, sh, sw, h0, w0, Cout, ldy, ntaps;
     int M, Ktot, ldgw, tiles_n, tiles_k, chunk, ablate;
+    int split, xcds;   // pixel splits; 8 = XCD-blocked item order (vt_xcd_item), 1 = identity
     float* slab;       // partial tiles go to slab[blockIdx.y * slab_stride + ...] with plain stores (no atomics)
     long slab_stride;  // elements per pixel split: Cout * ldgw
     unsigned magic_w, magic_h;  // ceil(2^32 / Wo), ceil(2^32 / Ho): exact n / d for n < 2^16
@@ -95,9 +96,14 @@ __global__ void __launch_bounds__(256 * G) wgrad_kernel(const WgradArgs p) {
     const int grp = gwave >> 2;       // wave group (pixel-step phase)
     const int wave = gwave & 3;       // wave inside the group
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile_n = blockIdx.x % p.tiles_n, tile_k = blockIdx.x / p.tiles_n;
+    // item = (pixel split, tile), tiles fastest: the workgroups of one XCD share a few pixel splits' rows of dz and x
+    const unsigned item = vt_xcd_item(blockIdx.x, gridDim.x, p.xcds);
+    const int ntile = p.tiles_n * p.tiles_k;
+    if (item >= (unsigned)(ntile * p.split)) return;
+    const int bsplit = (int)(item / (unsigned)ntile), btile = (int)(item - (unsigned)bsplit * ntile);
+    const int tile_n = btile % p.tiles_n, tile_k = btile / p.tiles_n;
     const int n0 = tile_n * 128, k0 = tile_k * 128;
-    const int m_begin = blockIdx.y * p.chunk;
+    const int m_begin = bsplit * p.chunk;
     const int m_end = min(p.M, m_begin + p.chunk);
     if (m_begin >= m_end) return;
 
@@ -133,17 +139,42 @@ __global__ void __launch_bounds__(256 * G) wgrad_kernel(const WgradArgs p) {
     const int cc = kc - tap * p.Cin;
     const int2 dd = sTap[tap];
 
-    int mrow[2], pb[2], pi[2], pj[2];
+    // Per-lane stream state of the two DMA instructions a wave issues per operand and stage: the output pixel mrow, its
+    // element offset in dz, and (gather form) the scaled coordinates hs = row * sh, ws = column * sw of the pixel with
+    // the element offset of input pixel (b, hs, ws).  Everything advances by ADDITIONS: round 2 advanced (b, row, column)
+    // by multiply-high quotients and rebuilt both addresses with 64-bit multiplies at every issue -- 23 quarter-rate
+    // integer multiplies among ~80 vector instructions per wave and step against 16 MFMAs, and the loop was bound by
+    // vector issue, not by the transposing reads (rocprofv3 PMC at 256 -> 256 @14x14: SQ_INSTS_VALU 24.8 M for 3.6 M
+    // MFMAs, LDS array 16 % busy, no bank conflicts).
+    constexpr int PKG = PK * G;
+    const int WoS = p.Wo * p.sw, HoS = p.Ho * p.sh;
+    const int qW = PKG / p.Wo, rW = PKG - qW * p.Wo;  // PKG pixels = qW rows + rW columns
+    const int qH = qW / p.Ho, rH = qW - qH * p.Ho;    // qW rows   = qH images + rH rows
+    const int adv_w = rW * p.sw, adv_h = rH * p.sh;
+    const int d0 = ((qH * p.Hi + rH * p.sh) * p.Wi + rW * p.sw) * p.ldx;  // offset deltas: PKG pixels ahead
+    const int d1 = (p.sh * p.Wi - WoS) * p.ldx;                           //   a column wrap
+    const int d2 = (p.Hi - HoS) * p.Wi * p.ldx;                           //   a row wrap (next image)
+    const int tap_h = p.h0 + dd.x, tap_w = p.w0 + dd.y;
+    const int tap_off = (tap_h * p.Wi + tap_w) * p.ldx + cc;              // this lane's tap and channel
+    const int zadv = PKG * p.ldy, xadv_unit = PKG * p.ldx;
+    int mrow[2], hs[2], ws[2], xoff[2], zoff[2];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m_begin + grp * PK + RPI * (wave + 4 * i) + rloc;
         mrow[i] = m;
-        const int mm = min(m, p.M - 1);
-        pb[i] = mm / HoWo;
-        const int rem = mm - pb[i] * HoWo;
-        pi[i] = rem / p.Wo;
-        pj[i] = rem - pi[i] * p.Wo;
+        zoff[i] = m * p.ldy + nn;  // (elements of dz < 2^31: vt_conv_wgrad)
+        if constexpr (kUnit) {
+            xoff[i] = m * p.ldx + cc;
+            hs[i] = ws[i] = 0;
+        } else {
+            const int mm = min(m, p.M - 1);
+            const int b_ = mm / HoWo;
+            const int rem = mm - b_ * HoWo;
+            const int i_ = rem / p.Wo, j_ = rem - i_ * p.Wo;
+            hs[i] = i_ * p.sh, ws[i] = j_ * p.sw;
+            xoff[i] = ((b_ * p.Hi + hs[i]) * p.Wi + ws[i]) * p.ldx;
+        }
     }
 
 #define VT_WG_ISSUE(st)                                                                           \
@@ -151,36 +182,34 @@ __global__ void __launch_bounds__(256 * G) wgrad_kernel(const WgradArgs p) {
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                           \
             const int jj = wave + 4 * i;                                                          \
             const bool mv = mrow[i] < m_end;                                                      \
-            const unsigned long pz = (unsigned long)(zg + ((long)mrow[i] * p.ldy + nn));          \
+            const unsigned long pz = (unsigned long)(zg + (unsigned)zoff[i]);                     \
             glds16((mv && nvalid) ? pz : zero_src, ring_base + (unsigned)((((st)*STAGE) * (int)sizeof(T)) + jj * 1024)); \
+            zoff[i] += zadv;                                                                      \
         }                                                                                         \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                           \
             const int jj = wave + 4 * i;                                                          \
             if constexpr (kUnit) {                                                                \
                 const bool xv = mrow[i] < m_end && kvalid;                                        \
-                const unsigned long px = (unsigned long)(xg + ((long)mrow[i] * p.ldx + cc));      \
+                const unsigned long px = (unsigned long)(xg + (unsigned)xoff[i]);                 \
                 glds16(xv ? px : zero_src,                                                        \
                        ring_base + (unsigned)((((st)*STAGE + TILE) * (int)sizeof(T)) + jj * 1024)); \
-                mrow[i] += PK * G;                                                                \
+                mrow[i] += PKG;                                                                   \
+                xoff[i] += xadv_unit;                                                             \
             } else {                                                                              \
-            const int hi = pi[i] * p.sh + p.h0 + dd.x;                                            \
-            const int wi = pj[i] * p.sw + p.w0 + dd.y;                                            \
-            const bool xv = mrow[i] < m_end && kvalid && (unsigned)hi < (unsigned)p.Hi &&         \
-                            (unsigned)wi < (unsigned)p.Wi;                                        \
-            const unsigned long px =                                                              \
-                (unsigned long)(xg + (((long)(pb[i] * p.Hi + hi) * p.Wi + wi) * p.ldx + cc));      \
-            glds16(xv ? px : zero_src,                                                            \
-                   ring_base + (unsigned)((((st)*STAGE + TILE) * (int)sizeof(T)) + jj * 1024));    \
-            mrow[i] += PK * G;                                                                    \
-            /* advance PK*G pixels: quotients by multiply-high (the `while` form cost two divergent     \
-               loops per row and step, up to 9 trips on the 7x7 maps) */                            \
-            pj[i] += PK * G;                                                                      \
-            const int qw = p.Wo == 1 ? pj[i] : (int)__umulhi((unsigned)pj[i], p.magic_w);         \
-            pj[i] -= qw * p.Wo;                                                                   \
-            pi[i] += qw;                                                                          \
-            const int qh = p.Ho == 1 ? pi[i] : (int)__umulhi((unsigned)pi[i], p.magic_h);         \
-            pi[i] -= qh * p.Ho;                                                                   \
-            pb[i] += qh;                                                                          \
+                const bool xv = mrow[i] < m_end && kvalid && (unsigned)(hs[i] + tap_h) < (unsigned)p.Hi && \
+                                (unsigned)(ws[i] + tap_w) < (unsigned)p.Wi;                       \
+                const unsigned long px = (unsigned long)(xg + (unsigned)(xoff[i] + tap_off));     \
+                glds16(xv ? px : zero_src,                                                        \
+                       ring_base + (unsigned)((((st)*STAGE + TILE) * (int)sizeof(T)) + jj * 1024)); \
+                mrow[i] += PKG;                                                                   \
+                /* PKG pixels ahead: at most one column wrap, then at most one row wrap (rH + 1 <= Ho) */ \
+                ws[i] += adv_w;                                                                   \
+                const bool c1 = ws[i] >= WoS;                                                     \
+                ws[i] -= c1 ? WoS : 0;                                                            \
+                hs[i] += adv_h + (c1 ? p.sh : 0);                                                 \
+                const bool c2 = hs[i] >= HoS;                                                     \
+                hs[i] -= c2 ? HoS : 0;                                                            \
+                xoff[i] += d0 + (c1 ? d1 : 0) + (c2 ? d2 : 0);                                    \
             }                                                                                     \
         }                                                                                         \
     } while (0)
@@ -305,9 +334,9 @@ __global__ void __launch_bounds__(256 * G) wgrad_kernel(const WgradArgs p) {
             const int n = n0 + h * ROWS + nrow, k = k0 + kcol;
             const int gq = ((nrow & 15) >> 2);  // the row's g at write time
             const float v = sAcc[nrow * 128 + (kcol ^ (gq << 4))];
-            if (n < p.Cout && k < p.Ktot && !p.ablate) {
+            if (n < p.Cout && k < p.Ktot && !(p.ablate & 1)) {
                 if (p.slab)
-                    p.slab[(long)blockIdx.y * p.slab_stride + (long)n * p.ldgw + k] = v;
+                    p.slab[(long)bsplit * p.slab_stride + (long)n * p.ldgw + k] = v;
                 else
                     atomicAdd(p.dw + ((long)n * p.ldgw + k), v);
             }
@@ -448,7 +477,9 @@ static int wgrad_impl(const vt_conv_desc* d, const void* x, const void* dz, floa
     a.slab_stride = slab_stride;
 
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)tiles, (unsigned)split);
+    a.split = (int)split;
+    a.xcds = VT_KNOB("VT_WGRAD_XCD", 8);
+    dim3 grid(vt_xcd_grid(tiles * split));
     const int stage = 2 * pk * 128 * vt_elem_size(d->dtype);  // 16 KiB
     const bool unit = d->ntaps == 1 && d->sh == 1 && d->sw == 1 && d->h0 + d->dh[0] == 0 && d->w0 + d->dw[0] == 0 &&
                       d->Ho == d->Hi && d->Wo == d->Wi;

@@ -27,6 +27,8 @@
 // rows and added with row-contiguous f32 atomics, as in vt_wgrad.hip.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "vt_common.h"
 
 #ifndef VT_WS_PD
@@ -46,6 +48,7 @@ struct WsArgs {
     unsigned magic_pw, magic_ph;  // ceil(2^32 / PW), ceil(2^32 / PH)  (PW, PH >= 2)
     short o[9];              // d_t - dmin
     int ntaps, tgn;          // taps (<= 9) and how many of them the first tap group owns (<= 5)
+    int split, xcds;         // pixel splits; 8 = XCD-blocked item order (vt_xcd_item), 1 = identity
     long rowx;               // elements between image rows of x (W*ldx for a dense tensor; larger for a row-parity view)
     float* slab;             // partial tiles go to slab[blockIdx.y * slab_stride + ...] with plain stores (no atomics)
     long slab_stride;        // elements per pixel split: Cout * ldgw
@@ -57,7 +60,8 @@ __device__ __attribute__((aligned(16))) unsigned int vt_ws_zero16[4];
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-__device__ __forceinline__ void glds16(unsigned long gsrc, unsigned lds_base) {
+__device__ __forceinline__ void glds16(unsigned long gsrc, unsigned lds_base_v) {
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_base_v);  // (wave-uniform by construction)
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
@@ -75,25 +79,36 @@ __device__ __forceinline__ void vm_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-struct Pos {  // a padded position, decomposed; advanced 32 positions per step
-    int b, i, j;
-    __device__ __forceinline__ void init(long P, int S, int PW) {
+struct Pos {  // a padded position, decomposed, and the element offset of its pixel; advanced 32 positions per step
+    int b, i, j, off;
+    __device__ __forceinline__ void init(long P, int S, int PW, int H, long row, int ld) {
         long bb = P / S;
         long rem = P - bb * S;
         if (rem < 0) rem += S, --bb;
         b = (int)bb;
         i = (int)(rem / PW);
         j = (int)(rem - (long)i * PW);
+        off = (int)(((long)b * H + i) * row + (long)j * ld);  // (mod 2^32 while b < 0; exact for every real pixel)
     }
-    // multiply-high quotients instead of `while` loops (divergent, one trip per wrapped row)
-    __device__ __forceinline__ void advance32(int PH, int PW, unsigned magic_pw, unsigned magic_ph) {
-        j += 32;
-        const int qw = (int)__umulhi((unsigned)j, magic_pw);
-        j -= qw * PW;
-        i += qw;
-        const int qh = (int)__umulhi((unsigned)i, magic_ph);
-        i -= qh * PH;
-        b += qh;
+};
+// The advance is additions only: round 2 recomputed (b, i, j) by multiply-high quotients and the offset by 64-bit
+// multiplies every step -- 18 quarter-rate integer multiplies among ~100 vector instructions per wave and step, against
+// 20 MFMAs: the loop was bound by vector issue (rocprofv3 PMC, 128 -> 128 @28x28: SQ_INSTS_VALU 22.4 M, SQ_INSTS_MFMA
+// 3.9 M, LDS array 16 % busy, no bank conflicts), not by the transposing reads.
+struct PosStep {
+    int q32, r32;    // 32 = q32 * PW + r32
+    int c0, c1, c2;  // offset deltas: 32 positions ahead | a column wrap | a row wrap (next image)
+    __device__ __forceinline__ void init(int PH, int PW, int H, long row, int ld) {
+        q32 = 32 / PW, r32 = 32 - q32 * PW;
+        c0 = (int)(r32 * (long)ld + q32 * row);
+        c1 = (int)(row - (long)PW * ld);
+        c2 = (int)((long)(H - PH) * row);
+    }
+    __device__ __forceinline__ void advance(Pos& p, int PH, int PW) const {
+        p.j += r32, p.i += q32, p.off += c0;
+        if (p.j >= PW) p.j -= PW, ++p.i, p.off += c1;
+        if (p.i >= PH) p.i -= PH, ++p.b, p.off += c2;
+        if (p.i >= PH) p.i -= PH, ++p.b, p.off += c2;  // (q32 + 1 < 2 PH: launch_ws_taps)
     }
 };
 
@@ -117,8 +132,8 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
     constexpr int WI = WIDE ? 2 * FI : FI, WJ = WIDE ? FJ / 2 : FJ;  // fragments per wave
     constexpr int TG = 5;  // taps per group (the second group owns 4)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sDz = smem;                  // [NS][32 rows][128 B]
-    char* sX = smem + NS * kDzSlot;    // [RX rows][128 B]
+    char* sX = smem;                   // [RX rows][128 B]: at LDS address 0, so a masked ring offset IS the address
+    char* sDz = smem + p.RX * 128;     // [NS][32 rows][128 B]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -127,9 +142,13 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
     const int rbase = WIDE ? 0 : wn * 16 * FI;        // first output channel of this wave inside the tile
     const int cbase = WIDE ? wave * 16 : wc * 16 * FJ;  // first input channel
     const int ntl = tg ? p.ntaps - p.tgn : p.tgn;  // taps this wave owns
-    const int tile_n = blockIdx.x % p.tiles_n, tile_c = blockIdx.x / p.tiles_n;
+    const unsigned item = vt_xcd_item(blockIdx.x, gridDim.x, p.xcds);  // (pixel split, tile), tiles fastest
+    const int ntile = p.tiles_n * p.tiles_c;
+    if (item >= (unsigned)(ntile * p.split)) return;
+    const int bsplit = (int)(item / (unsigned)ntile), btile = (int)(item - (unsigned)bsplit * ntile);
+    const int tile_n = btile % p.tiles_n, tile_c = btile / p.tiles_n;
     const int n0 = tile_n * NI, c0 = tile_c * NC;
-    const long Pbeg = (long)blockIdx.y * p.chunk;
+    const long Pbeg = (long)bsplit * p.chunk;
     const long Pend = min((long)p.NP, Pbeg + p.chunk);
     if (Pbeg >= Pend) return;
     const int nsteps = (int)((Pend - Pbeg + 31) / 32);
@@ -149,19 +168,21 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
     const int src_ld = tg ? p.ldx : p.ldy;
     const long src_row = tg ? p.rowx : (long)p.W * p.ldy;
     Pos ps;
-    long Ps = Pbeg + (tg ? p.dmin : 0) + 8 * wave + r8;  // this lane's stream position
-    ps.init(Ps, p.S, p.PW);
+    PosStep pst;
+    pst.init(p.PH, p.PW, p.H, src_row, src_ld);
+    const long Ps0 = Pbeg + (tg ? p.dmin : 0) + 8 * wave + r8;  // this lane's stream position
+    ps.init(Ps0, p.S, p.PW, p.H, src_row, src_ld);
+    int left = tg ? 0x7fffffff : (int)(Pend - Ps0);  // dz: positions until the split's end (x: never runs out)
     int nissued = 0;  // DMA instructions this wave has issued (x: ring chunk index)
 
     // dz rows beyond the split's end must be zero; x rows may be anything there (times dz = 0)
 #define VT_WS_ISSUE(dst)                                                                          \
     do {                                                                                          \
-        const bool ok = col_ok && (tg || Ps < Pend) && (unsigned)ps.b < (unsigned)p.B && ps.i < p.H && ps.j < p.W; \
-        const long eoff = ((long)ps.b * p.H + ps.i) * src_row + (long)ps.j * src_ld;             \
-        glds16(ok ? (unsigned long)(src_base + eoff) : zero_src, (dst) + (unsigned)wave * 1024u); \
+        const bool ok = col_ok && left > 0 && (unsigned)ps.b < (unsigned)p.B && ps.i < p.H && ps.j < p.W; \
+        glds16(ok ? (unsigned long)(src_base + (unsigned)ps.off) : zero_src, (dst) + (unsigned)wave * 1024u); \
         ++nissued;                                                                                \
-        Ps += 32;                                                                                 \
-        ps.advance32(p.PH, p.PW, p.magic_pw, p.magic_ph);                                         \
+        if (!tg) left -= 32;                                                                      \
+        pst.advance(ps, p.PH, p.PW);                                                              \
     } while (0)
 #define VT_WS_ISSUE_STEP(slot)                                                                    \
     do {                                                                                          \
@@ -208,54 +229,71 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
         if (s < nsteps) VT_WS_ISSUE_STEP(s);
 
     int cur = 0, nxt = PD % NS;
-    for (int s = 0; s < nsteps; ++s) {
-        // dz(s) and x chunk s+NH must have landed; the PD-1 younger steps (1 instruction per wave
-        // each) may stay in flight
-        const int younger = min(PD - 1, nsteps - 1 - s);
-        switch (younger) {  // (the count is an immediate of s_waitcnt)
-            case 0: vm_wait<0>(); break;
-            case 1: vm_wait<1>(); break;
-            case 2: vm_wait<2>(); break;
-            case 3: vm_wait<3>(); break;
-            case 4: vm_wait<4>(); break;
-            default: vm_wait<5>(); break;
-        }
+    // one step: NTL = the taps this wave owns, a compile-time count (the guarded `if (tt < ntl)` of round 2 kept every
+    // tap's reads behind the previous tap's MFMAs); YOUNGER = DMA steps that may stay in flight across the wait
+    auto step = [&](auto ntl_c, auto younger_c, int s) {
+        constexpr int NTL = decltype(ntl_c)::value;
+        // dz(s) and x chunk s+NH must have landed; the younger steps (1 instruction per wave each) may stay in flight
+        vm_wait<decltype(younger_c)::value>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s + PD < nsteps) VT_WS_ISSUE_STEP(nxt);
 
+        // all of the step's fragment reads first (18 in flight), the DMA issue's address arithmetic under their latency,
+        // then the MFMAs behind counted waits
         const char* dzs = sDz + cur * kDzSlot;
-        bf16x8 af[WI];
+        s16x4 alo[WI], ahi[WI];
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(dzs + a_off[i]));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(dzs + a_off[i] + 16 * 128));
-            af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            alo[i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(dzs + a_off[i]));
+            ahi[i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(dzs + a_off[i] + 16 * 128));
         }
         const unsigned sb = (unsigned)s * 4096u;
+        s16x4 blo[NTL > 0 ? NTL : 1][WJ], bhi[NTL > 0 ? NTL : 1][WJ];
 #pragma unroll
-        for (int tt = 0; tt < TG; ++tt) {
-            if (tt < ntl) {
-                const unsigned lo_o = (sb + b_off[tt]) & xmask;
-                const unsigned hi_o = (lo_o + 16u * 128u) & xmask;
-                bf16x8 bf[WJ];
+        for (int tt = 0; tt < NTL; ++tt) {
+            const unsigned lo_o = (sb + b_off[tt]) & xmask;
+            const unsigned hi_o = (lo_o + 16u * 128u) & xmask;
 #pragma unroll
-                for (int j = 0; j < WJ; ++j) {
-                    // the next 16 input channels sit one 32-byte group over: chunk index ^ 2
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sX + (lo_o ^ (32u * j))));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sX + (hi_o ^ (32u * j))));
-                    bf[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                }
+            for (int j = 0; j < WJ; ++j) {
+                // the next 16 input channels sit one 32-byte group over: chunk index ^ 2
+                blo[tt][j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sX + (lo_o ^ (32u * j))));
+                bhi[tt][j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sX + (hi_o ^ (32u * j))));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + PD < nsteps) VT_WS_ISSUE_STEP(nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 af[WI];
+#pragma unroll
+        for (int i = 0; i < WI; ++i)
+            af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(alo[i], ahi[i], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+        for (int tt = 0; tt < NTL; ++tt) {
+#pragma unroll
+            for (int j = 0; j < WJ; ++j) {
+                const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(blo[tt][j], bhi[tt][j], 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                 for (int i = 0; i < WI; ++i)
-#pragma unroll
-                    for (int j = 0; j < WJ; ++j)
-                        acc[tt][i][j] =
-                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[tt][i][j], 0, 0, 0);
+                    acc[tt][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[tt][i][j], 0, 0, 0);
             }
         }
         cur = (cur + 1 == NS) ? 0 : cur + 1;
         nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+    };
+    auto run = [&](auto ntl_c) {
+        using Y = std::integral_constant<int, PD - 1>;
+        using Z = std::integral_constant<int, 0>;
+        int s = 0;
+        for (; s + PD - 1 < nsteps; ++s) step(ntl_c, Y{}, s);  // PD - 1 younger steps exist
+        for (; s < nsteps; ++s) step(ntl_c, Z{}, s);            // the last PD - 1 steps: wait for everything
+    };
+    switch (ntl) {  // 9 taps: 5 | 4; the stride-2 views: 2 | 2 and 1 | 1 (launch_ws_taps)
+        case 5: run(std::integral_constant<int, 5>{}); break;
+        case 4: run(std::integral_constant<int, 4>{}); break;
+        case 3: run(std::integral_constant<int, 3>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        default: run(std::integral_constant<int, 0>{}); break;  // (a group without taps still brings in its operand)
     }
 #undef VT_WS_ISSUE
 #undef VT_WS_ISSUE_STEP
@@ -293,7 +331,7 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
                     col = (long)td * p.cin_dst + (c0 + c - blk * p.cblk);
                 }
                 if (p.slab)
-                    p.slab[(long)blockIdx.y * p.slab_stride + (long)(n0 + n) * p.ldgw + col] = sAcc[img * IMG + n * PITCH + c];
+                    p.slab[(long)bsplit * p.slab_stride + (long)(n0 + n) * p.ldgw + col] = sAcc[img * IMG + n * PITCH + c];
                 else
                     atomicAdd(p.dw + ((long)(n0 + n) * p.ldgw + col), sAcc[img * IMG + n * PITCH + c]);
             }
@@ -311,7 +349,9 @@ constexpr int kWsPD = VT_WS_PD;
 static_assert(kWsPD >= 2 && kWsPD <= 6, "vm_wait switch covers PD - 1 <= 5");
 
 template <int FI, int FJ, bool WIDE = false>
-int launch_ws(const WsArgs& a, long split, hipStream_t st) {
+int launch_ws(WsArgs& a, long split, hipStream_t st) {
+    a.split = (int)split;
+    a.xcds = VT_KNOB("VT_WGRAD_XCD", 8);
     constexpr int PD = kWsPD;
     const int rings = (PD + 1) * kDzSlot + a.RX * 128;
     const int image = 2 * 32 * FI * (32 * FJ + 4) * 4;
@@ -322,7 +362,7 @@ int launch_ws(const WsArgs& a, long split, hipStream_t st) {
         if (rc != VT_OK) return rc;
     }
     vt_note_kernel("wgrad_span_kernel<%d,%d,%d%s>", FI, FJ, PD, WIDE ? ",wide" : "");
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.tiles_n * a.tiles_c), (unsigned)split), dim3(512), smem, st, a);
+    hipLaunchKernelGGL(kern, dim3(vt_xcd_grid((long)a.tiles_n * a.tiles_c * split)), dim3(512), smem, st, a);
     VT_CHECK_LAUNCH("vt_conv_wgrad(span)");
     return VT_OK;
 }
@@ -343,6 +383,7 @@ int launch_ws_taps(WsArgs& a, int ntaps, const int* eh, const int* ew, hipStream
     a.magic_ph = (unsigned)((0x100000000ull + a.PH - 1) / a.PH);
     const long NP = (long)a.B * a.S;
     if (NP > 0x7ffffff0L || a.PW < 2 || a.PH < 2) return -1;
+    if (32 / a.PW + 1 >= 2 * a.PH) return -1;  // (the position advance of the kernel wraps at most two rows of images)
     a.NP = (int)NP;
     a.ntaps = ntaps, a.tgn = (ntaps + 1) / 2;
     int dmin = 1 << 30, dmax = -(1 << 30), off[9];
