@@ -869,6 +869,21 @@ __global__ void __launch_bounds__(kThreads)
 nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int C, long HW, int Cpad, long total) {
     for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
         const long b = i / HW, hw = i - b * HW;
+        if constexpr (sizeof(T) == 2) {
+            // the image batch of a step (3 -> 8 channels, 12.8 M pixels at batch 256): one 16-byte store per pixel
+            // instead of eight 2-byte ones (175 -> 70 us)
+            if (Cpad == 8) {
+                unsigned short h[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    h[c] = c < C ? __builtin_bit_cast(unsigned short, from_float<T>(x[(b * C + c) * HW + hw])) : (unsigned short)0;
+                uint4 v;
+                v.x = h[0] | ((unsigned)h[1] << 16), v.y = h[2] | ((unsigned)h[3] << 16);
+                v.z = h[4] | ((unsigned)h[5] << 16), v.w = h[6] | ((unsigned)h[7] << 16);
+                *(uint4*)(y + i * 8) = v;
+                continue;
+            }
+        }
         for (int c = 0; c < Cpad; ++c) {
             const float v = c < C ? x[(b * C + c) * HW + hw] : 0.f;
             y[i * Cpad + c] = from_float<T>(v);
