@@ -461,7 +461,14 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) atomicAdd(&sRed[(16 * nt + 4 * q + r) * K + 16 * ct + pl], dwacc[nt][ct][r]);
         __syncthreads();
-        for (int i = tid; i < N * K; i += 256) {
+        // every workgroup adds its image to the SAME N x K addresses and all of them finish together: each starts at its
+        // own 256-element chunk, so that the adds do not queue up address by address
+        constexpr int NCH = N * K / 256;
+        const int rot = (int)((blockIdx.x * 7u) % (unsigned)NCH);
+        for (int j = 0; j < NCH; ++j) {
+            int ch = j + rot;
+            ch -= ch >= NCH ? NCH : 0;
+            const int i = ch * 256 + tid;
             const int n = i / K, c = i - n * K;
             const int g = n >= N0;
             float* dst = a.dw[g];

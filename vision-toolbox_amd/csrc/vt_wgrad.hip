@@ -329,7 +329,14 @@ __global__ void __launch_bounds__(256 * G) wgrad_kernel(const WgradArgs p) {
             __syncthreads();
         }
         constexpr int ROWS = 128 / HALVES;
-        for (int idx = tid; idx < ROWS * 128; idx += 256 * G) {
+        // the pixel splits of a tile finish together and add to the same addresses: each starts at its own rows, so that
+        // the adds of different splits do not queue up on one address at a time
+        constexpr int NCHK = ROWS * 128 / (256 * G);
+        const int rot = (int)(((unsigned)bsplit * 5u) % (unsigned)NCHK);
+        for (int jc = 0; jc < NCHK; ++jc) {
+            int chk = jc + rot;
+            chk -= chk >= NCHK ? NCHK : 0;
+            const int idx = chk * (256 * G) + tid;
             const int nrow = idx >> 7, kcol = idx & 127;
             const int n = n0 + h * ROWS + nrow, k = k0 + kcol;
             const int gq = ((nrow & 15) >> 2);  // the row's g at write time
