@@ -197,9 +197,14 @@ int vt_stem_bn_bwd_combine(int32_t C, int32_t cin, const float* gzx, const float
                            int32_t fixed, void* stream);
 /* `fixed` bit 1 of vt_stem_bn_bwd_reduce: `z` holds the unit's OUTPUT y = relu(z*scale + shift) (the pre-activation was
  * never stored: forward = a VT_CONV_STATS|VT_CONV_NOSTORE pass + a pass with the affine/ReLU epilogue).  The mask is
- * y > 0, z is recovered as (y - shift) / scale where the mask is on, and the 32 z rows of gzx hold the correlations of the
- * 27 im2col patch values with the tap-shifted x instead; vt_stem_bn_bwd_combine_y then forms Z = W P with `w` the bf16
- * filter image [C][9][8] the forward conv read, and adds dW like vt_stem_bn_bwd_combine. */
+ * y > 0; the reduction then leaves `sums` entry 1 (sum g * xhat) ZERO, and vt_stem_bn_bwd_s2 fills it from the
+ * correlations before vt_bn_bwd_finalize: z is linear in the 27 im2col patch values, so sum g*z = sum_i w[n][i] G[n][i]
+ * exactly -- nothing is recovered from the rounded y.  The 32 z rows of gzx hold the correlations of the patch values
+ * with the tap-shifted x instead; vt_stem_bn_bwd_combine_y then forms Z = W P with `w` the bf16 filter image [C][9][8]
+ * the forward conv read, and adds dW like vt_stem_bn_bwd_combine.
+ * Order: reduce(fixed | 2) -> s2 -> vt_bn_bwd_finalize -> combine_y. */
+int vt_stem_bn_bwd_s2(int32_t C, const float* gzx, const void* w, const float* mean, const float* invstd, float* sums,
+                      int32_t fixed, void* stream);
 int vt_stem_bn_bwd_combine_y(int32_t C, int32_t cin, const float* gzx, const float* coef, const void* w, float* dw,
                              int32_t fixed, void* stream);
 
@@ -382,6 +387,7 @@ enum vt_op_kind {
     VT_OP_PW_APPLY,         /* vt_pw_fwd_apply */
     VT_OP_PW_REDUCE,        /* vt_pw_bwd_reduce */
     VT_OP_PW_BWD,           /* vt_pw_bwd_apply */
+    VT_OP_STEM_BWD_S2,      /* vt_stem_bn_bwd_s2 */
     VT_OP_KIND_END
 };
 

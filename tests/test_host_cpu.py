@@ -155,7 +155,7 @@ def test_cspdarknet53_program_structure():
     assert p.n_units == 67
     # the stem unit's backward is ONE streaming pass (BatchNorm reduction + filter-gradient correlations) and a
     # combine kernel: no dz, no bn_bwd_reduce / bn_bwd_apply / conv_wgrad for it (vt_stem_bwd.hip)
-    assert h["stem_bwd_reduce"] == 1 and h["stem_bwd_combine"] == 1
+    assert h["stem_bwd_reduce"] == 1 and h["stem_bwd_combine"] == 1 and h["stem_bwd_s2"] == 1
     # 17 of the 38 1x1 units run as pointwise passes that recompute z (vt_pointwise.hip: the 32 / 64 / 128-channel ones
     # of stages 0-2), conv1 | conv2 of stages 0 and 1 as ONE two-group launch each: 15 launches per pass
     pw_units, pw_launches = 17, 15

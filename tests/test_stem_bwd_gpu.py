@@ -84,8 +84,9 @@ def test_stem_backward_matches_float64(B, H, W, lddy, ldz, relu, fixed):
 @pytest.mark.parametrize("B,H,W,lddy,ldz,relu", CASES)
 def test_stem_backward_from_the_units_output(B, H, W, lddy, ldz, relu, fixed):
     """`fixed` bit 1: the pass reads y = relu(z*scale + shift) (bf16) instead of z, which the forward pass never stored.
-    Mask = y > 0; the BatchNorm sums use z recovered from y; the b*Z term of dW uses the EXACT z = W * patch (Z = W P with
-    P the patch / tap-shifted-x correlations), so the float64 reference takes z from a float64 conv of the bf16 operands."""
+    Mask = y > 0; z is linear in the 3x3 patch, so sum g*xhat (vt_stem_bn_bwd_s2: from G = sum g x(p+t) and W) and the b*Z
+    term of dW (Z = W P with P the patch / tap-shifted-x correlations) use the EXACT z = W * patch: the float64 reference
+    takes z from a float64 conv of the bf16 operands.  Nothing is recovered from y: a scale of exactly 0 is as exact."""
     torch.manual_seed(B * 1000 + W + 7)
     dev = "cuda"
     Cc = 32
@@ -96,8 +97,9 @@ def test_stem_backward_from_the_units_output(B, H, W, lddy, ldz, relu, fixed):
     z_true = F.conv2d(x[..., :3].double().permute(0, 3, 1, 2),
                       wq[..., :3].double().reshape(Cc, 3, 3, 3).permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
     sc = torch.randn(Cc, device=dev) * 0.8
-    sc = torch.where(sc.abs() < 0.05, torch.full_like(sc, 0.05), sc)
+    sc[3] = 0.0  # a BatchNorm weight of exactly 0: y = relu(shift) says nothing about z
     sf = torch.randn(Cc, device=dev) * 0.5
+    sf[3] = 0.7
     yv = z_true.float() * sc + sf
     yw = torch.randn(B, H, W, ldz, device=dev).to(torch.bfloat16)
     off_dy, off_y = (lddy - Cc), (ldz - Cc) // 2 // 8 * 8
@@ -114,12 +116,13 @@ def test_stem_backward_from_the_units_output(B, H, W, lddy, ldz, relu, fixed):
     st = stream()
     N.check(lib.vt_stem_bn_bwd_reduce(N.VT_BF16, B, H, W, Cc, vp(x), vp(dy), lddy, vp(y), ldz, vp(sc), vp(sf), vp(mu),
                                       vp(istd), relu, vp(sums), vp(gzx), fixed | 2, st))
+    assert (N.stats_decode(sums)[1] == 0).all()  # left to vt_stem_bn_bwd_s2
+    N.check(lib.vt_stem_bn_bwd_s2(Cc, vp(gzx), vp(wq), vp(mu), vp(istd), vp(sums), fixed, st))
     N.check(lib.vt_stem_bn_bwd_combine_y(Cc, 3, vp(gzx), vp(coef), vp(wq), vp(dw), fixed, st))
     torch.cuda.synchronize()
     on = (y.float() > 0) if relu else torch.ones_like(y, dtype=torch.bool)
     g = torch.where(on, dy.double(), torch.zeros_like(dy, dtype=torch.float64))
-    z_rec = (y.double() - sf.double()) * (1.0 / sc).double()
-    ref_s = torch.stack([g.sum((0, 1, 2)), (g * (z_rec - mu.double())).sum((0, 1, 2)) * istd.double()])
+    ref_s = torch.stack([g.sum((0, 1, 2)), (g * (z_true - mu.double())).sum((0, 1, 2)) * istd.double()])
     a, b, d = (coef[i].double() for i in range(3))
     dz = a * g - b * z_true + d
     w = torch.zeros(32, 3, 3, 3, dtype=torch.float64, device=dev, requires_grad=True)

@@ -166,6 +166,9 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
             return vt_stem_bn_bwd_reduce(I[0], I[1], I[2], I[3], I[4], P[0], P[1], I[5], P[2], I[6], (const float*)P[3],
                                          (const float*)P[4], (const float*)P[5], (const float*)P[6], I[7], (float*)P[7],
                                          (float*)P[8], I[8], st);
+        case VT_OP_STEM_BWD_S2:  // ptr: gzx w mean invstd sums | i: C fixed
+            return vt_stem_bn_bwd_s2(I[0], (const float*)P[0], P[1], (const float*)P[2], (const float*)P[3], (float*)P[4], I[1],
+                                     st);
         case VT_OP_STEM_BWD_COMBINE:  // ptr: gzx coef dw [w: the reduction read y, not z] | i: C cin fixed
             if (P[3])
                 return vt_stem_bn_bwd_combine_y(I[0], I[1], (const float*)P[0], (const float*)P[1], P[3], (float*)P[2], I[2],

@@ -87,11 +87,13 @@ constexpr int kCols = 96;  // 3 filter rows x 4 pixels x 8 channels
 // FA = C / 16 (2 or 4)
 // FROM_Y (round 3): the unit's OUTPUT y = relu(z*scale + shift) is read instead of the pre-activation z, which the forward
 // pass then never stores (the stem conv runs twice: a statistics-only pass and a pass with the normalise + ReLU epilogue).
-//   * mask: y > 0;  z = (y - shift) / scale wherever the mask is on (all the reduction needs);
-//   * the correlation Z = sum z * x(p+t), which needs z everywhere, is replaced by P = sum patch(p) * x(p+t) with
-//     patch(p) the 27 input values under the 3x3 window -- z is LINEAR in the patch, so Z = W P (vt_stem_bn_bwd_combine_y).
-//     The 32-column block that held z holds the patch (27 values + 5 zeros), gathered from the x ring: same fragments,
-//     same MFMA count.
+//   * mask: y > 0 (the same predicate: y = relu(z*scale + shift));
+//   * z is LINEAR in the 27 input values under the 3x3 window (the patch), so neither of the two sums that contain z needs
+//     z itself:  sum g * z = sum_i W[n][i] * G[n][i]  with G = sum g * x(p+t), which the pass accumulates anyway
+//     (vt_stem_bn_bwd_s2: it writes sum g * xhat into `sums` before vt_bn_bwd_finalize -- nothing is recovered from the
+//     rounded y, and a BatchNorm weight of exactly 0 is as exact as any other), and  Z = sum z * x(p+t) = W P  with
+//     P = sum patch(p) * x(p+t) (vt_stem_bn_bwd_combine_y): the 32-column block that held z holds the patch (27 values +
+//     5 zeros), gathered from the x ring: same fragments, same MFMA count.
 template <int FA, bool FROM_Y>
 __global__ void __launch_bounds__(256, 2) stem_bwd_kernel(const SbArgs p) {
     static_assert(!FROM_Y || FA == 2, "the patch block is 32 columns wide");
@@ -118,7 +120,6 @@ __global__ void __launch_bounds__(256, 2) stem_bwd_kernel(const SbArgs p) {
     // ---- zero the tiles once (the unused / flag blocks stay zero) ----------------------------------
     for (int i = tid; i < 4 * TILE / 16; i += 256) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
     if (tid < 3 * C) sCoef[tid] = (tid < C ? p.scale : tid < 2 * C ? p.shift - C : p.mean - 2 * C)[tid];
-    if (tid < C) sCoef[3 * C + tid] = p.scale[tid] != 0.f ? 1.f / p.scale[tid] : 0.f;
 
     // ---- ring prologue: rows [Pbeg - halo, Pbeg + halo) ---------------------------------------------
     {
@@ -219,7 +220,7 @@ __global__ void __launch_bounds__(256, 2) stem_bwd_kernel(const SbArgs p) {
         // ---- elementwise: g, partial sums, park the rows --------------------------------------------
         char* tg_ = sG + (s & 1) * TILE;
         char* tz_ = sZ + (s & 1) * TILE;
-        float sc[8], sf[8], mu[8], rs[8];  // re-read every step: registers that the MFMA phase gets back
+        float sc[8], sf[8], mu[8];  // re-read every step: registers that the MFMA phase gets back
 #pragma unroll
         for (int h4 = 0; h4 < 2; ++h4) {
             const f32x4 a4 = *(const volatile f32x4*)(sCoef + chunk * 8 + 4 * h4);
@@ -228,10 +229,6 @@ __global__ void __launch_bounds__(256, 2) stem_bwd_kernel(const SbArgs p) {
             sc[4 * h4] = a4[0], sc[4 * h4 + 1] = a4[1], sc[4 * h4 + 2] = a4[2], sc[4 * h4 + 3] = a4[3];
             sf[4 * h4] = b4[0], sf[4 * h4 + 1] = b4[1], sf[4 * h4 + 2] = b4[2], sf[4 * h4 + 3] = b4[3];
             mu[4 * h4] = c4[0], mu[4 * h4 + 1] = c4[1], mu[4 * h4 + 2] = c4[2], mu[4 * h4 + 3] = c4[3];
-            if constexpr (FROM_Y) {
-                const f32x4 d4 = *(const volatile f32x4*)(sCoef + 3 * C + chunk * 8 + 4 * h4);
-                rs[4 * h4] = d4[0], rs[4 * h4 + 1] = d4[1], rs[4 * h4 + 2] = d4[2], rs[4 * h4 + 3] = d4[3];
-            }
         }
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
@@ -245,7 +242,7 @@ __global__ void __launch_bounds__(256, 2) stem_bwd_kernel(const SbArgs p) {
                 float zv;
                 if constexpr (FROM_Y) {
                     on = !p.relu || fz[e] > 0.f;          // fz holds y
-                    zv = (fz[e] - sf[e]) * rs[e];          // z wherever the mask is on
+                    zv = mu[e];                            // (sum g * xhat comes from G: vt_stem_bn_bwd_s2)
                 } else {
                     on = !p.relu || fmaf(fz[e], sc[e], sf[e]) > 0.f;
                     zv = fz[e];
@@ -351,7 +348,7 @@ __global__ void __launch_bounds__(256, 2) stem_bwd_kernel(const SbArgs p) {
         for (int e = 0; e < 8; ++e) {
             const int c = chunk * 8 + e;
             vt_stat_add(p.sums, ((long)srep * 2 + 0) * C + c, s1[e]);
-            vt_stat_add(p.sums, ((long)srep * 2 + 1) * C + c, s2[e] * p.invstd[c]);
+            if constexpr (!FROM_Y) vt_stat_add(p.sums, ((long)srep * 2 + 1) * C + c, s2[e] * p.invstd[c]);
         }
     }
 }
@@ -419,6 +416,40 @@ __global__ void stem_bwd_combine_y_kernel(const float* __restrict__ gzx, const f
     dw[idx] += (float)v;
 }
 
+// FROM_Y: sums[1][n] = invstd_n * (sum_i w[n][i] G[n][i] - mean_n * sum g)   (= sum g * xhat, see the kernel's header)
+__global__ void stem_bwd_s2_kernel(const float* __restrict__ gzx, const bf16_t* __restrict__ w, const float* __restrict__ mean,
+                                   const float* __restrict__ invstd, float* __restrict__ sums, int C, int fixed) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= C) return;
+    const int rows = 2 * C + 16;
+    double dot = 0.0;
+    for (int i = 0; i < 27; ++i) {
+        const int t = i / 3, c = i - 3 * t;
+        const int col = (t / 3) * 32 + (t % 3) * 8 + c;
+        double v = 0.0;
+        if (fixed) {
+            const long long* q = (const long long*)gzx;
+            long long h = 0, l = 0;
+            for (int r = 0; r < kGzxReplicas; ++r) {
+                const long e = (long)r * rows * kCols + (long)n * kCols + col;
+                h += q[2 * e], l += q[2 * e + 1];
+            }
+            v = (double)h * 4096.0 + (double)l * (1.0 / 8589934592.0);
+        } else {
+            for (int r = 0; r < kGzxReplicas; ++r) v += (double)gzx[(long)r * rows * kCols + (long)n * kCols + col];
+        }
+        dot += (double)(float)w[(long)n * 72 + t * 8 + c] * v;
+    }
+    const double s1 = vt_stat_sum(sums, n, 2L * C);
+    const double s2 = (double)invstd[n] * (dot - (double)mean[n] * s1);
+    // (the entry is still zero: the reduction left sum g * xhat to this kernel.  Two limbs as vt_stat_add, from a double.)
+    const double hf = trunc(s2 * (1.0 / 4096.0));
+    const double rem = s2 - hf * 4096.0;
+    long long* q = (long long*)sums + 2 * ((long)C + n);
+    q[0] = (long long)hf;
+    q[1] = __double2ll_rn(rem * 8589934592.0);
+}
+
 }  // namespace
 
 extern "C" {
@@ -481,6 +512,15 @@ int vt_stem_bn_bwd_combine(int32_t C, int32_t cin, const float* gzx, const float
     hipLaunchKernelGGL(stem_bwd_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, gzx, coef, C,
                        cin, dw, fixed ? 1 : 0);
     VT_CHECK_LAUNCH("vt_stem_bn_bwd_combine");
+    return VT_OK;
+}
+
+int vt_stem_bn_bwd_s2(int32_t C, const float* gzx, const void* w, const float* mean, const float* invstd, float* sums,
+                      int32_t fixed, void* stream) {
+    VT_REQUIRE(C == 32 && gzx && w && mean && invstd && sums, VT_ERR_INVALID, "vt_stem_bn_bwd_s2: bad argument");
+    hipLaunchKernelGGL(stem_bwd_s2_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, gzx, (const bf16_t*)w, mean, invstd,
+                       sums, C, (fixed & 1) ? 1 : 0);
+    VT_CHECK_LAUNCH("vt_stem_bn_bwd_s2");
     return VT_OK;
 }
 

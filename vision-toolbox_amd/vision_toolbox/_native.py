@@ -88,7 +88,8 @@ VT_OP_MAX_PTR, VT_OP_MAX_INT, VT_OP_MAX_FLT, VT_MAX_BASES = 16, 110, 8, 16
     OP_PW_APPLY,
     OP_PW_REDUCE,
     OP_PW_BWD,
-) = range(1, 36)
+    OP_STEM_BWD_S2,
+) = range(1, 37)
 OP_SIDE_STREAM = 0x10000  # OR-ed into Op.kind: enqueue on the side stream
 
 OP_NAMES = {
@@ -127,6 +128,7 @@ OP_NAMES = {
     OP_PW_APPLY: "pw_apply",
     OP_PW_REDUCE: "pw_reduce",
     OP_PW_BWD: "pw_bwd",
+    OP_STEM_BWD_S2: "stem_bwd_s2",
 }
 
 
@@ -206,6 +208,7 @@ SYMBOLS = {
     "vt_stem_bn_bwd_reduce": (_i32, [_i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
     "vt_stem_bn_bwd_combine": (_i32, [_i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "vt_stem_bn_bwd_combine_y": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "vt_stem_bn_bwd_s2": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "vt_bn_act_bwd_apply": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "vt_pw_supported": (_i32, [_i32, _i32, _i32, _i32]),
     "vt_pw_fwd_stats": (_i32, [C.POINTER(PwDesc), C.POINTER(_vp), _vp]),

@@ -641,6 +641,9 @@ class Builder:
                     self.emit(N.OP_STEM_BWD_REDUCE,
                               [x.addr(), dy.addr(), zy.addr(), cp[0], cp[1], cp[2], cp[3], self.bp(sums), self.bp(gzx)],
                               [dt, B, x.H, x.W, Cout, dy.ld, zy.ld, int(relu), int(self.deterministic) | (2 if stem_y else 0)])
+                    if stem_y:  # sum g * xhat from the correlations (z is linear in the patch): nothing recovered from y
+                        self.emit(N.OP_STEM_BWD_S2, [self.bp(gzx), wptr, cp[2], cp[3], self.bp(sums)],
+                                  [Cout, int(self.deterministic)])
                     bcoef = self.f32(3 * Cout, "bwdcoef")
                     self.emit(N.OP_BN_BWD_FINALIZE,
                               [self.bp(sums), cp[0], cp[2], cp[3], self.pgrad(norm.weight), self.pgrad(norm.bias),
