@@ -443,9 +443,13 @@ __global__ void stem_bwd_s2_kernel(const float* __restrict__ gzx, const bf16_t* 
     const double s1 = vt_stat_sum(sums, n, 2L * C);
     const double s2 = (double)invstd[n] * (dot - (double)mean[n] * s1);
     // (the entry is still zero: the reduction left sum g * xhat to this kernel.  Two limbs as vt_stat_add, from a double.)
+    long long* q = (long long*)sums + 2 * ((long)C + n);
+    if (!(fabs(s2) < 1.0e30)) {  // non-finite (a poisoned sum g, a diverged G): poison this entry too (vt_common.h)
+        q[0] = kStatPoison, q[1] = 0;
+        return;
+    }
     const double hf = trunc(s2 * (1.0 / 4096.0));
     const double rem = s2 - hf * 4096.0;
-    long long* q = (long long*)sums + 2 * ((long)C + n);
     q[0] = (long long)hf;
     q[1] = __double2ll_rn(rem * 8589934592.0);
 }
