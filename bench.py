@@ -396,9 +396,12 @@ def main():
     ap.add_argument("--sync-bn", action="store_true",
                     help="SyncBatchNorm as in the reference recipe (configs/base.yaml:22); off for the headline "
                          "metric: 2 small sequential collectives per unit")
-    ap.add_argument("--main-priority", type=int, default=0,
+    ap.add_argument("--main-priority", type=int, default=None,
                     help="run the step on a torch stream of this priority (-1 = high): the filter-gradient side "
-                         "stream then only fills what the critical path leaves")
+                         "stream then only fills what the critical path leaves.  Default: -1 on one GPU (measured "
+                         "21.86 -> 21.71 and 22.14 -> 22.00 ms on two boxes), 0 with --gpus N > 1, where the RCCL "
+                         "kernels of the gradient exchange run on normal-priority streams and must not be starved "
+                         "by the step (not measurable on a one-GPU box)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 child runs that measure `traffic`")
     ap.add_argument("--deterministic", action="store_true",
                     help="bit-identical parameter updates (two-stage filter gradients, fixed-point bias sums): ~3 %% slower")
@@ -473,6 +476,8 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if args.main_priority is None:
+        args.main_priority = -1 if world == 1 else 0
     if args.main_priority != 0:
         torch.cuda.set_stream(torch.cuda.Stream(dev, priority=args.main_priority))
     launches0 = N.launch_count()
@@ -565,7 +570,8 @@ def main():
                        "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
                        "backend": backend if world > 1 else None, "local_device": f"cuda:{local}",
                        "gradient_exchange": args.exchange if world > 1 else None,
-                       "hip_graphs": bool(args.graphs), "sync_bn": bool(args.sync_bn), "deterministic": bool(ts.deterministic),
+                       "hip_graphs": bool(args.graphs), "main_stream_priority": args.main_priority,
+                       "sync_bn": bool(args.sync_bn), "deterministic": bool(ts.deterministic),
                        "final_loss": round(loss, 4)},
             "roofline": {"bound": "mfma", "achieved": round(dom["tflops"], 1), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4),
