@@ -251,7 +251,7 @@ class Builder:
         self.stem_from_y = os.environ.get("VT_STEM_FROM_Y", "1") != "0"
         # 3x3 stride-2 data gradients whose dz has at most this many channels (the HBM-bound ones) run as ONE
         # depth-to-space launch instead of four parity-class launches that each re-read dz
-        self.dgrad_d2s_maxc = int(os.environ.get("VT_DGRAD_D2S_MAXC", "64"))
+        self.dgrad_d2s_maxc = int(os.environ.get("VT_DGRAD_D2S_MAXC", "128"))
         # deterministic mode: the last sums still made with f32 atomics take an order-free form -- the filter gradients
         # become two-stage (partial tiles stored into slabs of ONE scratch that every layer reuses, then an ordered
         # reducer), the bias column sums and the one-pass stem kernel's correlations go through fixed point; with
