@@ -490,7 +490,7 @@ int launch_pw(const PwArgs& a, hipStream_t st, const char* who) {
     // every workgroup stages its own copy of W (up to 33 KiB): small tensors get fewer, longer workgroups
     // (the backward kernel that carries dW flushes N x K floats per workgroup through LDS and global atomics: one workgroup
     // per resident slot -- 2 per CU at its register count -- measured best: 64 x 64 at 0.8 M pixels 170 -> 117 us)
-    const int target = VT_KNOB("VT_PW_BLOCKS", (MODE == PW_BWD && G::kFull) ? 512 : 1024);
+    const int target = VT_KNOB("VT_PW_BLOCKS", 768);  // (round 3, in the step: 768 for every pass 21.49 vs 512 | 1024 21.55 ms)
     const int per_wave = VT_KNOB("VT_PW_UNITS_PER_WAVE", 8);
     long blocks = ((long)a.nunits + 4 * per_wave - 1) / (4 * per_wave);
     if (blocks > target) blocks = target;

@@ -446,9 +446,12 @@ int vt_wgrad_span_dispatch(const vt_conv_desc* d, const void* x, const void* dz,
     if (!enabled) return -1;
     if (d->dtype != VT_BF16 || d->ntaps != 9 || d->sh != 1 || d->sw != 1 || d->Ho != d->Hi || d->Wo != d->Wi)
         return -1;
-    // 14x14 and 7x7 maps with wide layers: the padded enumeration costs 15-30 % extra MFMA work and
-    // the general kernel's operands stay L2 resident there (measured 97 vs 115 us at 256ch 14x14)
-    if (enabled < 2 && d->Wi < 20 && d->Cin > 64 && d->Cout > 64) return -1;
+    // 14x14 and 7x7 maps with wide layers: the padded enumeration costs 15-30 % extra MFMA work, and in round 2 the
+    // general kernel, whose operands stay L2 resident there, was faster ALONE (97 vs 115 us at 256ch 14x14) and those
+    // layers went to it.  Inside the step the all-taps kernel wins since round 3 (one 8-wave workgroup per CU next to the
+    // main stream's kernels: 21.46 vs 21.55 ms, alternating runs): VT_WGRAD_SPAN_MINW = 20 restores the old rule.
+    const int minw_wide = VT_KNOB("VT_WGRAD_SPAN_MINW", 0);
+    if (enabled < 2 && d->Wi < minw_wide && d->Cin > 64 && d->Cout > 64) return -1;
     int ph = 0, pw = 0, eh[9], ew[9];
     for (int t = 0; t < 9; ++t) {
         eh[t] = d->h0 + d->dh[t], ew[t] = d->w0 + d->dw[t];
@@ -480,7 +483,9 @@ int vt_wgrad_span_s2_dispatch(const vt_conv_desc* d, const void* x, const void* 
     // tap count, so two launches of 2 and 4 taps only match the general kernel's time where that one is at its worst
     // (32 -> 64 @224->112: 0.49 vs 0.47 ms alone, but 1.6 instead of 2.6 GB fetched: -0.1 ms per step beside the
     // HBM-bound BatchNorm passes); at 64 -> 128 @112->56 it is 0.44 vs 0.29 ms, on the 8-channel VoVNet stem slower too.
-    const int minw = VT_KNOB("VT_WGRAD_S2_MINW", 100);
+    // (round 3: off by default -- with the XCD-blocked work order the general kernel no longer re-fetches its operands
+    //  2.7x on these layers: 32 -> 64 @224->112 0.41 ms either way alone, the step 21.49 vs 21.55 ms)
+    const int minw = VT_KNOB("VT_WGRAD_S2_MINW", 0);
     const int minc = VT_KNOB("VT_WGRAD_S2_MINC", 32);
     if (d->Cin < minc) return -1;
     if (minw <= 0 || d->dtype != VT_BF16 || d->ntaps != 9 || d->sh != 2 || d->sw != 2 || d->h0 != -1 || d->w0 != -1)
