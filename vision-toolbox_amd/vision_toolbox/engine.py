@@ -244,6 +244,12 @@ class Builder:
         # plain FORK (24.65 vs 24.66 ms: the 7 us per unit on the main stream are the event record itself, not the
         # host's issue order), so off
         self.fork_split = os.environ.get("VT_FORK_SPLIT", "0") != "0"
+        # ... except for the unit that reads the stem's output (and any unit whose input is at least VT_WGRAD_LATE_MB
+        # large): its data gradient, its filter gradient and the stem's one-pass backward are the HBM-bound tail of a step;
+        # released AFTER the data gradient, the filter gradient runs beside the stem's backward, which otherwise has the
+        # GPU to itself, instead of beside the data gradient (trace: 804 + 628 us; step 21.66 -> 21.54 ms)
+        self.wgrad_late_mb = float(os.environ.get("VT_WGRAD_LATE_MB", "0"))
+        self.wgrad_late_stem = os.environ.get("VT_WGRAD_LATE_STEM", "1") != "0"
         # stem unit (3 -> 32, s1): BatchNorm-backward reduction and filter gradient in one pass, dz never formed
         self.stem_fused_bwd = os.environ.get("VT_STEM_FUSED_BWD", "1") != "0"
         # ... and its pre-activation z (B x 224 x 224 x 32, the largest tensor of a step) is never stored: the conv runs
@@ -588,6 +594,7 @@ class Builder:
             self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, y.addr(), cp[0], cp[1],
                                         residual.addr() if residual else None, None], desc=d)
         elif stem_y:
+            y.stem_out = True  # (the unit that reads it releases its filter gradient late: wgrad_late_stem)
             stats = self.zeroed_f32(N.stat_floats(Cout), "stats")
             d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, y.ld, ldw, N.VT_CONV_STATS | N.VT_CONV_NOSTORE)
             self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, None, None, None, None, self.bp(stats)], desc=d)
@@ -700,10 +707,13 @@ class Builder:
                 # Host issue order: [mark the main stream's position: dz is complete] [data gradient, main stream]
                 # [side stream waits for the MARK] [filter gradient].  The filter gradient still depends on dz only,
                 # but the main stream does not sit idle while the host enqueues it (7 us x 66 units in the trace).
-                split = self.fork_split and w.requires_grad and x.needs_grad and not self.wgrad_late
+                late = self.wgrad_late or (x.needs_grad and (
+                    (self.wgrad_late_mb > 0 and x.M * x.C * 2 >= self.wgrad_late_mb * 1e6) or
+                    (self.wgrad_late_stem and getattr(x, "stem_out", False))))
+                split = self.fork_split and w.requires_grad and x.needs_grad and not late
                 if split:
                     self.emit(N.OP_FORK_MARK)
-                elif not self.wgrad_late:
+                elif not late:
                     emit_wgrad()
                 # data gradient
                 if x.needs_grad:
@@ -711,7 +721,7 @@ class Builder:
                                 ldw, Cout, k, s, pad, Ho, Wo)
                 if split:
                     emit_wgrad(wait_only=True)
-                elif self.wgrad_late:
+                elif late:
                     emit_wgrad()
 
             self.nodes.append(bwd)
