@@ -38,7 +38,6 @@ struct WgradArgs {
     int split, xcds;   // pixel splits; 8 = XCD-blocked item order (vt_xcd_item), 1 = identity
     float* slab;       // partial tiles go to slab[blockIdx.y * slab_stride + ...] with plain stores (no atomics)
     long slab_stride;  // elements per pixel split: Cout * ldgw
-    unsigned magic_w, magic_h;  // ceil(2^32 / Wo), ceil(2^32 / Ho): exact n / d for n < 2^16
     int8_t dh[VT_MAX_TAPS];
     int8_t dwv[VT_MAX_TAPS];
 };
@@ -447,8 +446,6 @@ static int wgrad_impl(const vt_conv_desc* d, const void* x, const void* dz, floa
     a.M = (int)M;
     a.Ktot = d->ntaps * d->Cin;
     a.ldgw = ldgw;
-    a.magic_w = (unsigned)((0x100000000ull + d->Wo - 1) / d->Wo);
-    a.magic_h = (unsigned)((0x100000000ull + d->Ho - 1) / d->Ho);
     a.tiles_n = (d->Cout + 127) / 128;
     a.tiles_k = (a.Ktot + 127) / 128;
     memcpy(a.dh, d->dh, VT_MAX_TAPS);

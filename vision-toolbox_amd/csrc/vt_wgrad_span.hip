@@ -45,7 +45,6 @@ struct WsArgs {
     int PH, PW, S, NP;       // padded rows / pitch / positions per image / total positions
     int dmin, NH, RX;        // smallest tap offset, halo chunks, ring rows (power of two)
     int tiles_n, tiles_c, chunk, ablate;
-    unsigned magic_pw, magic_ph;  // ceil(2^32 / PW), ceil(2^32 / PH)  (PW, PH >= 2)
     short o[9];              // d_t - dmin
     int ntaps, tgn;          // taps (<= 9) and how many of them the first tap group owns (<= 5)
     int split, xcds;         // pixel splits; 8 = XCD-blocked item order (vt_xcd_item), 1 = identity
@@ -379,8 +378,6 @@ namespace {
 int launch_ws_taps(WsArgs& a, int ntaps, const int* eh, const int* ew, hipStream_t st, float* scratch = nullptr,
                    long scratch_bytes = 0) {
     a.S = a.PH * a.PW;
-    a.magic_pw = (unsigned)((0x100000000ull + a.PW - 1) / a.PW);
-    a.magic_ph = (unsigned)((0x100000000ull + a.PH - 1) / a.PH);
     const long NP = (long)a.B * a.S;
     if (NP > 0x7ffffff0L || a.PW < 2 || a.PH < 2) return -1;
     if (32 / a.PW + 1 >= 2 * a.PH) return -1;  // (the position advance of the kernel wraps at most two rows of images)
