@@ -26,6 +26,7 @@ CASES = [
     (5, 31, 63, 48, 64, 1),      # operands that are channel slices of wider buffers
     (4, 224, 224, 32, 32, 1),    # the real map: halo 256 rows, ring of 1024
     (2, 40, 300, 32, 32, 0),     # wide map, no ReLU mask
+    (1, 5, 824, 32, 32, 1),      # the widest map the y form takes (engine.py: one more step of halo in the 2048-row ring)
 ]
 
 

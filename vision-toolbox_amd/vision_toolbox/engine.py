@@ -580,8 +580,8 @@ class Builder:
         coef = None
         stem_fused = (self.stem_fused_bwd and track and padded and has_bn and not fused and residual is None and
                       not x.needs_grad and w.requires_grad and dt == N.VT_BF16 and Cout == 32 and k == 3 and s == 1 and
-                      pad == 1 and x.C == 8 and x.ld == 8 and x.W <= 896 and B * (x.H + 1) * (x.W + 1) < 0x7fff0000)  # (ring in LDS)
-        stem_y = stem_fused and unit_training and self.stem_from_y and x.W <= 832
+                      pad == 1 and x.C == 8 and x.ld == 8 and x.W <= 888 and B * (x.H + 1) * (x.W + 1) < 0x7fff0000)  # (ring in LDS: halo <= 896 rows)
+        stem_y = stem_fused and unit_training and self.stem_from_y and x.W <= 824  # (one more step of halo)
         if has_bn:
             coef = self.f32(4 * Cout, "bncoef")  # scale, shift, mean, invstd
             cp = [self.bp(coef, i * Cout * 4) for i in range(4)]
