@@ -56,7 +56,7 @@ extern "C" {
                             * gradient of a 3x3 stride-2 convolution (the four parity classes as column blocks of a
                             * 2x2-tap filter image, zero where a class has no tap) and reads dz once. */
 
-#define VT_STAT_REPLICAS 32
+#define VT_STAT_REPLICAS 16
 /* A statistics buffer (`stats` of vt_conv_igemm, `sums` of the BatchNorm-backward reductions) is
  * int64[VT_STAT_REPLICAS][2][C][2], VT_STAT_BYTES(C) bytes, zeroed by the caller and passed as float*: fixed point,
  * value = hi*2^12 + lo/2^33, accumulated with integer atomics.  Integer addition is associative, so the statistics --

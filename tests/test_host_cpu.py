@@ -261,7 +261,7 @@ def test_statistics_buffer_fixed_point_roundtrip():
     v = torch.tensor([0.0, 1e-6, -1e-6, 3.25, -4095.75, 4096.0, 1.2345e7], dtype=torch.float32)
     w = torch.tensor([5e-9, -7.5, 123456.7, -0.03125, 4095.999, -8192.5, -1.2345e7], dtype=torch.float32)
     N.stats_encode(buf, 0, v, replica=3)
-    N.stats_encode(buf, 0, w, replica=31)
+    N.stats_encode(buf, 0, w, replica=N.VT_STAT_REPLICAS - 1)
     N.stats_encode(buf, 1, w, replica=0)
     got = N.stats_decode(buf)
     # resolution 2^-33 per contribution (values with finer bits, 1e-6 or 5e-9, round to it): 2^-34 error each

@@ -18,7 +18,7 @@ VT_OK, VT_ERR_INVALID, VT_ERR_UNSUPPORTED, VT_ERR_HIP = 0, 1, 2, 3
 VT_F32, VT_BF16 = 0, 1
 VT_MAX_TAPS = 36
 VT_CONV_RELU, VT_CONV_STATS, VT_CONV_RESIDUAL, VT_CONV_AFFINE, VT_CONV_D2S, VT_CONV_NOSTORE = 1, 2, 4, 8, 16, 32
-VT_STAT_REPLICAS = 32
+VT_STAT_REPLICAS = 16
 # a statistics buffer is int64[VT_STAT_REPLICAS][2][C][2]: value = hi * 2^12 + lo / 2^33 (vt_amd.h)
 
 
