@@ -139,6 +139,17 @@ int vt_fixed_to_f32(const void* q, float* dst, int64_t n, int32_t accumulate, vo
 int vt_pack_dgrad_filter(const void* w, int32_t src_dtype, int32_t ldw, void* out,
                          int32_t dst_dtype, const int32_t* sel_host, int32_t nsel,
                          int32_t Cout, int32_t ntaps, int32_t Cin, void* stream);
+/* The same for n filters in ceil(n / VT_PACK_BATCH) launches (bf16 -> bf16 only): a train step re-packs every filter
+ * once, 73 launches of ~6 us for CSPDarknet-53, which cost 0.3 ms of the step through the launches alone.  The
+ * executor (vt_run_ops*) gathers consecutive VT_OP_PACK_DGRAD ops of one stream into this call by itself. */
+#define VT_PACK_BATCH 40
+typedef struct vt_pack_item {
+    const void* w;
+    void* out;
+    int32_t ldw, nsel, Cout, ntaps, Cin;
+    int8_t sel[VT_MAX_TAPS];
+} vt_pack_item;
+int vt_pack_dgrad_filter_batch(const vt_pack_item* items, int32_t n, void* stream);
 
 /* ---- BatchNorm2d + ReLU (components.py:36-44) --------------------------- */
 /* training: stats -> batch mean/var, running-stat update (momentum, unbiased

@@ -476,3 +476,36 @@ def test_stride2_all_taps_filter_gradient_in_subprocess():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     buf = torch.zeros(16, device="cuda")
     N.check(N.lib().vt_memset(vp(buf), 0, 64, stream()))
+
+
+def test_filter_repack_batch_equals_the_single_launches():
+    """vt_pack_dgrad_filter_batch (what the executor turns a run of VT_OP_PACK_DGRAD ops into): 45 filters of mixed shapes
+    -- more than one VT_PACK_BATCH, 1x1 / 3x3 / depth-to-space tables with zero taps, a channel-slice source (ldw > taps *
+    Cin) -- bit-equal to one vt_pack_dgrad_filter call each."""
+    L = N.lib()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    shapes = [(64, 32, 9), (128, 128, 1), (32, 64, 9), (256, 128, 9), (80, 80, 9), (8, 24, 1), (128, 64, 9)]
+    items = (N.PackItem * 45)()
+    keep, ref = [], []
+    for k in range(45):
+        Cout, Cin, taps = shapes[k % len(shapes)]
+        ldw = taps * Cin + (16 if k % 3 == 0 else 0)
+        w = torch.randn(Cout, ldw, device="cuda", generator=gen).to(torch.bfloat16)
+        if taps == 9 and k % 2:  # a depth-to-space table: 4 column blocks x 4 taps, -1 where a class has no tap
+            sel = [4, -1, -1, -1, 5, 3, -1, -1, 7, -1, 1, -1, 8, 6, 2, 0]
+        else:
+            sel = list(range(taps - 1, -1, -1))
+        out1 = torch.full((Cin * len(sel) * Cout,), 7.0, device="cuda", dtype=torch.bfloat16)
+        out2 = torch.full_like(out1, 3.0)
+        arr = (C.c_int32 * len(sel))(*sel)
+        N.check(L.vt_pack_dgrad_filter(vp(w), N.VT_BF16, ldw, vp(out1), N.VT_BF16, arr, len(sel), Cout, taps, Cin, stream()))
+        it = items[k]
+        it.w, it.out, it.ldw, it.nsel, it.Cout, it.ntaps, it.Cin = w.data_ptr(), out2.data_ptr(), ldw, len(sel), Cout, taps, Cin
+        for i, v in enumerate(sel):
+            it.sel[i] = v
+        keep.append((w, out2))
+        ref.append(out1)
+    N.check(L.vt_pack_dgrad_filter_batch(C.byref(items), 45, stream()))
+    torch.cuda.synchronize()
+    for (w, out2), out1 in zip(keep, ref):
+        assert torch.equal(out1, out2)

@@ -948,6 +948,55 @@ pack_dgrad_kernel(const S* __restrict__ w, int ldw, D* __restrict__ out, SelTabl
     }
 }
 
+// n filters in one launch: workgroup b belongs to the item whose [first, first + blocks) range holds it
+struct PackBatchItem {
+    const bf16_t* w;
+    bf16_t* out;
+    int ldw, nsel, Cout, Cin;
+    unsigned first, blocks;
+    signed char sel[VT_MAX_TAPS];
+};
+struct PackBatch {
+    int n;
+    PackBatchItem it[VT_PACK_BATCH];
+};
+// a workgroup moves one 64 (out channels) x 64 (in channels) tile of one packed tap through LDS: 16-byte loads along c,
+// 16-byte stores along n (the one-element-per-thread kernel above reads w with a stride of ldw elements between lanes).
+// Cin, Cout and ldw are multiples of 8 and both bases 16-byte aligned (checked by the entry point).
+__global__ void __launch_bounds__(kThreads) pack_dgrad_batch_kernel(const PackBatch b) {
+    __shared__ __attribute__((aligned(16))) unsigned short tile[64][72];  // [c][n]
+    int k = 0;
+    while (k + 1 < b.n && blockIdx.x >= b.it[k + 1].first) ++k;  // (<= 40 items, kernel arguments: scalar loads)
+    const PackBatchItem& it = b.it[k];
+    const int lb = (int)(blockIdx.x - it.first);
+    const int tiles_n = (it.Cout + 63) / 64;
+    const int s = lb % it.nsel, rest = lb / it.nsel;
+    const int n0 = (rest % tiles_n) * 64, c0 = (rest / tiles_n) * 64;
+    const int src = it.sel[s];
+    const unsigned short* w = (const unsigned short*)it.w;
+    unsigned short* out = (unsigned short*)it.out;
+#pragma unroll
+    for (int e = threadIdx.x; e < 512; e += kThreads) {
+        const int r = e >> 3, j = e & 7;  // out channel n0 + r, in channels c0 + 8j ..
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (src >= 0 && n0 + r < it.Cout && c0 + 8 * j < it.Cin)
+            v = *(const uint4*)(w + ((long)(n0 + r) * it.ldw + (long)src * it.Cin + c0 + 8 * j));
+        const unsigned d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            tile[8 * j + 2 * q][r] = (unsigned short)(d[q] & 0xffffu);
+            tile[8 * j + 2 * q + 1][r] = (unsigned short)(d[q] >> 16);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = threadIdx.x; e < 512; e += kThreads) {
+        const int c = e >> 3, j = e & 7;  // in channel c0 + c, out channels n0 + 8j ..
+        if (c0 + c < it.Cin && n0 + 8 * j < it.Cout)
+            *(uint4*)(out + (((long)(c0 + c) * it.nsel + s) * it.Cout + n0 + 8 * j)) = *(const uint4*)&tile[c][8 * j];
+    }
+}
+
 // Walking order of the three BatchNorm passes over their rows (bit 0: bn_act_apply, 1: bn_bwd_reduce, 2: bn_bwd_apply;
 // set = last row block first).  A pass that follows a kernel which just streamed the same tensor front to back finds
 // that tensor's TAIL in the memory-side cache (256 MB), not its head: walking backwards would turn those into hits.
@@ -1434,6 +1483,39 @@ int vt_pack_dgrad_filter(const void* w, int32_t src_dtype, int32_t ldw, void* ou
     }
 #undef VT_PK
     VT_CHECK_LAUNCH("vt_pack_dgrad_filter");
+    return VT_OK;
+}
+
+int vt_pack_dgrad_filter_batch(const vt_pack_item* items, int32_t n, void* stream) {
+    VT_REQUIRE(items && n >= 1, VT_ERR_INVALID, "vt_pack_dgrad_filter_batch: bad argument");
+    for (int base = 0; base < n; base += VT_PACK_BATCH) {
+        PackBatch b;
+        memset(&b, 0, sizeof(b));
+        b.n = n - base < VT_PACK_BATCH ? n - base : VT_PACK_BATCH;
+        unsigned first = 0;
+        for (int k = 0; k < b.n; ++k) {
+            const vt_pack_item& s = items[base + k];
+            VT_REQUIRE(s.w && s.out && s.nsel >= 1 && s.nsel <= VT_MAX_TAPS && s.Cout > 0 && s.Cin > 0 && s.ntaps >= 1 &&
+                           s.ntaps <= VT_MAX_TAPS && s.ldw >= s.ntaps * s.Cin,
+                       VT_ERR_INVALID, "vt_pack_dgrad_filter_batch: bad item %d", base + k);
+            VT_REQUIRE(s.Cout % 8 == 0 && s.Cin % 8 == 0 && s.ldw % 8 == 0 && vt_aligned16(s.w) && vt_aligned16(s.out),
+                       VT_ERR_UNSUPPORTED, "vt_pack_dgrad_filter_batch: item %d: Cout, Cin, ldw must be multiples of 8 and "
+                       "both images 16-byte aligned", base + k);
+            PackBatchItem& d = b.it[k];
+            d.w = (const bf16_t*)s.w, d.out = (bf16_t*)s.out;
+            d.ldw = s.ldw, d.nsel = s.nsel, d.Cout = s.Cout, d.Cin = s.Cin;
+            for (int i = 0; i < s.nsel; ++i) {
+                VT_REQUIRE(s.sel[i] >= -1 && s.sel[i] < s.ntaps, VT_ERR_INVALID,
+                           "vt_pack_dgrad_filter_batch: item %d sel[%d]=%d outside [-1,%d)", base + k, i, s.sel[i], s.ntaps);
+                d.sel[i] = s.sel[i];
+            }
+            const long blocks = (long)s.nsel * ((s.Cout + 63) / 64) * ((s.Cin + 63) / 64);  // one 64 x 64 tile of one tap each
+            d.first = first, d.blocks = (unsigned)blocks;
+            first += (unsigned)blocks;
+        }
+        hipLaunchKernelGGL(pack_dgrad_batch_kernel, dim3(first), dim3(kThreads), 0, (hipStream_t)stream, b);
+        VT_CHECK_LAUNCH("vt_pack_dgrad_filter_batch");
+    }
     return VT_OK;
 }
 

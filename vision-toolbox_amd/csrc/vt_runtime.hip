@@ -396,6 +396,33 @@ static int run_ops_impl(const vt_op* ops, int32_t n, void* const* bases, int32_t
             // (unconditional: an earlier SEGMENT of the same list may have left side work open, VT_RUN_LEAVE_SIDE_OPEN)
             if (two) rc = stream_wait((hipStream_t)stream, (hipStream_t)side, bag);
             side_dirty = false;
+        } else if (op.kind == VT_OP_PACK_DGRAD && op.i[0] == VT_BF16 && op.i[2] == VT_BF16 && op.i[1] % 8 == 0 &&
+                   op.i[4] % 8 == 0 && op.i[6] % 8 == 0) {
+            // consecutive bf16 filter re-packs of one stream leave as ONE batched launch per VT_PACK_BATCH of them
+            std::vector<vt_pack_item> items;
+            int j = i;
+            bool bad = false;
+            for (; j < n; ++j) {
+                const vt_op& o = ops[j];
+                if ((o.kind & ~VT_OP_SIDE_STREAM) != VT_OP_PACK_DGRAD || ((o.kind & VT_OP_SIDE_STREAM) != 0) != on_side ||
+                    o.i[0] != VT_BF16 || o.i[2] != VT_BF16 || o.i[3] < 1 || o.i[3] > VT_MAX_TAPS || o.i[1] % 8 || o.i[4] % 8 ||
+                    o.i[6] % 8)
+                    break;
+                vt_pack_item it;  // i: src_dtype ldw dst_dtype nsel Cout ntaps Cin _ sel[36]
+                memset(&it, 0, sizeof(it));
+                it.w = rp(o, 0, bases, nbases, &bad), it.out = rp(o, 1, bases, nbases, &bad);
+                it.ldw = o.i[1], it.nsel = o.i[3], it.Cout = o.i[4], it.ntaps = o.i[5], it.Cin = o.i[6];
+                for (int t = 0; t < it.nsel; ++t) it.sel[t] = (int8_t)o.i[8 + t];
+                items.push_back(it);
+            }
+            if (bad) {
+                vt_set_error("vt_run_ops: a filter re-pack references an unbound base");
+                rc = VT_ERR_INVALID;
+            } else {
+                rc = vt_pack_dgrad_filter_batch(items.data(), (int)items.size(), (two && on_side) ? side : stream);
+            }
+            if (two && on_side) side_dirty = true;
+            i = j - 1;
         } else {
             rc = run_one(op, bases, nbases, (two && on_side) ? side : stream);
             if (two && on_side) side_dirty = true;

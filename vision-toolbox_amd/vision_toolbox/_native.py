@@ -162,6 +162,13 @@ class PwDesc(C.Structure):
     ]  # fmt: skip
 
 
+class PackItem(C.Structure):
+    """vt_pack_item"""
+
+    _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("ldw", C.c_int32), ("nsel", C.c_int32), ("Cout", C.c_int32),
+                ("ntaps", C.c_int32), ("Cin", C.c_int32), ("sel", C.c_int8 * 36)]
+
+
 class Ptr(C.Structure):
     """vt_ptr"""
 
@@ -194,6 +201,7 @@ SYMBOLS = {
     "vt_memset": (_i32, [_vp, _i32, _u64, _vp]),
     "vt_conv_igemm": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vt_conv_wgrad": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i32, _vp]),
+    "vt_pack_dgrad_filter_batch": (_i32, [_vp, _i32, _vp]),
     "vt_pack_dgrad_filter": (_i32, [_vp, _i32, _i32, _vp, _i32, C.POINTER(_i32), _i32, _i32, _i32, _i32, _vp]),
     "vt_bn_finalize": (_i32, [_vp, _i32, _f64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vt_stat_fold": (_i32, [_vp, _i32, _vp]),
