@@ -83,6 +83,24 @@ __device__ __forceinline__ unsigned vt_xcd_item(unsigned L, unsigned n, int xcds
 #endif
 static inline unsigned vt_xcd_grid(long items) { return (unsigned)((items + 7) / 8 * 8); }
 
+#if defined(__HIPCC__)
+// A FORK right behind a kernel (the filter gradient waits for dz) used to be an event RECORD on the main stream: a marker
+// packet between two kernels of the critical path, 66 per step.  The executor instead hands the producing launch an event
+// through this slot, and the launch attaches it to its own completion signal (hipExtLaunchKernelGGL's stop event): the side
+// stream waits for the kernel itself, the main queue carries no extra packet.  A launch site that supports it uses
+// VT_LAUNCH_STOP; the executor falls back to the record when the slot was not consumed.
+extern thread_local hipEvent_t vt_pending_stop_event;
+#define VT_LAUNCH_STOP(kernel, grid, block, smem, stream, ...)                                                    \
+    do {                                                                                                          \
+        if (vt_pending_stop_event) {                                                                              \
+            hipExtLaunchKernelGGL(kernel, grid, block, smem, stream, nullptr, vt_pending_stop_event, 0, __VA_ARGS__); \
+            vt_pending_stop_event = nullptr;                                                                      \
+        } else {                                                                                                  \
+            hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);                                   \
+        }                                                                                                         \
+    } while (0)
+#endif
+
 #define VT_REQUIRE(cond, code, ...)   \
     do {                              \
         if (!(cond)) {                \

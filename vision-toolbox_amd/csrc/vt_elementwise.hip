@@ -8,6 +8,8 @@
 // 16-byte chunks of a pixel row (full-line coalesced NHWC accesses, G13).
 #include <stdlib.h>
 
+#include <hip/hip_ext.h>
+
 #include "vt_common.h"
 
 namespace {
@@ -1104,14 +1106,14 @@ int vt_bn_act_apply(const void* z, int32_t ldz, const float* scale, const float*
     rm.rev = (vt_bn_order() >> 0) & 1;
     if (residual) {
         VT_DISPATCH_T(dtype, "vt_bn_act_apply",
-                      hipLaunchKernelGGL((bn_act_apply_kernel<T, true>), dim3(rm.blocks(M)), dim3(kThreads), 0,
-                                         (hipStream_t)stream, (const T*)z, ldz, scale, shift, (const T*)residual,
-                                         ldr, (T*)y, ldy, (long)M, rm, relu));
+                      VT_LAUNCH_STOP((bn_act_apply_kernel<T, true>), dim3(rm.blocks(M)), dim3(kThreads), 0,
+                                     (hipStream_t)stream, (const T*)z, ldz, scale, shift, (const T*)residual,
+                                     ldr, (T*)y, ldy, (long)M, rm, relu));
     } else {
         VT_DISPATCH_T(dtype, "vt_bn_act_apply",
-                      hipLaunchKernelGGL((bn_act_apply_kernel<T, false>), dim3(rm.blocks(M)), dim3(kThreads), 0,
-                                         (hipStream_t)stream, (const T*)z, ldz, scale, shift, (const T*)residual,
-                                         ldr, (T*)y, ldy, (long)M, rm, relu));
+                      VT_LAUNCH_STOP((bn_act_apply_kernel<T, false>), dim3(rm.blocks(M)), dim3(kThreads), 0,
+                                     (hipStream_t)stream, (const T*)z, ldz, scale, shift, (const T*)residual,
+                                     ldr, (T*)y, ldy, (long)M, rm, relu));
     }
     VT_CHECK_LAUNCH("vt_bn_act_apply");
     return VT_OK;
@@ -1162,9 +1164,9 @@ int vt_bn_act_bwd_apply(const void* dy, int32_t lddy, const void* z, int32_t ldz
     RowMap rm = RowMap::make(C, vt_epc(dtype), M);
     rm.rev = (vt_bn_order() >> 2) & 1;
     VT_DISPATCH_T(dtype, "vt_bn_act_bwd_apply",
-                  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(rm.blocks(M)), dim3(kThreads), 0,
-                                     (hipStream_t)stream, (const T*)dy, lddy, (const T*)z, ldz, scale, shift,
-                                     coef, (T*)dz, lddz, (long)M, C, rm, relu));
+                  VT_LAUNCH_STOP(bn_bwd_apply_kernel<T>, dim3(rm.blocks(M)), dim3(kThreads), 0,
+                                 (hipStream_t)stream, (const T*)dy, lddy, (const T*)z, ldz, scale, shift,
+                                 coef, (T*)dz, lddz, (long)M, C, rm, relu));
     VT_CHECK_LAUNCH("vt_bn_act_bwd_apply");
     return VT_OK;
 }

@@ -44,6 +44,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <hip/hip_ext.h>
+
 #include "vt_common.h"
 
 namespace {
@@ -496,7 +498,7 @@ int launch_pw(const PwArgs& a, hipStream_t st, const char* who) {
     if (blocks > target) blocks = target;
     if (blocks < 1) blocks = 1;
     vt_note_kernel("pw_kernel<%d,%d,%s>", N, K, MODE == PW_STATS ? "stats" : MODE == PW_APPLY ? "apply" : MODE == PW_REDUCE ? "reduce" : "bwd");
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, st, a);
+    VT_LAUNCH_STOP(kern, dim3((unsigned)blocks), dim3(256), smem, st, a);
     VT_CHECK_LAUNCH(who);
     return VT_OK;
 }

@@ -100,6 +100,8 @@ int vt_device_cus(void) {
     return v;
 }
 
+thread_local hipEvent_t vt_pending_stop_event = nullptr;
+
 namespace {
 
 inline void* rp(const vt_op& op, int k, void* const* bases, int nbases, bool* bad) {
@@ -349,13 +351,32 @@ static int run_ops_impl(const vt_op* ops, int32_t n, void* const* bases, int32_t
     static thread_local hipEvent_t eager_mark = nullptr;
     hipEvent_t capture_mark = nullptr;
     hipEvent_t& mark = bag ? capture_mark : eager_mark;
+    const int stop_events = VT_KNOB("VT_FORK_STOP_EVENT", 1);
+    hipEvent_t fork_ev = nullptr;  // completion event of the kernel right before the next FORK (see vt_common.h)
     for (int i = 0; i < n; ++i) {
         vt_op op = ops[i];
         const bool on_side = (op.kind & VT_OP_SIDE_STREAM) != 0;
         op.kind &= ~VT_OP_SIDE_STREAM;
         int rc = VT_OK;
         if (op.kind == VT_OP_FORK) {
-            if (two) rc = stream_wait((hipStream_t)side, (hipStream_t)stream, bag);
+            if (two && fork_ev) {
+                if (hipStreamWaitEvent((hipStream_t)side, fork_ev, 0) != hipSuccess) {
+                    vt_set_error("fork: waiting for the producer's completion event failed");
+                    rc = VT_ERR_HIP;
+                }
+            } else if (two) {
+                rc = stream_wait((hipStream_t)side, (hipStream_t)stream, bag);
+            }
+            fork_ev = nullptr;
+        } else if (stop_events && two && !bag && !on_side && i + 1 < n && ops[i + 1].kind == VT_OP_FORK &&
+                   (op.kind == VT_OP_BN_BWD_APPLY || op.kind == VT_OP_BN_ACT_APPLY || op.kind == VT_OP_PW_BWD)) {
+            // (single-launch ops only: the event must belong to the LAST kernel of the op)
+            hipError_t e = hipSuccess;
+            hipEvent_t ev = take_event(nullptr, &e);
+            if (e == hipSuccess) vt_pending_stop_event = ev;
+            rc = run_one(op, bases, nbases, stream);
+            if (e == hipSuccess && vt_pending_stop_event == nullptr) fork_ev = ev;  // consumed: attached to the launch
+            vt_pending_stop_event = nullptr;
         } else if (op.kind == VT_OP_FORK_MARK) {
             if (two) {
                 // (eager: an event of its own per thread and device, never a slot of the shared ring, which 64 later
