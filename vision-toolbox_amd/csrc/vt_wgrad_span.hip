@@ -404,9 +404,9 @@ int launch_ws_taps(WsArgs& a, int ntaps, const int* eh, const int* ew, hipStream
     const int target = VT_KNOB("VT_WGRAD_SPAN_TARGET", 256);
     const long tiles = (long)a.tiles_n * a.tiles_c;
     long split = target / tiles;
-    // (>= 96 steps per workgroup: at batch 128 the 256-workgroup target cut the 28x28 layers into 52-step pieces, and half
+    // (>= 144 steps per workgroup (96 .. 200 measured alike): at batch 128 the 256-workgroup target cut the 28x28 layers into 52-step pieces, and half
     //  as many workgroups of twice the length measured 12.54 vs 12.65 ms per step; batch 256 is unchanged by this bound)
-    const int min_steps = VT_KNOB("VT_WGRAD_SPAN_MINSTEPS", 96);
+    const int min_steps = VT_KNOB("VT_WGRAD_SPAN_MINSTEPS", 144);
     const long max_split = (NP + 32L * min_steps - 1) / (32L * min_steps);
     if (split > max_split) split = max_split;
     if (scratch && !a.cblk && split * (long)a.Cout * a.ldgw * 4 > scratch_bytes)
