@@ -463,7 +463,9 @@ static int wgrad_impl(const vt_conv_desc* d, const void* x, const void* dz, floa
     // at ~1.3 TB/s), so they get one workgroup per CU instead of two (measured 38 -> 32 us)
     const int tgt = (d->ntaps == 1 && M <= 262144 && target == 512) ? 256 : target;
     long split = tgt / tiles;
-    const long max_split = (M + 8L * pk * G - 1) / (8L * pk * G);
+    // steps per wave group and workgroup, at least (8 until round 3; 24 measured 12.29 vs 12.41 ms at batch 128, same at 256)
+    const int min_steps = VT_KNOB("VT_WGRAD_MINSTEPS", 24);
+    const long max_split = (M + (long)min_steps * pk * G - 1) / ((long)min_steps * pk * G);
     if (split > max_split) split = max_split;
     if (split > max_split_env) split = max_split_env;
     const long slab_stride = (long)d->Cout * ldgw;
