@@ -165,6 +165,14 @@ int vt_stat_fold(float* stats, int32_t C, void* stream);
 int vt_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, int32_t C, float* scale,
                       float* shift, float* mean, float* invstd, void* stream);
+/* n of them in ceil(n / VT_PACK_BATCH) launches (the executor gathers consecutive VT_OP_BN_EVAL_COEFFS ops itself) */
+typedef struct vt_bn_eval_item {
+    const float *gamma, *beta, *running_mean, *running_var;
+    float *scale, *shift, *mean, *invstd;
+    int32_t C;
+    float eps;
+} vt_bn_eval_item;
+int vt_bn_eval_coeffs_batch(const vt_bn_eval_item* items, int32_t n, void* stream);
 /* y = [relu](z*scale + shift) [+ residual] */
 int vt_bn_act_apply(const void* z, int32_t ldz, const float* scale, const float* shift,
                     const void* residual, int32_t ldr, void* y, int32_t ldy, int64_t M,

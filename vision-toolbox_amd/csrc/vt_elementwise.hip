@@ -117,6 +117,24 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
     if (invstd) invstd[c] = istd;
 }
 
+struct BnEvalBatch {
+    int n;
+    vt_bn_eval_item it[VT_PACK_BATCH];
+};
+// one workgroup per (BatchNorm, 256 channels)
+__global__ void __launch_bounds__(256) bn_eval_coeffs_batch_kernel(const BnEvalBatch b, int blocks_per_item) {
+    const vt_bn_eval_item& it = b.it[blockIdx.x / blocks_per_item];
+    const int c = (blockIdx.x % blocks_per_item) * 256 + threadIdx.x;
+    if (c >= it.C) return;
+    const float istd = 1.f / sqrtf(it.running_var[c] + it.eps);
+    const float g = it.gamma ? it.gamma[c] : 1.f, bb = it.beta ? it.beta[c] : 0.f;
+    const float sc = g * istd;
+    it.scale[c] = sc;
+    it.shift[c] = bb - it.running_mean[c] * sc;
+    if (it.mean) it.mean[c] = it.running_mean[c];
+    if (it.invstd) it.invstd[c] = istd;
+}
+
 // ---------------------------------------------------------------------------------
 // y = [relu](z*scale + shift) [+ residual]
 // ---------------------------------------------------------------------------------
@@ -1092,6 +1110,27 @@ int vt_bn_eval_coeffs(const float* gamma, const float* beta, const float* runnin
     hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma,
                        beta, running_mean, running_var, eps, C, scale, shift, mean, invstd);
     VT_CHECK_LAUNCH("vt_bn_eval_coeffs");
+    return VT_OK;
+}
+
+int vt_bn_eval_coeffs_batch(const vt_bn_eval_item* items, int32_t n, void* stream) {
+    VT_REQUIRE(items && n >= 1, VT_ERR_INVALID, "vt_bn_eval_coeffs_batch: bad argument");
+    for (int base = 0; base < n; base += VT_PACK_BATCH) {
+        BnEvalBatch b;
+        memset(&b, 0, sizeof(b));
+        b.n = n - base < VT_PACK_BATCH ? n - base : VT_PACK_BATCH;
+        int cmax = 0;
+        for (int k = 0; k < b.n; ++k) {
+            const vt_bn_eval_item& s = items[base + k];
+            VT_REQUIRE(s.running_mean && s.running_var && s.scale && s.shift && s.C > 0, VT_ERR_INVALID,
+                       "vt_bn_eval_coeffs_batch: bad item %d", base + k);
+            b.it[k] = s;
+            cmax = s.C > cmax ? s.C : cmax;
+        }
+        const int bpi = (cmax + 255) / 256;
+        hipLaunchKernelGGL(bn_eval_coeffs_batch_kernel, dim3((unsigned)(b.n * bpi)), dim3(256), 0, (hipStream_t)stream, b, bpi);
+        VT_CHECK_LAUNCH("vt_bn_eval_coeffs_batch");
+    }
     return VT_OK;
 }
 

@@ -417,6 +417,32 @@ static int run_ops_impl(const vt_op* ops, int32_t n, void* const* bases, int32_t
             // (unconditional: an earlier SEGMENT of the same list may have left side work open, VT_RUN_LEAVE_SIDE_OPEN)
             if (two) rc = stream_wait((hipStream_t)stream, (hipStream_t)side, bag);
             side_dirty = false;
+        } else if (op.kind == VT_OP_BN_EVAL_COEFFS && i + 1 < n &&
+                   (ops[i + 1].kind & ~VT_OP_SIDE_STREAM) == VT_OP_BN_EVAL_COEFFS) {
+            // a run of eval-mode coefficient ops (Program puts them all at the head of the list): batched launches
+            std::vector<vt_bn_eval_item> items;
+            int j = i;
+            bool bad = false;
+            for (; j < n; ++j) {
+                const vt_op& o = ops[j];
+                if ((o.kind & ~VT_OP_SIDE_STREAM) != VT_OP_BN_EVAL_COEFFS || ((o.kind & VT_OP_SIDE_STREAM) != 0) != on_side) break;
+                vt_bn_eval_item it;  // ptr: gamma beta rm rv scale shift mean invstd | i: C | f: eps
+                it.gamma = (const float*)rp(o, 0, bases, nbases, &bad), it.beta = (const float*)rp(o, 1, bases, nbases, &bad);
+                it.running_mean = (const float*)rp(o, 2, bases, nbases, &bad);
+                it.running_var = (const float*)rp(o, 3, bases, nbases, &bad);
+                it.scale = (float*)rp(o, 4, bases, nbases, &bad), it.shift = (float*)rp(o, 5, bases, nbases, &bad);
+                it.mean = (float*)rp(o, 6, bases, nbases, &bad), it.invstd = (float*)rp(o, 7, bases, nbases, &bad);
+                it.C = o.i[0], it.eps = (float)o.f[0];
+                items.push_back(it);
+            }
+            if (bad) {
+                vt_set_error("vt_run_ops: a BatchNorm coefficient op references an unbound base");
+                rc = VT_ERR_INVALID;
+            } else {
+                rc = vt_bn_eval_coeffs_batch(items.data(), (int)items.size(), (two && on_side) ? side : stream);
+            }
+            if (two && on_side) side_dirty = true;
+            i = j - 1;
         } else if (op.kind == VT_OP_PACK_DGRAD && op.i[0] == VT_BF16 && op.i[2] == VT_BF16 && op.i[1] % 8 == 0 &&
                    op.i[4] % 8 == 0 && op.i[6] % 8 == 0) {
             // consecutive bf16 filter re-packs of one stream leave as ONE batched launch per VT_PACK_BATCH of them

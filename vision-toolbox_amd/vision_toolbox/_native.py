@@ -202,6 +202,7 @@ SYMBOLS = {
     "vt_conv_igemm": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vt_conv_wgrad": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i32, _vp]),
     "vt_pack_dgrad_filter_batch": (_i32, [_vp, _i32, _vp]),
+    "vt_bn_eval_coeffs_batch": (_i32, [_vp, _i32, _vp]),
     "vt_pack_dgrad_filter": (_i32, [_vp, _i32, _i32, _vp, _i32, C.POINTER(_i32), _i32, _i32, _i32, _i32, _vp]),
     "vt_bn_finalize": (_i32, [_vp, _i32, _f64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vt_stat_fold": (_i32, [_vp, _i32, _vp]),
