@@ -439,6 +439,47 @@ def test_executor_and_graph_replay_agree():
         N.run_ops(E.ops_array([bad]), 1, [src.data_ptr()], stream())
 
 
+def test_fork_behind_a_kernel_completion_event_orders_the_side_stream():
+    """The executor releases the side stream at a FORK with the completion event of the kernel right before it
+    (hipExtLaunchKernelGGL stop event, vt_runtime.hip) instead of a recorded event.  A long BatchNorm apply on the
+    main stream, then FORK, then a short column sum of ITS OUTPUT on the side stream: were the side stream released
+    early, the sum would see the previous round's output (the rounds differ by their scale)."""
+    from vision_toolbox import engine as E
+
+    M, Cc = 1 << 20, 64
+    z = torch.randn(M, Cc, device="cuda").to(torch.bfloat16)
+    y = torch.zeros_like(z)
+    scale, shift = torch.ones(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+    out = torch.zeros(Cc, device="cuda")
+
+    def blank(kind, side=False):
+        op = N.Op()
+        op.kind = kind | (N.OP_SIDE_STREAM if side else 0)
+        for k in range(N.VT_OP_MAX_PTR):
+            op.ptr[k].base = -1
+        return op
+
+    a = blank(N.OP_BN_ACT_APPLY)  # ptr: z scale shift residual y | i: ldz ldr ldy C relu dtype | f: M
+    a.ptr[0].base, a.ptr[1].base, a.ptr[2].base, a.ptr[4].base = 0, 1, 2, 3
+    a.i[0], a.i[1], a.i[2], a.i[3], a.i[4], a.i[5] = Cc, 0, Cc, Cc, 0, N.VT_BF16
+    a.f[0] = M
+    c = blank(N.OP_COLSUM, side=True)  # ptr: a out | i: lda C dtype fixed | f: M
+    c.ptr[0].base, c.ptr[1].base = 3, 4
+    c.i[0], c.i[1], c.i[2], c.i[3] = Cc, Cc, N.VT_BF16, 0
+    c.f[0] = M
+    ops = E.ops_array([a, blank(N.OP_FORK), c, blank(N.OP_JOIN)])
+    bases = [z.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), out.data_ptr()]
+    side = torch.cuda.Stream()
+    for r in range(1, 7):
+        scale.fill_(float(r))  # exact in bf16: y = r z
+        out.zero_()
+        torch.cuda.synchronize()
+        N.run_ops(ops, 4, bases, stream(), side=int(side.cuda_stream))
+        torch.cuda.synchronize()
+        want = (z.float() * r).to(torch.bfloat16).float().sum(0)
+        torch.testing.assert_close(out, want, rtol=1e-4, atol=0.05 * r)
+
+
 @pytest.mark.parametrize("mode", ["0", "2", "3"], ids=["general_only", "span_forced", "span_256row_tiles"])
 def test_conv_kernel_variants_in_subprocess(mode):
     """vt_conv_igemm picks between the general gather kernel and the input-span kernel (and its
