@@ -480,6 +480,59 @@ def test_fork_behind_a_kernel_completion_event_orders_the_side_stream():
         torch.testing.assert_close(out, want, rtol=1e-4, atol=0.05 * r)
 
 
+RAGGED_K_CASES = [(2, 80, 80, 3, 1, 12, 12), (2, 80, 160, 3, 2, 16, 16), (3, 80, 80, 1, 1, 10, 7), (1, 48, 80, 3, 1, 9, 9),
+                  (1, 80, 160, 3, 1, 20, 20), (2, 160, 80, 1, 1, 13, 9), (2, 8, 80, 6, 2, 24, 20)]
+
+
+@pytest.mark.parametrize("case", RAGGED_K_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_gather_kernel_80_wide_tiles(case):
+    """80- and 160-channel outputs (Darknet-YOLOv5x) take 80-wide filter tiles on the gather kernel (VT_IGEMM_BN80):
+    with and without them against the float64 convolution, training and fused inference epilogue (with residual),
+    VT_IGEMM_SPAN=0 / VT_SPAN6=0 keeping the input-span kernels out."""
+    dtype = N.VT_BF16
+    B, Cin, Cout, k, s, H, W = case
+    pad = _pad(k, s)
+    x = filler.tensor(f"rx{case}", (B, Cin, H, W))
+    w = filler.tensor(f"rw{case}", (Cout, Cin, k, k), scale=(2.0 / (Cin * k * k)) ** 0.5)
+    sc = filler.tensor(f"rs{case}", (Cout,)).abs() + 0.5
+    sf = filler.tensor(f"rf{case}", (Cout,)) * 0.1
+    ref = F.conv2d(rounded(x, dtype).double(), rounded(w, dtype).double(), None, s, pad)
+    Ho, Wo = ref.shape[2:]
+    res = filler.tensor(f"rr{case}", (B, Cout, Ho, Wo))
+    ref_aff = torch.relu(ref * sc.double()[None, :, None, None] + sf.double()[None, :, None, None]) + rounded(res, dtype).double()
+    xd, wd, rd = nhwc(x, dtype), krsc(w, dtype), nhwc(res, dtype)
+    scd, sfd = sc.cuda(), sf.cuda()
+    names, outs = [], []
+    try:
+        N.set_knob("VT_IGEMM_SPAN", 0)
+        N.set_knob("VT_SPAN6", 0)
+        for bn80 in (0, 1):
+            N.set_knob("VT_IGEMM_BN80", bn80)
+            y = torch.full((B, Ho, Wo, Cout), float("nan"), device="cuda", dtype=TD[dtype])
+            stats = N.stats_buffer(Cout)
+            d = conv_desc(dtype, xd, Cin, Cout, k, s, pad, Cout, flags=N.VT_CONV_STATS)
+            N.check(N.lib().vt_conv_igemm(C.byref(d), vp(xd), vp(wd), vp(y), None, None, None, vp(stats), stream()))
+            names.append(N.last_kernel_name())
+            assert rel_err(to_nchw(y), ref) < tol(dtype), names
+            st = N.stats_decode(stats).cpu()
+            yy = y.double().reshape(-1, Cout).cpu()
+            np.testing.assert_allclose(st[0], yy.sum(0), rtol=1e-4, atol=1e-3)
+            np.testing.assert_allclose(st[1], (yy * yy).sum(0), rtol=1e-4, atol=1e-3)
+            ya = torch.full((B, Ho, Wo, Cout), float("nan"), device="cuda", dtype=TD[dtype])
+            d = conv_desc(dtype, xd, Cin, Cout, k, s, pad, Cout, flags=N.VT_CONV_AFFINE | N.VT_CONV_RELU | N.VT_CONV_RESIDUAL)
+            d.ldr = Cout
+            N.check(N.lib().vt_conv_igemm(C.byref(d), vp(xd), vp(wd), vp(ya), vp(scd), vp(sfd), vp(rd), None, stream()))
+            assert rel_err(to_nchw(ya), ref_aff) < tol(dtype), names
+            outs.append((y, ya))
+    finally:
+        N.set_knob("VT_IGEMM_SPAN", 1)
+        N.set_knob("VT_SPAN6", 1)
+        N.set_knob("VT_IGEMM_BN80", 1)
+    assert ",256,80," in names[1] and ",80," not in names[0], names
+    # same K order, same accumulators: the tile width does not change a single output
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("mode", ["0", "2", "3"], ids=["general_only", "span_forced", "span_256row_tiles"])
 def test_conv_kernel_variants_in_subprocess(mode):
     """vt_conv_igemm picks between the general gather kernel and the input-span kernel (and its

@@ -64,7 +64,13 @@ def main():
     if len(sys.argv) > 2:  # custom layers: Cin,Cout,k,s,H ...
         layers = [tuple(int(v) for v in a.split(",")) for a in sys.argv[2:]]
     for Cin, Cout, k, s, H in layers:
-        d, Ho = desc_for(B, Cin, Cout, k, s, H, 0 if os.environ.get("VT_BENCH_NOSTATS") else N.VT_CONV_STATS)
+        aff = bool(os.environ.get("VT_BENCH_AFFINE"))  # the inference epilogue (folded BatchNorm + ReLU [+ residual])
+        res = bool(os.environ.get("VT_BENCH_RESIDUAL"))
+        fl = (N.VT_CONV_AFFINE | N.VT_CONV_RELU | (N.VT_CONV_RESIDUAL if res else 0)) if aff else (
+            0 if os.environ.get("VT_BENCH_NOSTATS") else N.VT_CONV_STATS)
+        d, Ho = desc_for(B, Cin, Cout, k, s, H, fl)
+        d.ldr = Cout
+        sc, sf = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda") * 0.1
         x = torch.randn(B, H, H, Cin, device="cuda").to(torch.bfloat16)
         w = (torch.randn(Cout, k * k, Cin, device="cuda") * (2.0 / (k * k * Cin)) ** 0.5).to(torch.bfloat16)
         if os.environ.get("VT_BENCH_ZERO"):  # DVFS probe: the same launches on all-zero operands (guide: give-back item 1)
@@ -77,9 +83,11 @@ def main():
         flops = 2.0 * B * Ho * Ho * Cout * k * k * Cin
         line = f"{Cin:4d}->{Cout:4d} k{k} s{s} @{H:3d}  {flops / 1e9:7.1f} GF"
         if what in ("fwd", "all"):
-            ms = timeit(lambda st: N.check(lib.vt_conv_igemm(ctypes.byref(d), x.data_ptr(), w.data_ptr(), y.data_ptr(),
-                                                             None, None, None, stats.data_ptr(), st)))
-            line += f" | fwd {ms:7.4f} ms {flops / ms / 1e9:7.1f} TF/s"
+            resid = torch.randn(B, Ho, Ho, Cout, device="cuda").to(torch.bfloat16) if res else None
+            ms = timeit(lambda st: N.check(lib.vt_conv_igemm(
+                ctypes.byref(d), x.data_ptr(), w.data_ptr(), y.data_ptr(), sc.data_ptr() if aff else None,
+                sf.data_ptr() if aff else None, resid.data_ptr() if res else None, None if aff else stats.data_ptr(), st)))
+            line += f" | fwd {ms:7.4f} ms {flops / ms / 1e9:7.1f} TF/s [{N.last_kernel_name()}]"
         if what in ("wgrad", "all"):
             d0, _ = desc_for(B, Cin, Cout, k, s, H, 0)
             ms = timeit(lambda st: N.check(lib.vt_conv_wgrad(ctypes.byref(d0), x.data_ptr(), dz.data_ptr(),

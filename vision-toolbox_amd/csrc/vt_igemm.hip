@@ -54,7 +54,7 @@
 namespace {
 
 constexpr int kTapBytes = VT_MAX_TAPS * 16;  // int4 per tap
-constexpr int kStatBytes = 4 * 128 * 4;      // per row-wave (sum, sumsq): WM * 2 * BN floats, WM * BN <= 256
+constexpr int kStatBytes = 8 * 128 * 4;      // per row-wave (sum, sumsq): WM * 2 * BN floats, WM * BN <= 512
 constexpr int kHdrBytes = kTapBytes + kStatBytes;
 
 __device__ __attribute__((aligned(16))) unsigned int vt_zero16[4];  // source of every padded chunk
@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs p) {
     T* __restrict__ yg = (T*)p.y;
     const T* __restrict__ rg = (const T*)p.res;
     const bool has_res = (p.flags & VT_CONV_RESIDUAL) != 0;
-#pragma unroll 2
+#pragma unroll 4
     for (int idx = tid; idx < BM * CPR; idx += NT) {
         const int row = idx / CPR, ch = idx % CPR;
         const int m = tm * BM + row;
@@ -432,7 +432,8 @@ int launch(IgemmArgs& a, hipStream_t st) {
         const int rc = vt_raise_dynamic_lds((const void*)kern, smem, "vt_conv_igemm");
         if (rc != VT_OK) return rc;
     }
-    vt_note_kernel("igemm_kernel<%s,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", BM, BN, WM, WN, PD);
+    vt_note_kernel("igemm_kernel<%s,%d,%d,%d,%d,%d,uk%d>", sizeof(T) == 2 ? "bf16" : "f32", BM, BN, WM, WN, PD,
+                   (int)(a.Cin % BKe == 0));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, st, a);
     VT_CHECK_LAUNCH("vt_conv_igemm");
     return VT_OK;
@@ -525,6 +526,10 @@ extern "C" int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w
         // 96- and 64-row tiles (to dodge the "2.04 rounds" wave quantisation of 128-row tiles at
         // batch 256) measured 8-15 % SLOWER on the CSPDarknet-53 layers: the extra filter
         // staging per FLOP costs more than the idle tail saves.  One tile height.
+        // 80-wide filter tiles (5 fragments per wave, four row waves) where 128-wide ones would be 3/8 empty: the 80-
+        // and 160-channel layers of Darknet-YOLOv5x (80 -> 80 3x3 @160x160: 559 -> 420 us, the 6x6 stem 1316 -> 834 us;
+        // a 128-row tile of the same width measured 15-40 % slower).  VT_IGEMM_BN80=0: off
+        if (VT_KNOB("VT_IGEMM_BN80", 1) && d->Cout % 80 == 0 && d->Cout <= 160) return launch<bf16_t, 256, 80, 4, 1, 2>(a, st);
         if (d->Cout > 64) return launch<bf16_t, 128, 128, 2, 2, 2>(a, st);
         if (d->Cout > 32) return launch<bf16_t, 128, 64, 2, 2, 2>(a, st);
         return launch<bf16_t, 256, 32, 4, 1, 2>(a, st);
