@@ -381,54 +381,32 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs p) {
     T* __restrict__ yg = (T*)p.y;
     const T* __restrict__ rg = (const T*)p.res;
     const bool has_res = (p.flags & VT_CONV_RESIDUAL) != 0;
-    auto out_pixel = [&](int m) -> long {
-        if (p.dense_out) return m;
-        const int b = m / HoWo;
-        const int rem = m - b * HoWo;
-        const int oi = rem / p.Wo;
-        const int oj = rem - oi * p.Wo;
-        return ((long)b * p.oH + (oi * p.oHs + p.oh0)) * p.oW + (oj * p.oWs + p.ow0);
-    };
-    if (has_res) {
-        // residual rows in batches of four, every load of a batch in flight before its first use: loaded
-        // unconditionally (chunks outside the tensor read its first 16 bytes), so nothing orders a load behind the
-        // previous chunk's store -- a dependent load per chunk cost 70 us of an 80-channel YOLOv5x layer's 450
-        constexpr int ITER = (BM * CPR + NT - 1) / NT, RB = 4;
-#pragma unroll
-        for (int b0 = 0; b0 < ITER; b0 += RB) {
-            uint4 rr[RB];
-            long oy[RB];
-            bool ok[RB];
-#pragma unroll
-            for (int u = 0; u < RB; ++u) {
-                const int idx = tid + (b0 + u) * NT;
-                const int row = idx / CPR, ch = idx % CPR;
-                const int m = tm * BM + row;
-                const int n = tn * BN + ch * EPC;
-                ok[u] = b0 + u < ITER && idx < BM * CPR && m < p.M && n < p.Cout;
-                const long po = ok[u] ? out_pixel(m) : 0;
-                oy[u] = po * p.ldy + vt_out_col(p, n, p.ldy);
-                rr[u] = *(const uint4*)(rg + (ok[u] ? po * p.ldr + vt_out_col(p, n, p.ldr) : 0l));
-            }
-#pragma unroll
-            for (int u = 0; u < RB; ++u) {
-                if (!ok[u]) continue;
-                float fv[EPC], fr[EPC];
-                VecIO<T>::unpack(sOut4[tid + (b0 + u) * NT], fv);
-                VecIO<T>::unpack(rr[u], fr);
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) fv[e] += fr[e];
-                *(uint4*)(yg + oy[u]) = VecIO<T>::pack(fv);
-            }
-        }
-        return;
-    }
 #pragma unroll 2
     for (int idx = tid; idx < BM * CPR; idx += NT) {
         const int row = idx / CPR, ch = idx % CPR;
         const int m = tm * BM + row;
         const int n = tn * BN + ch * EPC;
-        if (m < p.M && n < p.Cout) *(uint4*)(yg + (out_pixel(m) * p.ldy + vt_out_col(p, n, p.ldy))) = sOut4[idx];
+        if (m < p.M && n < p.Cout) {
+            long po = m;
+            if (!p.dense_out) {
+                const int b = m / HoWo;
+                const int rem = m - b * HoWo;
+                const int oi = rem / p.Wo;
+                const int oj = rem - oi * p.Wo;
+                po = ((long)b * p.oH + (oi * p.oHs + p.oh0)) * p.oW + (oj * p.oWs + p.ow0);
+            }
+            uint4 v = sOut4[idx];
+            if (has_res) {
+                const uint4 r = *(const uint4*)(rg + (po * p.ldr + vt_out_col(p, n, p.ldr)));
+                float fv[EPC], fr[EPC];
+                VecIO<T>::unpack(v, fv);
+                VecIO<T>::unpack(r, fr);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) fv[e] += fr[e];
+                v = VecIO<T>::pack(fv);
+            }
+            *(uint4*)(yg + (po * p.ldy + vt_out_col(p, n, p.ldy))) = v;
+        }
     }
 }
 

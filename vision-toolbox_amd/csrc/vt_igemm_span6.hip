@@ -621,6 +621,21 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                         sf[e] = shift_[ne];
                     }
                 }
+                // the residual rows of this half, all in flight before the first one is used: loaded unconditionally
+                // (rows / channels outside the tensor read its first 16 bytes) so that nothing orders them behind the
+                // stores below -- one dependent load per row fragment cost 90 us of a 160-channel YOLOv5x layer's 400
+                // (MODE 2 only: the inference epilogue; the data gradient's accumulate keeps the in-place load)
+                constexpr bool kPreRes = MODE == 2;
+                uint4 rres[kPreRes ? FM : 1];
+                if (kPreRes && has_res) {
+#pragma unroll
+                    for (int i = 0; i < (kPreRes ? FM : 0); ++i) {
+                        const int tr = wrow + i * 16;
+                        const long po = sPo[tbl + tr];
+                        const bool ok = tr < rows_tile && po >= 0 && n < Cout_;
+                        rres[i] = *(const uint4*)(rg + (ok ? po * ldr_ + n : 0l));
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
                     const int tr = wrow + i * 16;       // row inside the tile
@@ -646,7 +661,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                             }
                         }
                         if (has_res) {
-                            const uint4 rr = *(const uint4*)(rg + (po * ldr_ + n));
+                            const uint4 rr = kPreRes ? rres[kPreRes ? i : 0] : *(const uint4*)(rg + (po * ldr_ + n));
                             float fv[8], fr[8];
                             VecIO<bf16_t>::unpack(out, fv);
                             VecIO<bf16_t>::unpack(rr, fr);
