@@ -480,6 +480,46 @@ def test_fork_behind_a_kernel_completion_event_orders_the_side_stream():
         torch.testing.assert_close(out, want, rtol=1e-4, atol=0.05 * r)
 
 
+@pytest.mark.parametrize("shape", [(2, 24, 20), (1, 8, 130), (3, 10, 256), (1, 64, 320), (2, 6, 2)], ids=str)
+@pytest.mark.parametrize("flags", [0, N.VT_CONV_AFFINE | N.VT_CONV_RELU, N.VT_CONV_AFFINE], ids=["raw", "affine_relu", "affine"])
+def test_yolov5_stem_kernel(shape, flags):
+    """6x6 stride-2 conv over padded-RGB pixels to 80 channels (the Darknet-YOLOv5x stem, vt_stem6.hip): against the
+    float64 convolution and against the gather kernel it replaces (same K order: the outputs must agree bit for bit),
+    on maps that end inside a 4 x 64 output block, with the output as a channel slice of a wider tensor."""
+    B, H, W = shape
+    dtype, Cin, Cout, k, s, pad = N.VT_BF16, 8, 80, 6, 2, 2
+    x = filler.tensor(f"s6x{shape}", (B, Cin, H, W))
+    x[:, 3:] = 0
+    w = filler.tensor(f"s6w{shape}", (Cout, Cin, k, k), scale=(2.0 / (3 * k * k)) ** 0.5)
+    sc = filler.tensor("s6s", (Cout,)).abs() + 0.5
+    sf = filler.tensor("s6f", (Cout,)) * 0.2
+    ref = F.conv2d(rounded(x, dtype).double(), rounded(w, dtype).double(), None, s, pad)
+    if flags & N.VT_CONV_AFFINE:
+        ref = ref * sc.double()[None, :, None, None] + sf.double()[None, :, None, None]
+    if flags & N.VT_CONV_RELU:
+        ref = torch.relu(ref)
+    xd, wd, scd, sfd = nhwc(x, dtype), krsc(w, dtype), sc.cuda(), sf.cuda()
+    Ho, Wo = ref.shape[2:]
+    ldy = 96
+    outs, names = [], []
+    try:
+        for on in (1, 0):
+            N.set_knob("VT_STEM6_KERNEL", on)
+            y = torch.full((B, Ho, Wo, ldy), 7.0, device="cuda", dtype=torch.bfloat16)
+            d = conv_desc(dtype, xd, Cin, Cout, k, s, pad, ldy, flags=flags)
+            N.check(N.lib().vt_conv_igemm(C.byref(d), vp(xd), vp(wd), vp(y), vp(scd) if flags else None, vp(sfd) if flags else None,
+                                          None, None, stream()))
+            torch.cuda.synchronize()
+            names.append(N.last_kernel_name())
+            outs.append(y)
+    finally:
+        N.set_knob("VT_STEM6_KERNEL", 1)
+    assert "stem6_kernel" in names[0] and "igemm_kernel" in names[1], names
+    assert (outs[0][..., Cout:] == 7.0).all()  # nothing outside the channel slice
+    assert rel_err(to_nchw(outs[0][..., :Cout]), ref) < tol(dtype)
+    assert torch.equal(outs[0], outs[1])
+
+
 RAGGED_K_CASES = [(2, 80, 80, 3, 1, 12, 12), (2, 80, 160, 3, 2, 16, 16), (3, 80, 80, 1, 1, 10, 7), (1, 48, 80, 3, 1, 9, 9),
                   (1, 80, 160, 3, 1, 20, 20), (2, 160, 80, 1, 1, 13, 9), (2, 8, 80, 6, 2, 24, 20)]
 

@@ -534,6 +534,8 @@ extern "C" int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w
     if (!d2s) {  // (these kernels write dense rows only)
         const int rc = vt_stem_dispatch(a, d->dtype, stream);  // RGB stem
         if (rc >= 0) return rc;
+        const int rc6 = vt_stem6_dispatch(a, d->dtype, stream);  // RGB stem of the YOLOv5 Darknets (6x6 stride 2)
+        if (rc6 >= 0) return rc6;
     }
     VT_REQUIRE(!(d->flags & VT_CONV_NOSTORE), VT_ERR_UNSUPPORTED, "vt_conv_igemm: NOSTORE outside the RGB stem kernel");
     if (!d2s) {  // (these kernels write dense rows only)

@@ -37,3 +37,7 @@ int vt_span6_dispatch(IgemmArgs& a, int dtype, void* stream);
 
 // vt_stem.hip: 3x3 stride-1 convolution over 8-channel (padded RGB) pixels; -1 when it does not apply.
 int vt_stem_dispatch(IgemmArgs& a, int dtype, void* stream);
+
+// vt_stem6.hip: 6x6 stride-2 convolution over 8-channel (padded RGB) pixels to 80 channels, inference epilogue
+// (the YOLOv5x stem); -1 when it does not apply.
+int vt_stem6_dispatch(IgemmArgs& a, int dtype, void* stream);
