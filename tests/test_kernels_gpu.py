@@ -526,9 +526,10 @@ RAGGED_K_CASES = [(2, 80, 80, 3, 1, 12, 12), (2, 80, 160, 3, 2, 16, 16), (3, 80,
 
 @pytest.mark.parametrize("case", RAGGED_K_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_gather_kernel_80_wide_tiles(case):
-    """80- and 160-channel outputs (Darknet-YOLOv5x) take 80-wide filter tiles on the gather kernel (VT_IGEMM_BN80):
-    with and without them against the float64 convolution, training and fused inference epilogue (with residual),
-    VT_IGEMM_SPAN=0 / VT_SPAN6=0 keeping the input-span kernels out."""
+    """80- and 160-channel outputs (Darknet-YOLOv5x) take 80- / 160-wide filter tiles on the gather kernel (VT_IGEMM_BN80;
+    VT_IGEMM_W8: 8-wave workgroups on 256 x 160 and 256 x 128 tiles): every tile shape against the float64 convolution,
+    training and fused inference epilogue (with residual), VT_IGEMM_SPAN=0 / VT_SPAN6=0 keeping the input-span
+    kernels out."""
     dtype = N.VT_BF16
     B, Cin, Cout, k, s, H, W = case
     pad = _pad(k, s)
@@ -546,8 +547,9 @@ def test_gather_kernel_80_wide_tiles(case):
     try:
         N.set_knob("VT_IGEMM_SPAN", 0)
         N.set_knob("VT_SPAN6", 0)
-        for bn80 in (0, 1):
+        for bn80, w8 in ((0, 0), (1, 0), (1, 7), (0, 6)):  # (bit 2: the 8-wave tile on small maps too)
             N.set_knob("VT_IGEMM_BN80", bn80)
+            N.set_knob("VT_IGEMM_W8", w8)
             y = torch.full((B, Ho, Wo, Cout), float("nan"), device="cuda", dtype=TD[dtype])
             stats = N.stats_buffer(Cout)
             d = conv_desc(dtype, xd, Cin, Cout, k, s, pad, Cout, flags=N.VT_CONV_STATS)
@@ -568,9 +570,12 @@ def test_gather_kernel_80_wide_tiles(case):
         N.set_knob("VT_IGEMM_SPAN", 1)
         N.set_knob("VT_SPAN6", 1)
         N.set_knob("VT_IGEMM_BN80", 1)
-    assert ",256,80," in names[1] and ",80," not in names[0], names
-    # same K order, same accumulators: the tile width does not change a single output
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        N.set_knob("VT_IGEMM_W8", 3)
+    assert ",256,80," in names[1] and ",80," not in names[0] and ",160," not in names[0], names
+    assert (",256,160,4,2," if Cout == 160 else ",256,80,") in names[2] and ",256,128,4,2," in names[3], names
+    # same K order, same accumulators: the tile shape does not change a single output
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1])
 
 
 @pytest.mark.parametrize("mode", ["0", "2", "3"], ids=["general_only", "span_forced", "span_256row_tiles"])

@@ -1,3 +1,4 @@
 set -e
-timeout -k 10 120 python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "yolov5_stem" 2>&1 | tail -15
-for i in 1 2; do for on in 1 0; do echo "STEM6=$on"; VT_STEM6_KERNEL=$on VT_BENCH_BATCH=64 VT_BENCH_AFFINE=1 timeout -k 10 120 python tools/bench_conv.py fwd 8,80,6,2,640 2>&1 | grep -v "variant\|amdgpu.ids"; done; done
+timeout -k 10 200 python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "80_wide" 2>&1 | tail -2
+run() { timeout -k 10 300 python bench.py --no-secondary --no-cpu-baseline --no-pmc 2>&1 | grep -o '"ms_per_step": [0-9.]*'; }
+for i in 1 2; do for w8 in 1 3; do echo "W8=$w8"; export VT_IGEMM_W8=$w8; run; timeout -k 10 200 python tools/bench_configs.py 5 2>&1 | grep -o '"ms": [0-9.]*'; done; done

@@ -54,8 +54,8 @@
 namespace {
 
 constexpr int kTapBytes = VT_MAX_TAPS * 16;  // int4 per tap
-constexpr int kStatBytes = 8 * 128 * 4;      // per row-wave (sum, sumsq): WM * 2 * BN floats, WM * BN <= 512
-constexpr int kHdrBytes = kTapBytes + kStatBytes;
+// statistics scratch, per row-wave (sum, sumsq): WM * 2 * BN floats, at least 2 KiB
+constexpr int stat_bytes(int WM, int BN) { return WM * 2 * BN * 4 > 2048 ? WM * 2 * BN * 4 : 2048; }
 
 __device__ __attribute__((aligned(16))) unsigned int vt_zero16[4];  // source of every padded chunk
 
@@ -99,27 +99,30 @@ __device__ __forceinline__ void mma<float>(const uint4& a, const uint4& b, f32x4
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
 }
 
-template <int BM, int BN, int PD>
+template <int BM, int BN, int PD, int NW, int WM>
 struct Geom {
     static constexpr int NI_A = BM / 16;                // DMA instructions covering the A tile
     static constexpr int NI = (BM + BN) / 16;           // ... the whole stage
-    static constexpr int IT = (NI + 3) / 4;             // per wave (4 waves), padded with dummies
-    static constexpr int SS = IT * 4 * 64;              // uint4 slots per stage incl. dummy area
+    static constexpr int IT = (NI + NW - 1) / NW;       // per wave (NW waves), padded with dummies
+    static constexpr int SS = IT * NW * 64;             // uint4 slots per stage incl. dummy area
+    static constexpr int HDR = kTapBytes + stat_bytes(WM, BN);
     static constexpr int NS = PD + 1;                   // stage slots
     static constexpr int STAGE_BYTES = NS * SS * 16;
 };
 
 template <typename T, int BM, int BN, int WM, int WN, int PD, bool UK>
-__global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs p) {
-    using G = Geom<BM, BN, PD>;
-    constexpr int NT = 256;
+__global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(const IgemmArgs p) {
+    constexpr int NW = WM * WN;  // waves: 4, or 8 for the 256-row tiles of 128 / 160 filter columns
+    using G = Geom<BM, BN, PD, NW, WM>;
+    constexpr int NT = 64 * NW;
+    constexpr int kHdrBytes = G::HDR;
     constexpr int EPC = 16 / sizeof(T);
     constexpr int BK = 4 * EPC;
     constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
     constexpr int IT = G::IT, SS = G::SS, NS = G::NS;
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile must be 16-granular");
-    static_assert(BN <= 128, "stat scratch sized for BN <= 128");
+    static_assert(BN <= 160, "filter tile width");
     static_assert(BM % 16 == 0 && BN % 16 == 0, "tile rows come in groups of 16 per DMA instruction");
     static_assert(PD >= 1 && PD <= 3, "prefetch distance");
 
@@ -160,7 +163,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs p) {
     const unsigned ring_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)sStage;
 
     // ---- per-lane DMA geometry (fixed for the whole K loop) --------------------
-    // instruction j = wave + 4*i of a stage fills slots [64j, 64j+64); lane l owns slot
+    // instruction j = wave + NW*i of a stage fills slots [64j, 64j+64); lane l owns slot
     // q = 64j + l = row (q>>2), position (q&3), and fetches chunk (q&3) ^ swz(row).
     // (row>>2)&3 == (l>>4)&3 for every j, so the chunk is the same for all of a lane's loads.
     const int cj = (lane & 3) ^ ((0x1320 >> (((lane >> 4) & 3) * 4)) & 3);
@@ -170,7 +173,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs p) {
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-        const int j = wave + 4 * i;
+        const int j = wave + NW * i;
         hb[i] = wb[i] = 0;
         off0[i] = 0;
         valid[i] = false;
@@ -209,7 +212,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs p) {
     if constexpr (UK) {
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
-            const int j = wave + 4 * i;
+            const int j = wave + NW * i;
             abase[i] = (unsigned long)(xg + (off0[i] + cj * EPC));
             amask[i] = 0;
             bptr[i] = zero_src;
@@ -235,8 +238,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs p) {
         if constexpr (UK) {                                                                     \
             const long koff = ((long)__builtin_amdgcn_readfirstlane(sTap[tap_u].z) + c0_u) * (long)sizeof(T); \
             _Pragma("unroll") for (int i = 0; i < IT; ++i) {                                    \
-                const int j = wave + 4 * i;                                                     \
-                const bool isA = (4 * i + 3 < G::NI_A) ? true : (4 * i >= G::NI_A ? false : j < G::NI_A); \
+                const int j = wave + NW * i;                                                     \
+                const bool isA = (NW * i + NW - 1 < G::NI_A) ? true : (NW * i >= G::NI_A ? false : j < G::NI_A); \
                 unsigned long ps;                                                               \
                 if (isA) {                                                                      \
                     ps = ((amask[i] >> tap_u) & 1ul) ? abase[i] + koff : zero_src;              \
@@ -256,10 +259,10 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs p) {
         const bool kval = tap < p.ntaps;                                                        \
         const int4 te = sTap[kval ? tap : 0];                                                   \
         _Pragma("unroll") for (int i = 0; i < IT; ++i) {                                        \
-            const int j = wave + 4 * i;                                                         \
+            const int j = wave + NW * i;                                                         \
             /* A / B / dummy is known at compile time unless the boundary cuts a group of 4 */  \
-            const bool isA = (4 * i + 3 < G::NI_A) ? true : (4 * i >= G::NI_A ? false : j < G::NI_A); \
-            const bool isB = !isA && ((4 * i + 3 < G::NI) ? true : (4 * i >= G::NI ? false : j < G::NI)); \
+            const bool isA = (NW * i + NW - 1 < G::NI_A) ? true : (NW * i >= G::NI_A ? false : j < G::NI_A); \
+            const bool isB = !isA && ((NW * i + NW - 1 < G::NI) ? true : (NW * i >= G::NI ? false : j < G::NI)); \
             const bool va = kval && valid[i] && (unsigned)(hb[i] + te.x) < (unsigned)p.Hi &&    \
                             (unsigned)(wb[i] + te.y) < (unsigned)p.Wi;                          \
             const unsigned long pa = (unsigned long)(xg + (off0[i] + te.z + c));                \
@@ -365,7 +368,6 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs p) {
     __syncthreads();
 
     if (stats && tid < 2 * BN) {
-        static_assert(WM * 2 * BN * 4 <= kStatBytes, "statistics staging");
         const int which = tid / BN, col = tid % BN;
         const int n = tn * BN + col;
         if (n < p.Cout) {
@@ -434,7 +436,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmArgs p) {
 
 template <typename T, int BM, int BN, int WM, int WN, int PD>
 int launch(IgemmArgs& a, hipStream_t st) {
-    using G = Geom<BM, BN, PD>;
+    using G = Geom<BM, BN, PD, WM * WN, WM>;
+    constexpr int kHdrBytes = G::HDR;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.Cout + BN - 1) / BN;
     a.chunk = (a.tiles_m + 7) / 8;
@@ -456,7 +459,7 @@ int launch(IgemmArgs& a, hipStream_t st) {
     }
     vt_note_kernel("igemm_kernel<%s,%d,%d,%d,%d,%d,uk%d>", sizeof(T) == 2 ? "bf16" : "f32", BM, BN, WM, WN, PD,
                    (int)(a.Cin % BKe == 0));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * WM * WN), smem, st, a);
     VT_CHECK_LAUNCH("vt_conv_igemm");
     return VT_OK;
 }
@@ -553,7 +556,17 @@ extern "C" int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w
         // 80-wide filter tiles (5 fragments per wave, four row waves) where 128-wide ones would be 3/8 empty: the 80-
         // and 160-channel layers of Darknet-YOLOv5x (80 -> 80 3x3 @160x160: 559 -> 420 us, the 6x6 stem 1316 -> 834 us;
         // a 128-row tile of the same width measured 15-40 % slower).  VT_IGEMM_BN80=0: off
-        if (VT_KNOB("VT_IGEMM_BN80", 1) && d->Cout % 80 == 0 && d->Cout <= 160) return launch<bf16_t, 256, 80, 4, 1, 2>(a, st);
+        // VT_IGEMM_W8: 8-wave workgroups on 256-row tiles (bit 0: 160 columns for Cout = 160; bit 1: 128 columns for
+        // every Cout > 64) -- the gathered rows are staged once per 160 / 128 filter columns instead of once per 80 / per
+        // 128 rows of half the height
+        const int w8 = VT_KNOB("VT_IGEMM_W8", 3);
+        if (VT_KNOB("VT_IGEMM_BN80", 1) && d->Cout % 80 == 0 && d->Cout <= 160) {
+            if ((w8 & 1) && d->Cout == 160) return launch<bf16_t, 256, 160, 4, 2, 2>(a, st);
+            return launch<bf16_t, 256, 80, 4, 1, 2>(a, st);
+        }
+        // (maps too small to give every CU a 256-row tile keep the 128-row one: 512 -> 512 @7x7 at batch 256)
+        if (d->Cout > 64 && (w8 & 2) && ((long)(a.M + 255) / 256) * ((d->Cout + 127) / 128) >= ((w8 & 4) ? 0 : 256))
+            return launch<bf16_t, 256, 128, 4, 2, 2>(a, st);
         if (d->Cout > 64) return launch<bf16_t, 128, 128, 2, 2, 2>(a, st);
         if (d->Cout > 32) return launch<bf16_t, 128, 64, 2, 2, 2>(a, st);
         return launch<bf16_t, 256, 32, 4, 1, 2>(a, st);
