@@ -1,4 +1,5 @@
 set -e
-timeout -k 10 200 python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "80_wide" 2>&1 | tail -2
-run() { timeout -k 10 300 python bench.py --no-secondary --no-cpu-baseline --no-pmc 2>&1 | grep -o '"ms_per_step": [0-9.]*'; }
-for i in 1 2; do for w8 in 1 3; do echo "W8=$w8"; export VT_IGEMM_W8=$w8; run; timeout -k 10 200 python tools/bench_configs.py 5 2>&1 | grep -o '"ms": [0-9.]*'; done; done
+L64="160,320,3,2,160 320,640,3,2,80 640,1280,3,2,40"
+for i in 1 2; do for b in 1 2; do echo "BN80=$b";
+  VT_IGEMM_BN80=$b VT_BENCH_BATCH=64 VT_BENCH_AFFINE=1 timeout -k 10 120 python tools/bench_conv.py fwd $L64 2>&1 | grep -v "variant\|amdgpu.ids" | cut -c1-110
+done; done
