@@ -67,7 +67,7 @@ def main():
         aff = bool(os.environ.get("VT_BENCH_AFFINE"))  # the inference epilogue (folded BatchNorm + ReLU [+ residual])
         res = bool(os.environ.get("VT_BENCH_RESIDUAL"))
         fl = (N.VT_CONV_AFFINE | N.VT_CONV_RELU | (N.VT_CONV_RESIDUAL if res else 0)) if aff else (
-            0 if os.environ.get("VT_BENCH_NOSTATS") else N.VT_CONV_STATS)
+            N.VT_CONV_RESIDUAL if res else (0 if os.environ.get("VT_BENCH_NOSTATS") else N.VT_CONV_STATS))  # res alone: a data gradient's accumulate
         d, Ho = desc_for(B, Cin, Cout, k, s, H, fl)
         d.ldr = Cout
         sc, sf = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda") * 0.1
@@ -86,7 +86,7 @@ def main():
             resid = torch.randn(B, Ho, Ho, Cout, device="cuda").to(torch.bfloat16) if res else None
             ms = timeit(lambda st: N.check(lib.vt_conv_igemm(
                 ctypes.byref(d), x.data_ptr(), w.data_ptr(), y.data_ptr(), sc.data_ptr() if aff else None,
-                sf.data_ptr() if aff else None, resid.data_ptr() if res else None, None if aff else stats.data_ptr(), st)))
+                sf.data_ptr() if aff else None, resid.data_ptr() if res else None, None if (aff or res) else stats.data_ptr(), st)))
             line += f" | fwd {ms:7.4f} ms {flops / ms / 1e9:7.1f} TF/s [{N.last_kernel_name()}]"
         if what in ("wgrad", "all"):
             d0, _ = desc_for(B, Cin, Cout, k, s, H, 0)

@@ -592,22 +592,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
     const int rrow = lane / CPRW, rch = lane % CPRW;
     const int ncol = tn * BN + wn * TN + rch * EPC;
     const long ycol = vt_out_col(p, ncol, p.ldy), rcol = vt_out_col(p, ncol, p.ldr);
-    // residual chunks one slab ahead of their use, loaded unconditionally (chunks outside the tensor read its first
-    // 16 bytes): nothing orders a load behind the previous slab's stores (the accumulate of the 1x1 data gradients)
-    uint4 rcur[NPASS], rnxt[NPASS];
-    auto fetch_res = [&](int i, uint4 (&dst)[NPASS]) {
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            const int lr = ps * RPP + rrow;
-            const int tr = wm * TM + i * 16 + lr;
-            const bool ok = lr < 16 && m0 + tr < p.M && ncol < p.Cout;
-            dst[ps] = *(const uint4*)(rg + (ok ? (long)sPo[ok ? tr : 0] * p.ldr + rcol : 0l));
-        }
-    };
-    if (has_res) fetch_res(0, rcur);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-        if (has_res && i + 1 < FM) fetch_res(i + 1, rnxt);
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
 #pragma unroll
@@ -633,7 +619,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
                     const long po = sPo[tr];
                     uint4 v = raw;
                     if (has_res) {
-                        const uint4 rr = rcur[ps];
+                        const uint4 rr = *(const uint4*)(rg + (po * p.ldr + rcol));
                         float fv[EPC], fr[EPC];
                         VecIO<T>::unpack(v, fv);
                         VecIO<T>::unpack(rr, fr);
@@ -646,8 +632,6 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
             }
         }
         lds_fence();
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) rcur[ps] = rnxt[ps];
     }
     if (stats) {  // (uniform per launch: every wave takes the barriers)
         // The WM row-waves of a column fold their partials in LDS in a fixed order and ONE fixed-point atomic leaves
