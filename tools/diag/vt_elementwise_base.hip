@@ -404,14 +404,6 @@ maxpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
             const long t2 = row / Wo;
             const int ho = (int)(t2 % Ho);
             const long b = t2 / Ho;
-            // all nine taps in flight before the first comparison: loaded unconditionally from clamped coordinates
-            // (a dependent, predicated load per tap made the pass 3.5x its HBM time)
-            uint4 raw[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const int h = min(max(ho * 2 - 1 + k / 3, 0), H - 1), w = min(max(wo * 2 - 1 + k % 3, 0), W - 1);
-                raw[k] = ld16(x + ((b * H + h) * W + w) * ldx + col * EPC);
-            }
             float best[EPC];
             int bi[EPC];
 #pragma unroll
@@ -421,28 +413,29 @@ maxpool_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
             }
             bool first = true;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const int h = ho * 2 - 1 + k / 3, w = wo * 2 - 1 + k % 3;
-                if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
-                    float v[EPC];
-                    VecIO<T>::unpack(raw[k], v);
+            for (int dr = 0; dr < 3; ++dr) {
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) {
-                        // ATen: first max in (kh, kw) scan order wins; NaN propagates
-                        if (first || v[e] > best[e] || v[e] != v[e]) {
-                            best[e] = v[e];
-                            bi[e] = k;
+                for (int dc = 0; dc < 3; ++dc) {
+                    const int h = ho * 2 - 1 + dr, w = wo * 2 - 1 + dc;
+                    if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+                        float v[EPC];
+                        VecIO<T>::unpack(ld16(x + ((b * H + h) * W + w) * ldx + col * EPC), v);
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) {
+                            // ATen: first max in (kh, kw) scan order wins; NaN propagates
+                            if (first || v[e] > best[e] || v[e] != v[e]) {
+                                best[e] = v[e];
+                                bi[e] = dr * 3 + dc;
+                            }
                         }
+                        first = false;
                     }
-                    first = false;
                 }
             }
             st16(y + row * ldy + col * EPC, VecIO<T>::pack(best));
-            // the EPC tap indices of the chunk as one 4- / 8-byte store
-            unsigned* ap = (unsigned*)(amax + row * C + col * EPC);
+            uint8_t* ap = amax + row * C + col * EPC;
 #pragma unroll
-            for (int q = 0; q < EPC / 4; ++q)
-                ap[q] = (unsigned)bi[4 * q] | ((unsigned)bi[4 * q + 1] << 8) | ((unsigned)bi[4 * q + 2] << 16) | ((unsigned)bi[4 * q + 3] << 24);
+            for (int e = 0; e < EPC; ++e) ap[e] = (uint8_t)bi[e];
         }
     }
 }
@@ -468,36 +461,22 @@ maxpool_bwd_kernel(const T* __restrict__ dy, int lddy, const uint8_t* __restrict
 #pragma unroll
             for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
             if (accumulate) VecIO<T>::unpack(ld16(dx + row * lddx + col * EPC), acc);
-            // windows (ho, wo) with ho*2-1 <= h <= ho*2+1: one for an even coordinate, two for an odd one.  The loads
-            // of all of them (gradient chunk + tap indices) are issued before the first use.
-            const int ho_lo = h >> 1, wo_lo = w >> 1;
-            uint4 gr[4];
-            unsigned ar[4][EPC / 4];
-            bool need[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int ho = ho_lo + (k >> 1), wo = wo_lo + (k & 1);
-                need[k] = (k >> 1) <= (h & 1) && (k & 1) <= (w & 1) && ho < Ho && wo < Wo;
-                gr[k] = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-                for (int q = 0; q < EPC / 4; ++q) ar[k][q] = 0xffffffffu;
-                if (need[k]) {
+            // windows (ho, wo) with ho*2-1 <= h <= ho*2+1
+            const int ho_lo = h >> 1, ho_hi = (h + 1) >> 1;
+            const int wo_lo = w >> 1, wo_hi = (w + 1) >> 1;
+            for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+                if (ho >= Ho) continue;
+                for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                    if (wo >= Wo) continue;
+                    const int tap = (h - (ho * 2 - 1)) * 3 + (w - (wo * 2 - 1));
                     const long orow = (b * Ho + ho) * Wo + wo;
-                    gr[k] = ld16(dy + orow * lddy + col * EPC);
-                    const unsigned* ap = (const unsigned*)(amax + orow * C + col * EPC);
+                    float g[EPC];
+                    VecIO<T>::unpack(ld16(dy + orow * lddy + col * EPC), g);
+                    const uint8_t* ap = amax + orow * C + col * EPC;
 #pragma unroll
-                    for (int q = 0; q < EPC / 4; ++q) ar[k][q] = ap[q];
+                    for (int e = 0; e < EPC; ++e)
+                        if (ap[e] == tap) acc[e] += g[e];
                 }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int ho = ho_lo + (k >> 1), wo = wo_lo + (k & 1);
-                const unsigned tap = (unsigned)((h - (ho * 2 - 1)) * 3 + (w - (wo * 2 - 1)));
-                float g[EPC];
-                VecIO<T>::unpack(gr[k], g);
-#pragma unroll
-                for (int e = 0; e < EPC; ++e)
-                    if (need[k] && ((ar[k][e >> 2] >> (8 * (e & 3))) & 0xffu) == tap) acc[e] += g[e];
             }
             st16(dx + row * lddx + col * EPC, VecIO<T>::pack(acc));
         }
