@@ -66,6 +66,9 @@ CASES = [
     (2048, 128, [64, 64], 16, True),  # CSP stage 1 (filter gradient outside the kernel)
     (1555, 128, [128], 0, True),
     (1024, 128, [64], 0, False),
+    (1555, 160, [160], 0, True),     # Darknet-YOLOv5x bottleneck conv1 (inference runs the apply pass alone)
+    (2048, 160, [160], 16, False),
+    (1024, 160, [96, 64], 0, True),
 ]
 
 

@@ -272,6 +272,7 @@ class Builder:
         # passes of the unfused path, which is then as fast (measured at batch 256, CSPDarknet-53: 22.40 ms with the 51 MB
         # tensors of stage 2 included, 22.11 without; 23.32 with the pointwise path off)
         self.pointwise_min_mb = float(os.environ.get("VT_PW_MIN_MB", "80"))
+        self.pointwise_inference = os.environ.get("VT_PW_INFERENCE", "1") != "0"
         self._hoisted: list[N.Op] = []
         # SyncBatchNorm (configs/base.yaml:22): the trainer all-reduces every layer's statistics
         # between the kernel that accumulates them and the finalize kernel; the finalize kernels
@@ -745,8 +746,11 @@ class Builder:
         if len(flags) != 1 or len({sp[3] is None for sp in specs}) != 1:  # (a residual for every group or for none)
             return 0
         unit_training, _ = next(iter(flags))
-        if not unit_training and not self.need_grad:
-            return 0  # inference: one conv launch with the affine + ReLU epilogue is already a single pass
+        # (inference: the apply pass alone, with the running-statistics coefficients -- it streams x once at ~5.5 TB/s
+        #  where the conv launch with the affine + ReLU epilogue stages it through LDS at ~2.7: 160 -> 160 @80x80 x 64
+        #  images, 46 vs 91 us.  VT_PW_INFERENCE=0: the conv launch)
+        if not unit_training and not self.need_grad and not self.pointwise_inference:
+            return 0
         if self.need_grad and not x.needs_grad:
             return 0  # (the backward kernel always forms dx)
         if x.M * x.C * 2 < self.pointwise_min_mb * 1e6:
