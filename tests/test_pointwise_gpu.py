@@ -69,6 +69,7 @@ CASES = [
     (1555, 160, [160], 0, True),     # Darknet-YOLOv5x bottleneck conv1 (inference runs the apply pass alone)
     (2048, 160, [160], 16, False),
     (1024, 160, [96, 64], 0, True),
+    (1100, 320, [160], 0, True),     # Darknet-YOLOv5x CSP conv1 / conv2 of the 320-channel stage
 ]
 
 

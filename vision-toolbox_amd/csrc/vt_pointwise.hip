@@ -522,6 +522,7 @@ int dispatch_pw(int N, int K, const PwArgs& a, hipStream_t st, const char* who) 
     VT_PW_CASE(128, 128)
     VT_PW_CASE(64, 128)
     VT_PW_CASE(160, 160)
+    VT_PW_CASE(160, 320)
 #undef VT_PW_CASE
     vt_set_error("%s: no pointwise kernel for %d -> %d channels", who, K, N);
     return VT_ERR_UNSUPPORTED;
@@ -529,7 +530,7 @@ int dispatch_pw(int N, int K, const PwArgs& a, hipStream_t st, const char* who) 
 
 bool shape_ok(int N, int K) {
     return (N == 32 && K == 32) || (N == 64 && K == 64) || (N == 32 && K == 64) || (N == 128 && K == 128) ||
-           (N == 64 && K == 128) || (N == 160 && K == 160);
+           (N == 64 && K == 128) || (N == 160 && K == 160) || (N == 160 && K == 320);
 }
 
 int fill_common(PwArgs& a, const vt_pw_desc* d, const char* who) {
