@@ -101,3 +101,36 @@ def test_span6_is_bit_identical_to_the_span_kernel(shape, mode):
     if s0 is not None:
         # the statistics are sums of the (same) stored values in a different order
         torch.testing.assert_close(s1, s0, rtol=2e-3 if "span_kernel" not in n0 else 1e-5, atol=0.5)
+
+
+@pytest.mark.parametrize("mode", [m for m in MODES if m[0] != "stats"], ids=[m[0] for m in MODES if m[0] != "stats"])
+def test_160_columns_run_as_128_on_span6_plus_32_on_the_span_kernel(mode):
+    """Cout = 128 k + 32 without batch statistics (Darknet-YOLOv5x's 160-channel layers; VoVNet-39's data gradients): two
+    launches over the same input, columns [0, 128) on span6 and [128, 160) on the input-span kernel's 32-wide tile
+    (VT_SPAN6_SPLIT).  Same values as the unsplit launch, nothing outside the channel slice."""
+    B, Cin, Cout, H, W = 16, 96, 160, 64, 80
+    flags = mode[1]
+    torch.manual_seed(11)
+    ldx, ldy = Cin + 32, Cout + 64
+    xb = torch.randn(B, H, W, ldx, device="cuda").to(torch.bfloat16)
+    x = xb[..., 16:16 + Cin]
+    w = (torch.randn(Cout, 9, Cin, device="cuda") * (2.0 / (9 * Cin)) ** 0.5).to(torch.bfloat16)
+    res = torch.randn(B, H, W, Cout, device="cuda").to(torch.bfloat16) if flags & N.VT_CONV_RESIDUAL else None
+    scale = torch.rand(Cout, device="cuda") + 0.5 if flags & N.VT_CONV_AFFINE else None
+    shift = torch.randn(Cout, device="cuda") if flags & N.VT_CONV_AFFINE else None
+    d = _desc(B, Cin, Cout, H, W, ldx, ldy, Cout if res is not None else 0, flags, flip=False)
+    outs, launches = [], []
+    try:
+        for split in (2, 0):  # (2: the inference epilogues too; by default only the data gradients are split)
+            N.set_knob("VT_SPAN6_SPLIT", split)
+            yb = torch.full((B, H, W, ldy), float("nan"), device="cuda", dtype=torch.bfloat16)
+            before = N.launch_count()
+            name = _run("2", d, x, w, yb[..., 32:32 + Cout], scale, shift, res, None)
+            launches.append(N.launch_count() - before)
+            assert "span6" in name
+            outs.append(yb)
+    finally:
+        N.set_knob("VT_SPAN6_SPLIT", 1)
+    assert launches == [2, 1], launches
+    assert torch.equal(torch.isnan(outs[0].float()), torch.isnan(outs[1].float()))
+    assert torch.equal(torch.nan_to_num(outs[0].float()), torch.nan_to_num(outs[1].float()))

@@ -720,8 +720,8 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
 
 }  // namespace
 
-// returns -1 when this kernel does not apply (the caller then tries the other span kernels)
-int vt_span6_dispatch(IgemmArgs& a0, int dtype, void* stream) {
+// returns -1 when this kernel does not apply; `dry`: every check, no launch
+static int span6_run(IgemmArgs& a0, int dtype, void* stream, bool dry) {
     // VT_SPAN6=0 disables, =2 forces this kernel wherever it applies (tests); default: the layers it measured faster
     // on than vt_igemm_span.hip (128-wide filter tiles on maps of 20 x 20 and larger, where the padded coordinates
     // cost <= 10 % extra MFMA work)
@@ -779,6 +779,7 @@ int vt_span6_dispatch(IgemmArgs& a0, int dtype, void* stream) {
     if (mode == 1 && (p.flags & (VT_CONV_AFFINE | VT_CONV_RELU | VT_CONV_RESIDUAL))) return -1;
     if (mode == 0 && (p.flags & VT_CONV_RELU)) return -1;
     auto kern = mode == 1 ? span6_kernel<1> : (mode == 2 ? span6_kernel<2> : span6_kernel<0>);
+    if (dry) return VT_OK;
     {
         const int rc = vt_raise_dynamic_lds((const void*)kern, 160 * 1024, "vt_conv_igemm(span6)");
         if (rc != VT_OK) return rc;
@@ -815,4 +816,36 @@ int vt_span6_dispatch(IgemmArgs& a0, int dtype, void* stream) {
         }
     }
     return VT_OK;
+}
+
+// returns -1 when this kernel does not apply (the caller then tries the other span kernels)
+int vt_span6_dispatch(IgemmArgs& a0, int dtype, void* stream) {
+    // 128 k + 32 output channels (160: Darknet-YOLOv5x, VoVNet-39): the filter tiles are 128 wide, so the last one would
+    // be a quarter full and cost as much as a full one.  The first 128 k columns run here, the last 32 on the input-span
+    // kernel's 32-wide tile as a second launch over the same input (160 -> 160 @80x80 x 64 images, residual epilogue:
+    // 360 -> 186 + 110 us alone).  Not with batch statistics (their buffer is indexed by the launch's own channel count),
+    // not for 64 remaining columns (192 @14x14: 60 us whole, 42 + 32 split).  By default (VT_SPAN6_SPLIT=1) only the data
+    // gradients take it (VoVNet-39 step 25.87 -> 25.70 ms); inside the YOLOv5x forward the pair measured no faster than
+    // the whole launch (305 vs 320 us per layer in the trace, 13.64 vs 13.56 ms per forward): =2 splits those too, =0 none
+    const int rem = a0.Cout % 128;
+    const int split = VT_KNOB("VT_SPAN6_SPLIT", 1);
+    if (split && a0.Cout > 128 && rem == 32 && dtype == VT_BF16 && (split >= 2 || !(a0.flags & VT_CONV_AFFINE)) &&
+        !(a0.flags & (VT_CONV_STATS | VT_CONV_D2S | VT_CONV_NOSTORE))) {
+        const int head = a0.Cout - rem;
+        IgemmArgs a1 = a0;
+        a1.Cout = head;
+        if (span6_run(a1, dtype, stream, true) == VT_OK) {
+            IgemmArgs a2 = a0;
+            a2.Cout = rem;
+            a2.w = (const char*)a0.w + (long)head * a0.ldw * 2;
+            a2.y = (char*)a0.y + (long)head * 2;
+            if (a0.res) a2.res = (const char*)a0.res + (long)head * 2;
+            if (a0.scale) a2.scale = a0.scale + head;
+            if (a0.shift) a2.shift = a0.shift + head;
+            const int rc2 = vt_span_dispatch(a2, dtype, stream);
+            if (rc2 == VT_OK) return span6_run(a1, dtype, stream, false);
+            if (rc2 != -1) return rc2;
+        }
+    }
+    return span6_run(a0, dtype, stream, false);
 }
