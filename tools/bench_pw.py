@@ -47,6 +47,8 @@ def main():
     full = N.lib().vt_pw_supported(N.VT_BF16, K, cs[0], cs[1] if len(cs) > 1 else 0) == 2
     dws = [torch.zeros(c, K, device="cuda") if full else None for c in cs]
     dzs = [None if full else torch.zeros(M, c, device="cuda", dtype=BF) for c in cs]
+    import os
+    ress = [torch.randn(M, c, device="cuda").to(BF) if os.environ.get("VT_BENCH_RESIDUAL") else None for c in cs]  # apply + residual
     s = int(torch.cuda.current_stream().cuda_stream)
     lib = N.lib()
 
@@ -54,7 +56,7 @@ def main():
         if mode == "stats":
             N.check(lib.vt_pw_fwd_stats(C.byref(d), vps(stats), s))
         elif mode == "apply":
-            N.check(lib.vt_pw_fwd_apply(C.byref(d), coef.data_ptr(), vps(ys), ld, vps([None] * len(cs)), arr(C.c_int32, [0, 0]), s))
+            N.check(lib.vt_pw_fwd_apply(C.byref(d), coef.data_ptr(), vps(ys), ld, vps(ress), ld if ress[0] is not None else arr(C.c_int32, [0, 0]), s))
         elif mode == "reduce":
             N.check(lib.vt_pw_bwd_reduce(C.byref(d), coef.data_ptr(), vps(ys), ld, vps(stats), s))
         else:
