@@ -816,6 +816,14 @@ int vt_span_dispatch(IgemmArgs& a, int dtype, void* stream) {
         dmax = d > dmax ? d : dmax;
     }
     hipStream_t st = (hipStream_t)stream;
+    // Plain GEMMs with a long K or many filter columns (1x1 convs with >= 320 channels on either side: the OSA
+    // aggregation convs of VoVNet-39, the 14x14 stage of CSPDarknet-53): the gather kernel's 8-wave 256 x 128 tile stages
+    // the rows once per 128 columns for 16 waves per CU and measured 7-20 % faster there (768 -> 256 @56x56, B=256:
+    // 632 -> 570 us; 1472 -> 768 @14x14: 171 -> 136 us; 256 -> 256 @28x28: equal).  VT_SPAN_GEMM=1: keep them here
+    const int gemm_minc = VT_KNOB("VT_SPAN_GEMM_MINC", 320);
+    if (dtype == VT_BF16 && a.ntaps == 1 && (a.Cin >= gemm_minc || a.Cout >= gemm_minc) && !VT_KNOB("VT_SPAN_GEMM", 0) &&
+        (VT_KNOB("VT_IGEMM_W8", 3) & 2) && (long)((a.M + 255) / 256) * ((a.Cout + 127) / 128) >= 256 && enabled < 2)
+        return -1;
     if (dtype == VT_BF16) {
         // 256-row tiles; maps too small to give every CU a tile (7x7 at batch 256) run the
         // 128-row variant for <= 64 output channels and fall back to the general kernel's
