@@ -181,7 +181,11 @@ def test_cspdarknet53_program_structure():
 def test_inference_program_is_fully_fused():
     p = _dry_program("cspdarknet53", N.VT_BF16, False, False)
     h = p.kind_histogram
-    assert h["conv_igemm"] == 67 and "bn_act_apply" not in h and p.n_bwd == 0
+    # one launch per unit and nothing else: a conv with the affine + ReLU epilogue, or -- for the 1x1 units the pointwise
+    # kernels cover (17 of them in 15 launches, as in training; large inputs only outside this test's VT_PW_MIN_MB=0) --
+    # the pointwise apply pass with the running-statistics coefficients
+    assert h["conv_igemm"] == 67 - 17 and h["pw_apply"] == 15 and "pw_stats" not in h
+    assert "bn_act_apply" not in h and p.n_bwd == 0
     p = _dry_program("vovnet39", N.VT_F32, False, False)
     assert p.kind_histogram["conv_igemm"] == 39 and p.kind_histogram["maxpool_fwd"] == 4
     # OSA concat elided, f32 needs no mirror: the one copy is the stem filter's 3 -> 4 channel pad
