@@ -624,8 +624,8 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                 // the residual rows of this half, all in flight before the first one is used: loaded unconditionally
                 // (rows / channels outside the tensor read its first 16 bytes) so that nothing orders them behind the
                 // stores below -- one dependent load per row fragment cost 90 us of a 160-channel YOLOv5x layer's 400
-                // (MODE 2 only: the inference epilogue; the data gradient's accumulate keeps the in-place load)
-                constexpr bool kPreRes = MODE == 2;
+                // (MODE 0 too: the accumulating data gradients of VoVNet-39's OSA chains -- its step 25.37 -> 25.03 ms)
+                constexpr bool kPreRes = MODE != 1;
                 uint4 rres[kPreRes ? FM : 1];
                 if (kPreRes && has_res) {
 #pragma unroll
