@@ -10,8 +10,8 @@
 //   * a workgroup owns a 4 x 64 block of output pixels (one row per wave) and DMAs the 12 x 132 input
 //     pixels under it into LDS ONCE (25 KB; even and odd columns apart, so that the 16 lanes of a
 //     fragment -- 16 consecutive output pixels, input stride 2 -- read 16 consecutive 16-byte slots);
-//   * workgroups are persistent (two per CU) and keep the whole filter in LDS (80 rows x 592 B: 36 taps +
-//     one pad slot, conflict-free for the 16-row fragment reads);
+//   * workgroups are persistent (two per CU) and keep the whole filter in LDS (9 K-steps x 80 rows x 64 B, chunk
+//     positions swizzled by the row: conflict-free 16-row fragment reads);
 //   * K = 9 steps of 4 taps x 8 channels in the tensor's own tap order, 20 MFMAs per wave and step;
 //     the FILTER is the MFMA's row operand, so a lane ends up with 4 consecutive channels of one pixel
 //     per accumulator, and the filter rows are permuted at staging time such that its five accumulators
@@ -48,9 +48,10 @@ constexpr int kHalf = kPC / 2;
 constexpr int kPatchSlots = kPR * kPC;
 constexpr int kPatchInstr = (kPatchSlots + 63) / 64;   // 25 LDS-DMA instructions of 64 x 16 B
 constexpr int kN = 80, kTaps = 36, kSteps = kTaps / 4;
-constexpr int kWRow = kTaps + 1;                       // 16-byte slots per filter row: 592 B
-constexpr int kWSlots = kN * kWRow;
-constexpr int kWInstr = (kWSlots + 63) / 64;           // 47
+// filter image in LDS: [K-step s][row R = 16 j + u][4 chunks of 16 B], the chunk position XOR-swizzled by the row as in
+// vt_igemm.hip (conflict-free 16-row fragment reads; rows of 592 B with a pad slot measured 50 % bank conflicts)
+constexpr int kWSlots = kSteps * kN * 4;
+constexpr int kWInstr = (kWSlots + 63) / 64;           // 45
 constexpr int kWBytes = kWInstr * 1024, kPatchBytes = kPatchInstr * 1024;
 constexpr int kSmem = kWBytes + kPatchBytes;           // 73,728 B: two workgroups per CU
 
@@ -76,10 +77,11 @@ __global__ void __launch_bounds__(256, 2) stem6_kernel(const IgemmArgs p, const 
     // ---- the filter, once per workgroup: LDS row R = 16 j + u holds channel stem6_channel(j, u) ----------
     for (int k = wave; k < kWInstr; k += 4) {
         const int slot = k * 64 + lane;
-        const int R = slot / kWRow, t = slot - R * kWRow;
-        const bool ok = R < kN && t < kTaps;
+        const int row = slot >> 2, s_ = row / kN, R = row - s_ * kN;
+        const int c = (slot & 3) ^ ((0x1320 >> (((R >> 2) & 3) * 4)) & 3);
+        const bool ok = slot < kWSlots;
         const int ch = stem6_channel(R >> 4, R & 15);
-        glds16(ok ? (unsigned long)(wg + ((long)ch * p.ldw + t * 8)) : zero_src, w_base + (unsigned)k * 1024u);
+        glds16(ok ? (unsigned long)(wg + ((long)ch * p.ldw + (4 * s_ + c) * 8)) : zero_src, w_base + (unsigned)k * 1024u);
     }
 
     // XCD-blocked block order: workgroups b, b + 8, ... share an XCD (and its L2) and walk one contiguous eighth of
@@ -114,7 +116,7 @@ __global__ void __launch_bounds__(256, 2) stem6_kernel(const IgemmArgs p, const 
         toff[s] = (kh * kPC + (kw & 1) * kHalf + (kw >> 1)) * 16;
     }
     const char* pix = smem + kWBytes + ((2 * wave) * kPC + c16) * 16;
-    const char* wrow = smem + c16 * (kWRow * 16) + g * 16;  // + j * 16 rows, + s * 64 B
+    const char* wrow = smem + (c16 * 4 + (g ^ ((0x1320 >> (((c16 >> 2) & 3) * 4)) & 3))) * 16;  // + (80 s + 16 j) rows of 64 B
     // epilogue coefficients of the 20 channels this lane stores (rows 4 g + r of the five accumulators)
     const bool affine = (p.flags & VT_CONV_AFFINE) != 0, relu = (p.flags & VT_CONV_RELU) != 0;
     float sc[20], sf[20];
@@ -141,7 +143,7 @@ __global__ void __launch_bounds__(256, 2) stem6_kernel(const IgemmArgs p, const 
         for (int s = 0; s < kSteps; ++s) {
             uint4 wf[5], xf[4];
 #pragma unroll
-            for (int j = 0; j < 5; ++j) wf[j] = *(const uint4*)(wrow + j * (16 * kWRow * 16) + s * 64);
+            for (int j = 0; j < 5; ++j) wf[j] = *(const uint4*)(wrow + (s * kN + j * 16) * 64);
 #pragma unroll
             for (int i = 0; i < 4; ++i) xf[i] = *(const uint4*)(pix + toff[s] + i * 256);
 #pragma unroll
