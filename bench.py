@@ -198,13 +198,15 @@ def insitu_layer_times(ts, Cin, Cout, ntaps, HW, reps=4, which="fwd"):
 
 
 def time_train_step(model, batch, image_size, steps, warmup, dev):
-    """ms per fused train step of `model` at per-GPU batch `batch` on this GPU alone (no process group)"""
+    """ms per fused train step of `model` at per-GPU batch `batch` on this GPU alone (data_parallel=False: the
+    single-GPU program even when this process is a rank of a larger job)"""
     from vision_toolbox import backbones
     from vision_toolbox.trainer import TrainStep
 
     torch.manual_seed(0)
     ts = TrainStep(getattr(backbones, model)(), 1000, batch, image_size, torch.bfloat16, lr=0.05, momentum=0.9,
-                   weight_decay=2e-5, label_smoothing=0.1, device=dev, use_graphs=False, process_group=None)
+                   weight_decay=2e-5, label_smoothing=0.1, device=dev, use_graphs=False, process_group=None,
+                   data_parallel=False)
     g = torch.Generator(device=dev)
     g.manual_seed(1234)
     ts.images.copy_(torch.rand(ts.images.shape, device=dev, generator=g))
@@ -449,8 +451,22 @@ def main():
         lo, hi = chk.clone(), chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        # the N > 1 line is self-contained: rank 0 alone builds (and, on a GPU, times) the single-GPU program at the same
+        # per-GPU batch while the other ranks wait at a barrier; here only the control flow and the plan are exercised
+        n1_segments = n1_launches = None
+        if rank == 0:
+            torch.manual_seed(0)
+            solo = TrainStep(getattr(backbones, args.model)(), 1000, args.batch, args.image_size, torch.bfloat16,
+                             device="cpu", plan_only=True, data_parallel=False)
+            assert solo.world == 1 and solo.bucketer is None
+            n1_segments, n1_launches = len(solo.bwd_cuts), solo.prog.n_fwd + solo.prog.n_bwd
+            assert n1_launches == ts.prog.n_fwd + ts.prog.n_bwd, "a rank must run the single-GPU launch lists"
+        dist.barrier()
         if rank == 0:
             print(json.dumps({"plan_only": True, "n_gpus": world, "backend": backend, "buckets": len(ts.bucketer.buckets),
+                              "n1_same_per_gpu_batch_ms": None, "n1_same_per_gpu_batch_images_per_sec": None,
+                              "weak_scaling_efficiency": None, "exchange_exposed_ms": None,
+                              "n1_plan": {"bwd_segments": n1_segments, "launches": n1_launches},
                               "bwd_segments": len(ts.bwd_cuts), "allreduce_ok": ok, "gradient_exchange": ts.exchange,
                               "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                               "head_bucket_bytes": 4 * (ts.bucketer.buckets[-1][1] - ts.bucketer.buckets[-1][0]),
@@ -503,6 +519,31 @@ def main():
         elapsed = float(t.item())
     loss = ts.loss()
     assert N.launch_count() > launches0 and loss == loss, "HIP path did not run / loss is NaN"
+
+    # ---- N > 1: the line carries its own denominators (no RCCL N > 1 run exists on a one-GPU box: DESIGN 6) ---------
+    exposed_ms = n1_ms = None
+    if world > 1 and not args.steps_only:
+        # (a) what the gradient exchange leaves exposed: the same data-parallel schedule (cut lists, stream ordering)
+        #     with the collectives not issued, every rank, max over ranks
+        ts.skip_exchange = True
+        for _ in range(3):
+            ts.step()
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            ts.step()
+        torch.cuda.synchronize()
+        el_nx = time.perf_counter() - t1
+        ts.skip_exchange = False
+        t = torch.tensor([el_nx], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exposed_ms = (elapsed - float(t.item())) / args.steps * 1e3
+        # (b) the weak-scaling denominator: rank 0 alone times the single-GPU program at the same per-GPU batch (same
+        #     stream priority as the run above) while the other ranks wait at the barrier
+        if rank == 0:
+            n1_ms, _ = time_train_step(args.model, args.batch, args.image_size, args.steps, args.warmup, dev)
+        barrier()
 
     if args.steps_only:
         if rank == 0:
@@ -594,6 +635,14 @@ def main():
             "train_step_tflops": round(28.0e9 * (args.batch / 1.0) * world / (ms * 1e-3) / 1e12, 1)
             if args.model == "cspdarknet53" and args.image_size == 224 else None,
         }
+        if world > 1:
+            n1_ips = args.batch / n1_ms * 1e3
+            out["n1_same_per_gpu_batch_ms"] = round(n1_ms, 3)
+            out["n1_same_per_gpu_batch_images_per_sec"] = round(n1_ips, 1)
+            out["weak_scaling_efficiency"] = round(value / (world * n1_ips), 4)
+            out["exchange_exposed_ms"] = round(exposed_ms, 3)
+            out["exchange_exposed_note"] = ("ms_per_step minus the same data-parallel schedule timed with the collectives "
+                                            "not issued (max over ranks); the N = 1 figures are rank 0 alone, same per-GPU batch")
         if world == 1 and not args.no_secondary:
             del ts
             torch.cuda.empty_cache()

@@ -150,6 +150,14 @@ def test_bench_launches_its_own_ranks_from_one_command():
     assert len(lines) == 1
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["allreduce_ok"] and rec["params_equal"] and rec["buckets"] >= 2
+    # the N > 1 line is self-contained (round 4): its own same-batch N = 1 denominator, the efficiency against it and
+    # the exposed part of the gradient exchange -- timed on a GPU, null in a plan-only run, whose rank 0 still builds
+    # the single-GPU plan beside the data-parallel one and finds the same launches in it
+    for key in ("n1_same_per_gpu_batch_ms", "n1_same_per_gpu_batch_images_per_sec", "weak_scaling_efficiency",
+                "exchange_exposed_ms"):
+        assert key in rec
+    assert rec["n1_plan"]["bwd_segments"] == 1 and rec["n1_plan"]["launches"] > 100
+    assert rec["bwd_segments"] >= 2
 
 
 def test_plan_buckets_head_bucket_and_alignment():

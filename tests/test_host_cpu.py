@@ -274,3 +274,30 @@ def test_statistics_buffer_fixed_point_roundtrip():
     assert got[0][3].item() == 3.25 - 0.03125 and got[0][5].item() == 4096.0 - 8192.5  # dyadic values: exact
     hi = buf[3, 0, :, 0]
     assert hi.tolist() == [0, 0, 0, 0, 0, 1, 3013]  # trunc(v / 4096): the hi limb stays zero below 4096
+
+
+def test_padded_stem_filter_is_read_from_the_bf16_mirror():
+    """under exchange='sharded' only the bf16 mirror of a conv filter is refreshed on the ranks that do
+    not own its slice, so no forward op may read a conv filter from the f32 master buffer in bf16 mode -- the RGB stem's
+    padding copy (3 -> 8 channels) did.  It now takes the mirror (same rounding of the same master value)."""
+    import torch
+
+    from vision_toolbox import _native as N
+    from vision_toolbox import backbones
+    from vision_toolbox import engine as E
+    from vision_toolbox.trainer import TrainStep
+
+    for factory in (backbones.cspdarknet53, backbones.darknet_yolov5n, backbones.vovnet19_slim_ese):
+        ts = TrainStep(factory(), 16, 2, 64, torch.bfloat16, device="cpu", plan_only=True)
+        st = ts.store
+        conv_w = [(o, o + p.numel()) for o, p in zip(st.offsets, st.params) if p.dim() == 4]
+        copies = 0
+        for i in range(ts.prog.n_fwd):
+            op = ts.prog.fwd_ops[i]
+            for k in range(N.VT_OP_MAX_PTR):
+                if op.ptr[k].base == E.PARAMS:  # an f32 read of the master buffer: BatchNorm / bias parameters only
+                    off = op.ptr[k].offset // 4
+                    assert not any(a <= off < b for a, b in conv_w), (factory.__name__, i, op.kind & 0xFFFF)
+            if (op.kind & 0xFFFF) == N.OP_COPY2D and op.ptr[0].base == E.MIRROR:
+                copies += 1
+        assert copies == 1, factory.__name__

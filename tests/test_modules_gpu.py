@@ -215,9 +215,13 @@ def test_model_eval_feature_maps_f32_vs_reference(name, golden_dir):
     assert rel_err(logits.cpu(), _t(gm[f"{name}.eval.logits"])) < 1e-3
 
 
+@pytest.mark.parametrize("pw_min_mb", ["0", "80"], ids=["pointwise_units", "production_threshold"])
 @pytest.mark.parametrize("name", ["cspdarknet53", "vovnet39", "darknet19"])
-def test_model_bf16_tracks_reference(name, golden_dir):
-    """bf16 kernels: every activation is stored in bf16, so only a loose bound is meaningful."""
+def test_model_bf16_tracks_reference(name, pw_min_mb, golden_dir, monkeypatch):
+    """bf16 kernels: every activation is stored in bf16, so only a loose bound is meaningful.  Both settings of the
+    pointwise threshold (read when the launch lists are built): every covered 1x1 unit on vt_pointwise.hip, and the
+    production default, under which these toy tensors take the unfused conv + BatchNorm kernels."""
+    monkeypatch.setenv("VT_PW_MIN_MB", pw_min_mb)
     gm = np.load(golden_dir / "models.npz")
     model = _classifier(name, torch.bfloat16)
     x, y = filler.images(4, 64).cuda(), filler.labels(4, 16).cuda()

@@ -147,7 +147,11 @@ def test_cspdarknet53_train_bn_first_step_gradients_track_oracle():
     assert errs[-1] < 3.0 * base[-1] + 1e-3, (errs[-5:], base[-5:])
 
 
-def test_bf16_train_step_decreases_loss_and_matches_f32_roughly():
+@pytest.mark.parametrize("pw_min_mb", ["0", "80"], ids=["pointwise_units", "production_threshold"])
+def test_bf16_train_step_decreases_loss_and_matches_f32_roughly(pw_min_mb, monkeypatch):
+    # VT_PW_MIN_MB is read when a launch list is built: 0 (tests/conftest.py) sends every covered 1x1 unit through the
+    # pointwise kernels, 80 is the production default (at this size: the unfused conv + BatchNorm kernels everywhere)
+    monkeypatch.setenv("VT_PW_MIN_MB", pw_min_mb)
     ncls, B, S = 16, 8, 64
     x, y = filler.images(B, S), filler.labels(B, ncls)
     losses = {}

@@ -779,11 +779,13 @@ static int span6_run(IgemmArgs& a0, int dtype, void* stream, bool dry) {
     if (mode == 1 && (p.flags & (VT_CONV_AFFINE | VT_CONV_RELU | VT_CONV_RESIDUAL))) return -1;
     if (mode == 0 && (p.flags & VT_CONV_RELU)) return -1;
     auto kern = mode == 1 ? span6_kernel<1> : (mode == 2 ? span6_kernel<2> : span6_kernel<0>);
-    if (dry) return VT_OK;
     {
+        // (in the dry run too: the only fallible step of a launch, so a caller that splits the columns over two kernels
+        //  knows this half cannot fail once the other one has been issued)
         const int rc = vt_raise_dynamic_lds((const void*)kern, 160 * 1024, "vt_conv_igemm(span6)");
         if (rc != VT_OK) return rc;
     }
+    if (dry) return VT_OK;
     vt_note_kernel("span6_kernel<bf16,2x4+4 waves,FM%d>", kFMX);
     hipLaunchKernelGGL(kern, dim3(8 * 32), dim3(768), smem, (hipStream_t)stream, a);
     VT_CHECK_LAUNCH("vt_conv_igemm(span6)");

@@ -444,7 +444,9 @@ static int run_ops_impl(const vt_op* ops, int32_t n, void* const* bases, int32_t
             if (two && on_side) side_dirty = true;
             i = j - 1;
         } else if (op.kind == VT_OP_PACK_DGRAD && op.i[0] == VT_BF16 && op.i[2] == VT_BF16 && op.i[1] % 8 == 0 &&
-                   op.i[4] % 8 == 0 && op.i[6] % 8 == 0) {
+                   op.i[4] % 8 == 0 && op.i[6] % 8 == 0 && op.i[3] >= 1 && op.i[3] <= VT_MAX_TAPS) {
+            // (the tap-count check is the gather loop's own: an op that fails it must fall through to run_one, which
+            //  reports it, instead of leaving `items` empty and this op to be visited again)
             // consecutive bf16 filter re-packs of one stream leave as ONE batched launch per VT_PACK_BATCH of them
             std::vector<vt_pack_item> items;
             int j = i;

@@ -557,7 +557,11 @@ class Builder:
         if padded:
             wpack = self.alloc(Cout * ntaps * x.C * _ESIZE[dt], "wpad")
             self.emit(N.OP_MEMSET, [self.bp(wpack)], [0], [wpack.nbytes])
-            self.emit(N.OP_COPY2D, [self.pref(w), self.bp(wpack)], [N.VT_F32, dt, Cin_w, 0],
+            # (bf16: from the mirror every other filter is read from -- the same rounding of the same master value, and
+            #  under the sharded gradient exchange the mirror is what the all-gather refreshes on every rank, whereas the
+            #  f32 master of a slice another rank owns goes stale)
+            wsrc, wsrc_dt = (self.pref(w, mirror=True), dt) if dt == N.VT_BF16 else (self.pref(w), N.VT_F32)
+            self.emit(N.OP_COPY2D, [wsrc, self.bp(wpack)], [wsrc_dt, dt, Cin_w, 0],
                       [Cin_w, x.C, Cout * ntaps])
             wptr = self.bp(wpack)
         elif dt == N.VT_F32:

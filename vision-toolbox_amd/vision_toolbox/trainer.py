@@ -135,6 +135,7 @@ class TrainStep:
         deterministic: Optional[bool] = None,
         exchange: str = "allreduce",
         head_bucket_kb: float = 256.0,
+        data_parallel: Optional[bool] = None,
     ):
         N.lib()
         self.device = torch.device(device if device is not None else "cuda")
@@ -145,12 +146,18 @@ class TrainStep:
         self.dtype = N.VT_BF16 if dtype == torch.bfloat16 else N.VT_F32
         self.pg = process_group
         self.world = 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
+        # data_parallel=False: this rank's program alone, whatever process group exists (bench.py times the N = 1
+        # denominator of a weak-scaling run on rank 0 of the same job)
+        if data_parallel is not False and torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(process_group)
         # a one-rank process group still takes the data-parallel schedule (cut lists, bucket collectives on the
         # filter-gradient stream, broadcasts): how the RCCL path is exercised on a one-GPU box (tests)
-        self.dp = self.world > 1 or (os.environ.get("VT_DP_WORLD1", "0") != "0" and torch.distributed.is_available()
-                                     and torch.distributed.is_initialized())
+        self.dp = data_parallel is not False and (
+            self.world > 1 or (os.environ.get("VT_DP_WORLD1", "0") != "0" and torch.distributed.is_available()
+                               and torch.distributed.is_initialized()))
+        # (measurement only) run the data-parallel schedule -- cut lists, stream ordering -- without issuing the
+        # collectives: step time with them minus step time without = what the exchange leaves exposed
+        self.skip_exchange = False
         head = nn.Linear(backbone.get_last_out_channels(), num_classes)
         self.model = nn.Sequential(backbone, nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten(), head)
         self.model.train()
@@ -272,6 +279,8 @@ class TrainStep:
             INPUT=self.images.data_ptr(), LABELS=self.labels.data_ptr(), MOMENTUM=self.mflat.data_ptr(),
             HYPER=self.lr_dev.data_ptr())
         self.use_graphs = use_graphs
+        self._master_stale = False
+        self.model.register_state_dict_pre_hook(self._refuse_stale_export)
         self._side = None  # side stream for the filter gradients (eager mode; graphs fork internally)
         self._graphs = None
         self.steps_done = 0
@@ -304,10 +313,18 @@ class TrainStep:
 
     def gather_master(self) -> None:
         """sharded exchange: refresh the f32 master parameters and the momentum of the slices other ranks own (before a
-        checkpoint / state_dict); a no-op for the all-reduce exchange"""
+        checkpoint / state_dict; a collective: every rank calls it); a no-op for the all-reduce exchange"""
         if self.exchange == "sharded":
             self.bucketer.gather(self.store.pflat)
             self.bucketer.gather(self.mflat)
+        self._master_stale = False
+
+    def _refuse_stale_export(self, *_):
+        # state_dict() of the wrapped model reads views of the flat f32 buffer: after a sharded step the slices other
+        # ranks own hold LAST step's values there, and a checkpoint written from them would silently mix old and new
+        if self._master_stale:
+            raise RuntimeError("exchange='sharded': the f32 master parameters of the slices other ranks own are stale "
+                               "on this rank; call TrainStep.gather_master() on every rank before state_dict()")
 
     @staticmethod
     def _sync_points(ops, n, kind):
@@ -354,7 +371,7 @@ class TrainStep:
                 N.run_ops(sub, hi - lo, self.bases, s, side=side, leave_side_open=keep_side_open and hi != n)
             if hi in marks:  # stream-ordered: NCCL makes the launch stream wait, no host sync
                 self._sync_stats(*marks[hi][1], s)
-            if hi in cut_buckets and cut_buckets[hi]:
+            if hi in cut_buckets and cut_buckets[hi] and not self.skip_exchange:
                 if side and self._side is not None:
                     N.stream_wait(side, s)
                     with torch.cuda.stream(self._side):
@@ -440,7 +457,7 @@ class TrainStep:
                 self._graphs["head"].launch(s)
                 for g, bks in zip(self._graphs["bwd"], self.cut_buckets):
                     g.launch(s)
-                    for bi in bks:
+                    for bi in ([] if self.skip_exchange else bks):
                         self.bucketer.reduce_bucket(bi)
             else:
                 if self._side is None:
@@ -450,14 +467,15 @@ class TrainStep:
                 self._run_list(p.fwd_ops, p.n_fwd, self._fwd_sync, [], {}, s, side, keep_side_open=False)
                 self._run_list(p.bwd_ops, p.n_bwd, self._bwd_sync, self.bwd_cuts,
                                dict(zip(self.bwd_cuts, self.cut_buckets)), s, side)
-            if self.bucketer is not None:
+            if self.bucketer is not None and not self.skip_exchange:
                 self.bucketer.finish()
             if self.use_graphs and not self.sync_bn:
                 self._graphs["opt"].launch(s)
             else:
                 N.run_ops(self.opt_ops, self.n_opt, self.bases, s)
-            if self.exchange == "sharded":
+            if self.exchange == "sharded" and not self.skip_exchange:
                 self._gather_weights()
+                self._master_stale = True
         self.steps_done += 1
 
     def loss(self) -> float:
