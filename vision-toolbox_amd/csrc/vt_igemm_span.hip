@@ -1,31 +1,35 @@
-// vt_igemm_span.hip -- implicit-GEMM convolution for "stride-1 grid" convs with the input
-// staged ONCE per channel chunk and re-used by every filter tap.
+// vt_igemm_span.hip -- implicit-GEMM convolution with the input staged ONCE per channel chunk and re-used by every
+// filter tap ("input span").
 //
-// Applies when the gather steps the input by 1 and the iterated grid equals the input grid
-// (every 3x3/1x1 stride-1 conv of ConvNormAct, reference components.py:26-35; every
-// stride-1 data gradient; the parity classes of the stride-2 data gradients) and Cin is a
-// multiple of the 64-byte K chunk.  Why a second kernel: vt_igemm.hip stages the gathered
-// A rows separately for each tap, so a 3x3 conv pushes every input pixel through the
-// global->LDS path 9 times; measured, that path (~9 TB/s chip wide for 64-byte segments),
-// not the MFMA pipe or HBM, bounds it -- at ~570 TFLOP/s on the 128..512-channel layers and
-// at 2-4x the HBM time on the 32/64-channel layers at 112x112.
-// Here, with the flat pixel index m = (b*H + i)*W + j, tap t reads input pixel m + d_t,
-// d_t = eh_t*W + ew_t, so the BM output pixels of a tile need ONE contiguous span of
-// BM + (dmax - dmin) input pixels for all taps.  Per channel chunk (32 bf16 / 16 f32):
+// Stride-1 grids (every 3x3/1x1 stride-1 conv of ConvNormAct, reference components.py:26-35; every stride-1 data
+// gradient; the parity classes of the stride-2 data gradients), Cin a multiple of the 64-byte K chunk.  Why a second
+// kernel: vt_igemm.hip stages the gathered A rows separately for each tap, so a 3x3 conv pushes every input pixel through
+// the global->LDS path 9 times; measured, that path (~9 TB/s chip wide for 64-byte segments), not the MFMA pipe or HBM,
+// bounds it -- at ~570 TFLOP/s on the 128..512-channel layers and at 2-4x the HBM time on the 32/64-channel layers at
+// 112x112.  Here, with the flat pixel index m = (b*H + i)*W + j, tap t reads input pixel m + d_t, d_t = eh_t*W + ew_t, so
+// the BM output pixels of a tile need ONE contiguous span of BM + (dmax - dmin) input pixels for all taps.  Per channel
+// chunk (32 bf16 / 16 f32):
 //   * the span is DMA'd once into a 2-slot LDS ring  (A: span x 64 B),
 //   * per tap only the BN x 64 B filter slice is DMA'd (3-slot ring, 2 in flight),
-//   * tap t's MFMA A-fragments are read from the span at row offset d_t - dmin; a fragment
-//     row whose tap leaves the image (padding) reads a 16-byte zero block instead: the
-//     per-lane LDS address is selected from a per-row tap mask built once per tile, so the
-//     loop carries 3 VALU ops per fragment and nothing between ds_read and MFMA.
+//   * tap t's MFMA A-fragments are read from the span at row offset d_t - dmin; a fragment row whose tap leaves the
+//     image (padding) reads a 16-byte zero block instead: the per-lane LDS address is selected from a per-row tap mask
+//     built once per tile, so the loop carries 3 VALU ops per fragment and nothing between ds_read and MFMA.
 //
-// 4 waves as WM x WN; BN=128: 2x2, wave tile 128x64; BN=64/32: 4x1, wave tile 64xBN.
-// Same LDS-DMA / counted-vmcnt discipline, swizzle, statistics and XCD-aware tile map as
-// vt_igemm.hip.  All A fragments of a wave are 16 rows apart, so their swizzle term is
-// identical and one address per tap serves all of them.
-// Epilogue: each wave stages its own 16-row slabs through a private LDS window and writes
-// 16-byte row segments; no block barrier after the main loop's last one, statistics go
-// straight to the global replicas from each wave.
+// Stride 2 (round 4: the 3x3 stride-2 padding-1 conv that opens every Darknet / CSPDarknet stage, reference
+// backbones/darknet.py:35,43, on even maps) as the same kernel over the SPACE-TO-DEPTH view of the input (template
+// flag S2).  The four parity planes P_ac[b][i][j] = x[b][2i+a][2j+c] have the output's grid, and on them the conv is a
+// stride-1 conv whose taps are offsets in {-1, 0}^2: plane (1,1) carries 4 taps, (1,0) and (0,1) two each, (0,0) one --
+// nine steps per channel chunk, the same MFMA work as the gather kernel, but every input pixel enters LDS ONCE per
+// filter-column tile instead of 2.25 times (and 9 times with padding rounding on the small-channel layers).  A plane's
+// span is gathered straight from the NHWC tensor (row r of the span = plane position m0 + dmin_p + r = one 64-byte
+// segment at pixel (2i+a, 2j+c)); each plane has its own LDS slot, reloaded for the next chunk as soon as its last tap
+// has been read (five or more steps before its first use), in the order (1,1), (1,0), (0,1), (0,0).
+//
+// 4 waves as WM x WN; BN=128: 2x2, wave tile 128x64; BN=64/32: 4x1, wave tile 64xBN.  Same LDS-DMA / counted-vmcnt
+// discipline, swizzle, statistics and XCD-aware tile map as vt_igemm.hip.  All A fragments of a wave are 16 rows apart,
+// so their swizzle term is identical and one address per tap serves all of them.
+// Epilogue: each wave stages its own 16-row slabs through a private LDS window and writes 16-byte row segments; the
+// statistics of the row-waves are folded in LDS and leave as one fixed-point atomic per column and moment.
 #include <stdlib.h>
 
 #include "vt_common.h"
@@ -36,27 +40,6 @@ namespace {
 constexpr int kTapBytes = 32 * 16;  // ntaps <= 32 on this path
 
 __device__ __attribute__((aligned(16))) unsigned int vt_span_zero16[4];
-#ifdef VT_SPAN_STAMPS  // diagnostic build only: per-workgroup phase clocks (never in the shipped library)
-__device__ unsigned long long vt_span_stamps[8192 * 4];
-__device__ unsigned long long vt_span_loop[8192 * 4];
-#define VT_STAMP(k)                                                                  \
-    do {                                                                             \
-        if (threadIdx.x == 0 && blockIdx.x < 8192) vt_span_stamps[blockIdx.x * 4 + (k)] = wall_clock64(); \
-    } while (0)
-#define VT_LOOP_CLK(var) unsigned long long var = clock64()
-#define VT_LOOP_ACC(k, a, b) loop_acc[k] += (b) - (a)
-#else
-#define VT_STAMP(k) do { } while (0)
-#define VT_LOOP_CLK(var) do { } while (0)
-#define VT_LOOP_ACC(k, a, b) do { } while (0)
-#endif
-
-// diagnostic builds only (tools/build_diag.sh): -DVT_SPAN_ABLATE=<bits>  1: no MFMA, 2: no LDS-DMA inside the
-// main loop, 4: no fragment reads.  Results are wrong by construction; only the time is read.
-#ifndef VT_SPAN_ABLATE
-#define VT_SPAN_ABLATE 0
-#endif
-
 // chunk ^= 2 * ((row >> 2) & 1): the one 4-entry swizzle family (found by enumeration) under which a ds_read_b128 of
 // 16 consecutive 64-byte rows is conflict free for EVERY starting row -- a tap shifts the fragment rows by an
 // arbitrary offset; the table 0x1320 used before is conflict free only for offsets that are multiples of 4.
@@ -140,6 +123,7 @@ __device__ __forceinline__ void mma<float>(const uint4& a, const uint4& b, f32x4
 
 // LDS map (bytes): [taps 512][row masks BM*4][row output pixel BM*4][filter ring 3 x BROWS*64]
 //                  [zero 16 .. 64][span slot 0][span slot 1 (only when Cin spans > 1 chunk)]
+//                  (S2: four plane slots of their own lengths instead of the two span slots)
 template <int BM, int BN, int PD>
 struct SpanLds {
     static constexpr int BROWS = BN < 64 ? 64 : BN;
@@ -152,9 +136,23 @@ struct SpanLds {
     __host__ __device__ static constexpr int bytes(int ita, int nslots, int nw = 4) { return kA + nslots * ita * nw * 16 * 64; }
 };
 
+// Stride-2 launches (space-to-depth view): plane class q = 0..3 is plane (a, c) = (1,1), (1,0), (0,1), (0,0); its span
+// starts dmin_q = {-Wo-1, -Wo, -1, 0} plane positions before the tile and is npieces[q] pieces of 16 rows long.
+struct SpanS2 {
+    int slot_off[4];   // byte offset of class q's slot inside the span area
+    int npieces[4];    // 16-row pieces of its span: ceil((BM - dmin_q) / 16)
+    int plane_off[4];  // (a*W + c) * ldx * sizeof(T): byte offset of the plane's pixel inside the 2x2 block
+    int delta[4];      // -dmin_q as a byte distance in x for a row that does not wrap: {2W+2, 2W, 2, 0} pixels
+    int wrap;          // extra byte distance when the step back by one plane column leaves the row (j = 0): W pixels
+    int maxoff;        // byte offset in x of the pixel under the last plane position (B-1, Ho-1, Wo-1)
+    int8_t t_q[12], t_rs[12];  // step t of a chunk: plane class and filter tap (3*r + s)
+    short t_drow[12];          // and the row offset of its fragments inside the class's span
+};
+constexpr int kS2MaxP = 6;  // span pieces per wave, at most (4 waves: spans of up to 384 rows)
+
 // ita: span DMA instructions per wave per chunk (span = 64*ita rows >= BM + dmax - dmin)
-template <typename T, int BM, int BN, int WM, int WN, int PD, bool PP = false, bool DB = false>
-__global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel(const IgemmArgs p, const int dmin, const int ita) {
+template <typename T, int BM, int BN, int WM, int WN, int PD, bool S2 = false>
+__global__ void __launch_bounds__(64 * WM * WN, 2) span_kernel(const IgemmArgs p, const int dmin, const int ita, const SpanS2 g) {
     constexpr int NW = WM * WN;  // waves: 4, or 8 for the 256 x 128 tile (wave tile 64 x 64, 16 waves per CU)
     constexpr int NT = 64 * NW;
     constexpr int EPC = 16 / sizeof(T);
@@ -167,9 +165,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
     constexpr int NSB = PD + 1;
     static_assert((NW == 4 || NW == 8) && ITB >= 1 && TM % 16 == 0 && TN % 16 == 0, "tile shape");
     static_assert(L::kZero >= FM * 1024, "zero block must sit above the fragment offsets");
+    static_assert(!S2 || (sizeof(T) == 2 && PD == 2), "the stride-2 view is a bf16 path");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int4* sTap = (int4*)smem;  // x: row offset in the span, y: filter tap index, z/w: eh, ew
+    int4* sTap = (int4*)smem;  // x: row offset in the span, y: filter tap index, z/w: eh, ew  (S2: z = slot offset in uint4)
     unsigned* sMask = (unsigned*)(smem + L::kMask);
     int* sPo = (int*)(smem + L::kPo);
     uint4* sB = (uint4*)(smem + L::kB);  // [NSB][BSLOT]
@@ -189,12 +188,15 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
     const int tm = xcd * p.chunk + ml;
     if (ml >= p.chunk || tm >= p.tiles_m) return;
 
-    VT_STAMP(0);
     const int W = p.Wi, H = p.Hi, HW = H * W;
     const long m0 = (long)tm * BM;
     if (tid < p.ntaps) {
-        const int eh = p.h0 + p.dh[tid], ew = p.w0 + p.dw[tid];
-        sTap[tid] = make_int4(eh * W + ew - dmin, tid, eh, ew);
+        if constexpr (S2) {
+            sTap[tid] = make_int4(g.t_drow[tid], g.t_rs[tid], g.slot_off[g.t_q[tid]] >> 4, 0);
+        } else {
+            const int eh = p.h0 + p.dh[tid], ew = p.w0 + p.dw[tid];
+            sTap[tid] = make_int4(eh * W + ew - dmin, tid, eh, ew);
+        }
     }
     if (tid < 4) ((unsigned*)sZ)[tid] = 0u;
     const T* __restrict__ xg = (const T*)p.x;
@@ -231,7 +233,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
 
     // Fast DMA addressing (interior tiles: every span row inside [0, M), every filter row < Cout, all
     // byte offsets < 4 GiB): scalar base + constant per-lane 32-bit offset, no VALU per instruction.
-    const bool a_fast = __all(pix0 >= 0 && pix0 + 16l * NW * (ita - 1) < p.M) && (p.fast_dma & 1) &&
+    const bool a_fast = !S2 && __all(pix0 >= 0 && pix0 + 16l * NW * (ita - 1) < p.M) && (p.fast_dma & 1) &&
                         (unsigned long)p.M * p.ldx * sizeof(T) < 0xffff0000ul;
     bool bv_all = true;
 #pragma unroll
@@ -244,6 +246,23 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
 #pragma unroll
     for (int i = 0; i < ITB; ++i)
         b_voff[i] = (unsigned)((tn * BN + 16 * (wave + NW * i) + (lane >> 2)) * p.ldw + cj * EPC) * (unsigned)sizeof(T);
+
+    // S2: byte offset in x of the pixel (b, 2i, 2j) under plane position v0 = m0 + r of this lane's row r of piece
+    // wave + NW*P, plus its chunk position; bit P of s2_wrap: that position is the first of its row (j = 0), so one column back is the last column
+    // of the row above.  A plane class's source is this minus the class's (wave-uniform) distance.
+    int s2_off[S2 ? kS2MaxP : 1];
+    unsigned s2_wrap = 0;
+    if constexpr (S2) {
+        const int Wo = p.Wo;
+#pragma unroll
+        for (int P = 0; P < kS2MaxP; ++P) {
+            const long v0 = m0 + 16 * (wave + NW * P) + (lane >> 2);  // (may pass the last position: its class position need not)
+            const int q = (int)(v0 / Wo);
+            const int j0 = (int)(v0 - (long)q * Wo);
+            s2_off[P] = (int)((4 * v0 - 2 * j0) * (long)p.ldx * (long)sizeof(T)) + cj * 16;
+            s2_wrap |= (j0 == 0 ? 1u : 0u) << P;
+        }
+    }
 
     // span of channel chunk `ic` into slot `sl`
 #define VT_ISSUE_A(sl, ic)                                                                   \
@@ -261,6 +280,26 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
             glds16(src, a_base + (unsigned)(((sl)*aslot + (wave + NW * i) * 64) * 16));      \
         }                                                                                    \
     } while (0)
+    // S2: span of plane class q, channel chunk ic, into the class's own slot; returns the instructions issued.  A row
+    // before the first image (reachable through padding only: its fragments are masked) or past the last position
+    // (feeding discarded outputs only) is clamped into the tensor.
+    auto issue_plane = [&](int q, int ic) -> int {
+        const char* sb = (const char*)xg + ((long)g.plane_off[q] + (long)ic * (CH * (long)sizeof(T)));
+        const int dq = g.delta[q], np = g.npieces[q];
+        const bool back1 = (q == 0 || q == 2);  // classes whose span starts one plane column back
+        const unsigned lds0 = a_base + (unsigned)g.slot_off[q];
+        int n = 0;
+#pragma unroll
+        for (int P = 0; P < kS2MaxP; ++P) {
+            if (wave + NW * P < np) {
+                int off = s2_off[P] - dq - ((back1 && ((s2_wrap >> P) & 1u)) ? g.wrap : 0);
+                off = min(max(off, 0), g.maxoff + 48);  // (+48: the last position keeps its chunk position)
+                glds16s((unsigned)off, sb, lds0 + (unsigned)((wave + NW * P) * 1024));
+                ++n;
+            }
+        }
+        return n;
+    };
     // filter slice of step (chunk ic, tap it): rows n, K offset it*Cin + ic*CH
 #define VT_ISSUE_B(bslot, ic, it)                                                          \
     do {                                                                                   \
@@ -276,14 +315,20 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
             glds16(ps, b_base + (unsigned)(((bslot)*BSLOT + (wave + NW * i) * 64) * 16));  \
         }                                                                                  \
     } while (0)
+    // (S2: step `it` of a chunk multiplies filter tap t_rs[it])
+#define VT_TAP_OF(it) (S2 ? (int)g.t_rs[it] : (it))
 
-    // prologue: span of chunk 0, filter slices of steps 0 and 1
-    VT_ISSUE_A(0, 0);
+    // prologue: span of chunk 0 (S2: all four planes of chunk 0), filter slices of steps 0 and 1
+    if constexpr (S2) {
+        for (int q = 0; q < 4; ++q) (void)issue_plane(q, 0);
+    } else {
+        VT_ISSUE_A(0, 0);
+    }
     int ic_n = 0, it_n = 0;  // (chunk, tap) of the next filter slice to issue
 #pragma unroll
-    for (int s = 0; s < PD + (DB ? 1 : 0); ++s) {
+    for (int s = 0; s < PD; ++s) {
         if (s < nsteps) {
-            VT_ISSUE_B(s, ic_n, it_n);
+            VT_ISSUE_B(s, ic_n, VT_TAP_OF(it_n));
             if (++it_n == p.ntaps) it_n = 0, ++ic_n;
         }
     }
@@ -293,22 +338,32 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
         unsigned bits = 0;
         int po = 0;
         if (m < p.M) {
-            const int b = (int)(m / HW);
-            const int rem = (int)(m - (long)b * HW);
-            const int oi = rem / W, oj = rem - oi * W;
-            for (int t = 0; t < p.ntaps; ++t) {
-                const int eh = p.h0 + p.dh[t], ew = p.w0 + p.dw[t];
-                if ((unsigned)(oi + eh) < (unsigned)H && (unsigned)(oj + ew) < (unsigned)W) bits |= 1u << t;
+            if constexpr (S2) {
+                const int HoWo = p.Ho * p.Wo;
+                const int b = (int)(m / HoWo);
+                const int rem = (int)(m - (long)b * HoWo);
+                const int oi = rem / p.Wo, oj = rem - oi * p.Wo;
+                for (int t = 0; t < p.ntaps; ++t) {  // bit = filter tap index
+                    const int ih = oi * 2 + p.h0 + p.dh[t], iw = oj * 2 + p.w0 + p.dw[t];
+                    if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) bits |= 1u << t;
+                }
+                po = p.dense_out ? (int)m : (b * p.oH + (oi * p.oHs + p.oh0)) * p.oW + (oj * p.oWs + p.ow0);
+            } else {
+                const int b = (int)(m / HW);
+                const int rem = (int)(m - (long)b * HW);
+                const int oi = rem / W, oj = rem - oi * W;
+                for (int t = 0; t < p.ntaps; ++t) {
+                    const int eh = p.h0 + p.dh[t], ew = p.w0 + p.dw[t];
+                    if ((unsigned)(oi + eh) < (unsigned)H && (unsigned)(oj + ew) < (unsigned)W) bits |= 1u << t;
+                }
+                po = p.dense_out ? (int)m : (b * p.oH + (oi * p.oHs + p.oh0)) * p.oW + (oj * p.oWs + p.ow0);
             }
-            po = p.dense_out ? (int)m : (b * p.oH + (oi * p.oHs + p.oh0)) * p.oW + (oj * p.oWs + p.ow0);
         }
         sMask[r] = bits;
         sPo[r] = po;
     }
-    if constexpr (PP) vm_wait_dyn((min(PD, nsteps) - 1) * ITB);  // span 0 and slice 0 landed before the first LOAD tick
     __syncthreads();  // tap table, row masks, zero block
 
-    VT_STAMP(1);
     // Static priority split (fast_dma bits 1..2 = mode): two workgroups share a CU, one wave of each per SIMD.  At
     // equal priority the matrix pipe is shared evenly, which locks the two waves IN phase (both in their MFMA
     // block together, both in their scalar / DMA / barrier block together) and the phases add up instead of
@@ -329,152 +384,65 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
     int ic = 0, it = 0;  // (chunk, tap) of the step being computed
     int bcur = 0, bnxt = PD % NSB;
     int a_age = 0;  // steps since the last span was issued (0: none yet)
-#ifdef VT_SPAN_STAMPS
-    unsigned long long loop_acc[4] = {0, 0, 0, 0};
-#endif
-    if constexpr (PP) {
-        // ---- ping-pong schedule (8 waves, one workgroup per CU) -------------------------------------
-        // The two row halves of the tile (waves 0-3 / 4-7; one wave of each per SIMD) run half a
-        // step apart: in every "tick" (= one workgroup barrier) one half issues its LDS-DMA and reads
-        // its 12 fragments while the other half issues its 32 MFMAs, so the MFMA pipe of a SIMD
-        // always has one wave feeding it and the other wave's staging hides behind it.
-        //   group 0: LOAD(s) at tick 2s,   MFMA(s) at tick 2s+1
-        //   group 1: idle at tick 0, LOAD(s) at tick 2s+1, MFMA(s) at tick 2s+2
-        // B(s+1) is first read at tick 2s+2 (group 0), so every wave retires its part of it before
-        // the barrier that ends tick 2s+1: group 0 after its MFMAs, group 1 after its loads.  Both
-        // groups execute 2*nsteps barriers.  Requires ntaps >= PD (a span is never needed within
-        // PD steps of its issue).
-        static_assert(NW == 8 && WN == 2, "ping-pong needs two 4-wave row halves");
-        const int grp = wm >> 1;
-        if (grp == 1) {
+    if constexpr (S2) {
+        // ---- stride 2: nine steps per chunk over the four plane slots -------------------------------------------------
+        // Step it of a chunk reads class t_q[it] (steps 0-3: (1,1); 4,5: (1,0); 6,7: (0,1); 8: (0,0)).  A class's slot is
+        // free once its last step has been left by every wave, i.e. behind the barrier of the step after it: the next
+        // chunk's (1,1) is issued in step 4, (1,0) in step 6, (0,1) in step 8 and (0,0) in step 0 of the next chunk --
+        // each at least five steps before its first reader, and older than that reader's filter slice (issued PD = 2
+        // steps ahead), whose counted wait therefore covers it.  Younger than slice s at the top of step s: the slice
+        // of step s+1 and whatever plane pieces step s-1 issued in front of it.
+        int prev_pieces = 0;
+        for (int s = 0; s < nsteps; ++s) {
+            const int nb = min(PD - 1, nsteps - 1 - s);
+            if (prev_pieces == 0 && nb == 1) vm_wait<ITB>();
+            else vm_wait_dyn(nb * ITB + prev_pieces);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-        }
-        int a_since = 1 << 20;  // LOAD ticks since this wave issued a span
-        for (int s = 0; s < nsteps; ++s) {
-            // ---- LOAD(s)
-            ++a_since;
-            if (it == 0 && ic + 1 < nchunks) {
-                VT_ISSUE_A((ic + 1) & 1, ic + 1);
-                a_since = 0;
+            prev_pieces = 0;
+            if (it == 0) {
+                if (ic > 0) prev_pieces = issue_plane(3, ic);
+            } else if (it >= 4 && !(it & 1) && ic + 1 < nchunks) {
+                prev_pieces = issue_plane((it - 4) >> 1, ic + 1);
             }
             if (s + PD < nsteps) {
-                VT_ISSUE_B(bnxt, ic_n, it_n);
+                VT_ISSUE_B(bnxt, ic_n, VT_TAP_OF(it_n));
                 if (++it_n == p.ntaps) it_n = 0, ++ic_n;
             }
-            const int d = __builtin_amdgcn_readfirstlane(sTap[it].x);
-            const int srow0 = wm * TM + (lane & 15) + d;
-            const uint4* A = sA + (ic & 1) * aslot + srow0 * 4 + ((lane >> 4) ^ swz(srow0));
-            const uint4* Bt = sB + bcur * BSLOT + wn * TN * 4 + b_lane;
-            uint4 af[FM], bf[FN];
+            {
+                const int4 tp = sTap[it];
+                const int d = __builtin_amdgcn_readfirstlane(tp.x);
+                const int rs = __builtin_amdgcn_readfirstlane(tp.y);
+                const int so = __builtin_amdgcn_readfirstlane(tp.z);
+                const int srow0 = wm * TM + (lane & 15) + d;
+                const uint4* A = sA + so + srow0 * 4 + ((lane >> 4) ^ swz(srow0));
+                const uint4* Bt = sB + bcur * BSLOT + wn * TN * 4 + b_lane;
+                uint4 af[FM], bf[FN];
 #pragma unroll
-            for (int j = 0; j < FN; ++j) bf[j] = Bt[j * 64];
+                for (int j = 0; j < FN; ++j) bf[j] = Bt[j * 64];
 #pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const uint4* src = ((fmask[i] >> it) & 1u) ? A : sZ - i * 64;
-                af[i] = src[i * 64];
-            }
-            // younger than B(s+1): the slices issued in the last PD-1 LOAD ticks, plus a span issued
-            // in one of them
-            const int nb = max(0, min(PD - 1, nsteps - 2 - s));
-            const int allowed = nb * ITB + ((a_since <= PD - 2) ? ita : 0);
-            if (grp == 1) vm_wait_dyn(s + 1 < nsteps ? allowed : 0);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            // ---- MFMA(s)
-            __builtin_amdgcn_s_setprio(1);
+                for (int i = 0; i < FM; ++i) {
+                    const uint4* src = ((fmask[i] >> rs) & 1u) ? A : sZ - i * 64;
+                    af[i] = src[i * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+                for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) mma<T>(af[i], bf[j], acc[i][j]);
-            __builtin_amdgcn_s_setprio(0);
-            if (grp == 0) vm_wait_dyn(s + 1 < nsteps ? allowed : 0);
-            if (!(grp == 1 && s + 1 == nsteps)) {
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
+                    for (int j = 0; j < FN; ++j) mma<T>(af[i], bf[j], acc[i][j]);
             }
             if (++it == p.ntaps) it = 0, ++ic;
             bcur = (bcur + 1 == NSB) ? 0 : bcur + 1;
             bnxt = (bnxt + 1 == NSB) ? 0 : bnxt + 1;
         }
-    } else if constexpr (DB) {
-        // ---- register double buffering: the fragments of step s+1 are read while step s's MFMAs run --------
-        // Invariant at the top of step s: filter slices <= s+2 have been issued, slice s+1 (and with it everything
-        // older, in particular the span of its chunk) must have landed before the barrier, because every wave
-        // reads step s+1's fragments during step s.  Slice s+3 is issued after the barrier into the ring slot of
-        // slice s, whose fragments are in registers (read during step s-1; the lgkmcnt wait before the barrier
-        // retires this wave's reads, the barrier everybody else's).  Ring: PD + 1 = 3 slots.  Requires
-        // ntaps >= 3: a span issued at the first tap of a chunk is older than the slice issued with it, which is
-        // waited for two steps later, before the span's first reader.
-        static_assert(PD == 2, "double-buffered fragments: three ring slots");
-        uint4 af0[FM], bf0[FN], af1[FM], bf1[FN];
-        auto read_frags = [&](uint4 (&af)[FM], uint4 (&bf)[FN], int ic_r, int it_r, int bslot) {
-            const int d = __builtin_amdgcn_readfirstlane(sTap[it_r].x);
-            const int srow0 = wm * TM + (lane & 15) + d;
-            const uint4* A = sA + (ic_r & 1) * aslot + srow0 * 4 + ((lane >> 4) ^ swz(srow0));
-            const uint4* Bt = sB + bslot * BSLOT + wn * TN * 4 + b_lane;
-#pragma unroll
-            for (int j = 0; j < FN; ++j) bf[j] = Bt[j * 64];
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const uint4* src = ((fmask[i] >> it_r) & 1u) ? A : sZ - i * 64;
-                af[i] = src[i * 64];
-            }
-        };
-        bool a_prev = false;  // a span was issued in the previous step
-        int icr = 0, itr = 0, br = 0;  // (chunk, tap, ring slot) of the step whose fragments are read next
-        read_frags(af0, bf0, 0, 0, 0);
-        if (++itr == p.ntaps) itr = 0, ++icr;
-        br = 1;
-        auto step = [&](int s, uint4 (&caf)[FM], uint4 (&cbf)[FN], uint4 (&naf)[FM], uint4 (&nbf)[FN]) {
-            const bool more = s + 1 < nsteps;
-            if (more) {
-                if (a_prev) vm_wait_dyn((s + 2 < nsteps ? ITB : 0) + ita);
-                else if (s + 2 < nsteps) vm_wait<ITB>();
-                else vm_wait<0>();
-            }
-            lds_fence();
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            a_prev = false;
-            if (it == 0 && ic + 1 < nchunks) {
-                VT_ISSUE_A((ic + 1) & 1, ic + 1);
-                a_prev = true;
-            }
-            if (s + 3 < nsteps) {
-                VT_ISSUE_B(bcur, ic_n, it_n);  // slot of slice s == slot of slice s+3
-                if (++it_n == p.ntaps) it_n = 0, ++ic_n;
-            }
-            // (unconditional: the last step re-reads its own, still valid, fragments -- a branch here makes the
-            //  compiler wait for these reads before the MFMAs below)
-            read_frags(naf, nbf, more ? icr : ic, more ? itr : it, more ? br : bcur);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) mma<T>(caf[i], cbf[j], acc[i][j]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (++it == p.ntaps) it = 0, ++ic;
-            if (++itr == p.ntaps) itr = 0, ++icr;
-            bcur = (bcur + 1 == NSB) ? 0 : bcur + 1;
-            br = (br + 1 == NSB) ? 0 : br + 1;
-        };
-        for (int s = 0; s < nsteps; s += 2) {
-            step(s, af0, bf0, af1, bf1);
-            if (s + 1 < nsteps) step(s + 1, af1, bf1, af0, bf0);
-        }
     } else
     for (int s = 0; s < nsteps; ++s) {
-        VT_LOOP_CLK(c0);
         // Retire this step's filter slice B(s).  VM operations retire in issue order, so everything
         // older is complete as well.  Younger than B(s): the slices of the next nb steps and, if it
         // was issued fewer than PD steps ago, the next chunk's span A' (issued just before the
         // slice of its step).  A' is needed at the first tap of its chunk; if that is NOW (few taps),
         // only the slices issued after A' may stay in flight.
         const int nb = min(PD - 1, nsteps - 1 - s);
-        if constexpr ((VT_SPAN_ABLATE & 2) != 0) {
-            if (s == 0) vm_wait<0>();
-        } else
         if (a_age >= 1 && a_age <= PD - 1) {  // once or twice per chunk: a span is in the window
             int allowed = nb * ITB;
             if (it == 0 && ic > 0 && a_age == p.ntaps)
@@ -489,13 +457,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
         } else {
             vm_wait<0>();
         }
-        VT_LOOP_CLK(c1);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        VT_LOOP_CLK(c2);
         // issue: next chunk's span at the first tap of a chunk, then the slice of step s+PD
         a_age = a_age ? a_age + 1 : 0;
-        if constexpr ((VT_SPAN_ABLATE & 2) == 0) {
         if (it == 0 && ic + 1 < nchunks) {
             VT_ISSUE_A((ic + 1) & 1, ic + 1);
             a_age = 1;
@@ -504,9 +469,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
             VT_ISSUE_B(bnxt, ic_n, it_n);
             if (++it_n == p.ntaps) it_n = 0, ++ic_n;
         }
-        }
 
-        VT_LOOP_CLK(c3);
         {
             const int d = __builtin_amdgcn_readfirstlane(sTap[it].x);
             const int srow0 = wm * TM + (lane & 15) + d;
@@ -515,16 +478,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
             uint4 af[FM], bf[FN];
             // filter fragments first: every MFMA of the first A row needs them
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                if constexpr ((VT_SPAN_ABLATE & 4) != 0) bf[j] = make_uint4(lane + j, s, lane, 0x3f803f80u);
-                else bf[j] = Bt[j * 64];
-            }
+            for (int j = 0; j < FN; ++j) bf[j] = Bt[j * 64];
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 // (sZ - i*64)[i*64] == sZ[0]: the constant stays in the instruction's offset field
                 const uint4* src = ((fmask[i] >> it) & 1u) ? A : sZ - i * 64;
-                if constexpr ((VT_SPAN_ABLATE & 4) != 0) af[i] = make_uint4(0x3f803f80u, lane * 3 + i, s, (unsigned)(unsigned long)src);
-                else af[i] = src[i * 64];
+                af[i] = src[i * 64];
             }
             // all fragment reads are issued before the first MFMA (the scheduler otherwise funnels
             // the A fragments through one register quad: read, wait lgkmcnt(0), 4 MFMAs, read, ...)
@@ -532,34 +491,17 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    if constexpr ((VT_SPAN_ABLATE & 1) != 0)
-                        asm volatile("" ::"v"(af[i].x), "v"(af[i].y), "v"(af[i].z), "v"(af[i].w), "v"(bf[j].x), "v"(bf[j].y), "v"(bf[j].z), "v"(bf[j].w));
-                    else mma<T>(af[i], bf[j], acc[i][j]);
-                }
+                for (int j = 0; j < FN; ++j) mma<T>(af[i], bf[j], acc[i][j]);
         }
-#ifdef VT_SPAN_STAMPS
-        asm volatile("s_nop 0" ::: "memory");
-        unsigned long long c4 = clock64();
-        VT_LOOP_ACC(0, c0, c1);
-        VT_LOOP_ACC(1, c1, c2);
-        VT_LOOP_ACC(2, c2, c3);
-        VT_LOOP_ACC(3, c3, c4);
-#endif
         if (++it == p.ntaps) it = 0, ++ic;
         bcur = (bcur + 1 == NSB) ? 0 : bcur + 1;
         bnxt = (bnxt + 1 == NSB) ? 0 : bnxt + 1;
     }
 #undef VT_ISSUE_A
 #undef VT_ISSUE_B
-    // every wave is done with the rings; they become the staging windows (ping-pong: nobody reads
-    // the rings after the last barrier inside the loop)
-    if constexpr (!PP) __syncthreads();
-    VT_STAMP(2);
-#ifdef VT_SPAN_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x < 8192)
-        for (int k = 0; k < 4; ++k) vt_span_loop[blockIdx.x * 4 + k] = loop_acc[k];
-#endif
+#undef VT_TAP_OF
+    // every wave is done with the rings; they become the staging windows
+    __syncthreads();
 
     // ---- epilogue: per wave, 16-row slabs through a private LDS window --------------------------
     constexpr int PITCH = TN + EPC;          // elements; +16 B keeps the 16-byte reads aligned
@@ -681,14 +623,20 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM >= 512 ? 1 : 2)) span_kernel
             }
         }
     }
-    VT_STAMP(3);
 }
 
 template <typename L>
 bool smem_ok(int ita, int nw, int nchunks) { return L::bytes(ita, nchunks > 1 ? 2 : 1, nw) <= 160 * 1024; }
 
-template <typename T, int BM, int BN, int WM, int WN, int PD, bool PP = false, bool DB = false>
-int launch_span_pd(IgemmArgs& a, int dmin, int span, hipStream_t st) {
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_span(IgemmArgs& a, int dmin, int span, hipStream_t st) {
+    // two filter slices in flight.  A third measured 3 % slower on the MFMA-bound layers once the issue stream was cleaned
+    // up (703 vs 727 TFLOP/s on 128 channels @28x28); EVERY slice of a 9-step tile in flight from the prologue on (PD = 8,
+    // round 4, for the short-K HBM-bound layers) measured slower too -- 32 -> 32 3x3 @112x112: 209 -> 253 us, 32 -> 64:
+    // 262 -> 299 us: the ring's 36 KB cost a workgroup per CU, and what bounds those layers is the first-access latency
+    // of a tile (prologue ~4.7 us of a ~12 us workgroup life), which only more resident workgroups or a persistent,
+    // prefetching kernel hide.
+    constexpr int PD = 2;
     using L = SpanLds<BM, BN, PD>;
     constexpr int NW = WM * WN;
     const int ita = (span + 16 * NW - 1) / (16 * NW);
@@ -699,100 +647,104 @@ int launch_span_pd(IgemmArgs& a, int dmin, int span, hipStream_t st) {
     const int nchunks = a.Cin / (64 / (int)sizeof(T));
     const int smem = L::bytes(ita, nchunks > 1 ? 2 : 1, NW);
     const long blocks = (long)8 * a.chunk * a.tiles_n;
-    auto kern = span_kernel<T, BM, BN, WM, WN, PD, PP, DB>;
+    auto kern = span_kernel<T, BM, BN, WM, WN, PD, false>;
     {
         const int rc = vt_raise_dynamic_lds((const void*)kern, 160 * 1024, "vt_conv_igemm(span)");
         if (rc != VT_OK) return rc;
     }
-    vt_note_kernel("span_kernel<%s,%d,%d,%d,%d,%d%s>", sizeof(T) == 2 ? "bf16" : "f32", BM, BN, WM, WN, PD,
-                   PP ? ",pingpong" : (DB ? ",dbuf" : ""));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NW), smem, st, a, dmin, ita);
+    vt_note_kernel("span_kernel<%s,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", BM, BN, WM, WN, PD);
+    SpanS2 g;
+    memset(&g, 0, sizeof(g));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NW), smem, st, a, dmin, ita, g);
     VT_CHECK_LAUNCH("vt_conv_igemm(span)");
-#ifdef VT_SPAN_STAMPS
-    {
-        static int calls = 0;
-        if (++calls == 20) {  // a warm launch
-            (void)hipStreamSynchronize(st);
-            static unsigned long long h[8192 * 4];
-            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(vt_span_stamps), sizeof(h));
-            const long nb = blocks < 8192 ? blocks : 8192;
-            unsigned long long t0 = ~0ull, t1 = 0;
-            double ph[3] = {0, 0, 0};
-            for (long b = 0; b < nb; ++b) {
-                if (h[b * 4] < t0) t0 = h[b * 4];
-                if (h[b * 4 + 3] > t1) t1 = h[b * 4 + 3];
-                for (int k = 0; k < 3; ++k) ph[k] += (double)(h[b * 4 + k + 1] - h[b * 4 + k]);
-            }
-            fprintf(stderr, "[span stamps] blocks %ld span %.2f us | avg per WG: prologue %.2f us, loop %.2f us, epilogue %.2f us\n",
-                    nb, (t1 - t0) * 0.01, ph[0] / nb * 0.01, ph[1] / nb * 0.01, ph[2] / nb * 0.01);
-            static unsigned long long hl[8192 * 4];
-            (void)hipMemcpyFromSymbol(hl, HIP_SYMBOL(vt_span_loop), sizeof(hl));
-            double la[4] = {0, 0, 0, 0};
-            for (long b = 0; b < nb; ++b)
-                for (int k = 0; k < 4; ++k) la[k] += (double)hl[b * 4 + k];
-            fprintf(stderr, "[span stamps] loop cycles per WG (wave 0, shader clock): vmwait %.0f barrier %.0f issue %.0f reads+mfma %.0f\n",
-                    la[0] / nb, la[1] / nb, la[2] / nb, la[3] / nb);
-            // start-time histogram: how many rounds
-            int late = 0;
-            for (long b = 0; b < nb; ++b) late += (h[b * 4] - t0) * 0.01 > 5.0;
-            fprintf(stderr, "[span stamps] workgroups starting > 5 us after the first: %d\n", late);
-        }
-    }
-#endif
     return VT_OK;
-}
-
-template <typename T, int BM, int BN, int WM, int WN>
-int launch_span(IgemmArgs& a, int dmin, int span, hipStream_t st) {
-    // two filter slices in flight; a third (VT_SPAN_PD=3, where two workgroups still fit a CU) measured
-    // 3 % slower once the issue stream was cleaned up (703 vs 727 TFLOP/s on 128ch @28x28)
-    const int pd_env = VT_KNOB("VT_SPAN_PD", 0);
-    constexpr int NW = WM * WN;
-    const int ita = (span + 16 * NW - 1) / (16 * NW);
-    const int nchunks = a.Cin / (64 / (int)sizeof(T));
-    const bool fits3 = 2 * SpanLds<BM, BN, 3>::bytes(ita, nchunks > 1 ? 2 : 1, NW) <= 160 * 1024;
-    const bool pd3 = pd_env == 3 && fits3 && nchunks * a.ntaps >= 6;
-    if (pd3) return launch_span_pd<T, BM, BN, WM, WN, 3>(a, dmin, span, st);
-    if constexpr (sizeof(T) == 2 && BN == 128 && WM == 2 && WN == 2 && (BM == 224 || BM == 256)) {
-        // the MFMA-bound 3x3 layers: fragments of step s+1 are read under the MFMAs of step s
-        const int db_env = VT_KNOB("VT_SPAN_DB", 0);
-        if (db_env && a.ntaps >= 3 && nchunks * a.ntaps >= 4)
-            return launch_span_pd<T, BM, BN, WM, WN, 2, false, true>(a, dmin, span, st);
-    }
-    return launch_span_pd<T, BM, BN, WM, WN, 2>(a, dmin, span, st);
 }
 
 template <typename T, int BM>
 int launch_span_bn(IgemmArgs& a, int dmin, int span, hipStream_t st) {
-    if constexpr (BM == 512) {
-        // 8 waves of 128 x 64: the filter slices (the larger part of the staged bytes) are fetched
-        // once per 512 pixels instead of once per 256.  Narrow layers: 4 waves of 128 x BN -- their
-        // K loop is 1-4 steps long, so a workgroup is mostly prologue + epilogue and what matters
-        // is the bytes it keeps in flight.
-        if (a.Cout > 64) {
-            const int pp = VT_KNOB("VT_SPAN_PP", 1);
-            if (pp && a.ntaps >= 3) return launch_span_pd<T, BM, 128, 4, 2, 3, true>(a, dmin, span, st);
-            return launch_span<T, BM, 128, 4, 2>(a, dmin, span, st);
-        }
-        if (a.Cout > 32) return launch_span<T, BM, 64, 4, 1>(a, dmin, span, st);
-        return launch_span<T, BM, 32, 4, 1>(a, dmin, span, st);
-    } else if constexpr (BM == 224) {
+    if constexpr (BM == 224) {
         // 7 x 32 rows: 2 x 2 waves of 112 x BN/2 for every width
         if (a.Cout > 64) return launch_span<T, BM, 128, 2, 2>(a, dmin, span, st);
         if (a.Cout > 32) return launch_span<T, BM, 64, 2, 2>(a, dmin, span, st);
         return launch_span<T, BM, 32, 2, 2>(a, dmin, span, st);
     } else {
-        if (a.Cout > 64) {
-            // 256 x 128 tile: 4 waves of 128 x 64 (VT_SPAN_WAVES=8: 8 waves of 64 x 64; measured equal)
-            const int waves = VT_KNOB("VT_SPAN_WAVES", 4);
-            if constexpr (BM == 256 && sizeof(T) == 2) {
-                if (waves == 8) return launch_span<T, BM, 128, 4, 2>(a, dmin, span, st);
-            }
-            return launch_span<T, BM, 128, 2, 2>(a, dmin, span, st);
-        }
+        // 256 x 128 tile: 4 waves of 128 x 64 (8 waves of 64 x 64 measured equal)
+        if (a.Cout > 64) return launch_span<T, BM, 128, 2, 2>(a, dmin, span, st);
         if (a.Cout > 32) return launch_span<T, BM, 64, 4, 1>(a, dmin, span, st);
         return launch_span<T, BM, 32, 4, 1>(a, dmin, span, st);
     }
+}
+
+// ---- stride 2 (space-to-depth view) ---------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+int launch_s2(IgemmArgs& a, hipStream_t st, bool dry) {
+    constexpr int PD = 2, NW = WM * WN;
+    using L = SpanLds<BM, BN, PD>;
+    static_assert(NW == 4, "piece distribution: four waves");
+    SpanS2 g;
+    memset(&g, 0, sizeof(g));
+    const int Wo = a.Wo, W = a.Wi;
+    const int dmins[4] = {-Wo - 1, -Wo, -1, 0};
+    const int pa[4] = {1, 1, 0, 0}, pc[4] = {1, 0, 1, 0};
+    const long px = (long)a.ldx * 2;  // bytes per pixel step
+    int off = 0;
+    for (int q = 0; q < 4; ++q) {
+        g.npieces[q] = (BM - dmins[q] + 15) / 16;
+        if ((g.npieces[q] + NW - 1) / NW > kS2MaxP) return -1;
+        g.slot_off[q] = off;
+        off += g.npieces[q] * 1024;
+        g.plane_off[q] = (int)((pa[q] * (long)W + pc[q]) * px);
+    }
+    g.delta[0] = (int)((2L * W + 2) * px), g.delta[1] = (int)(2L * W * px), g.delta[2] = (int)(2 * px), g.delta[3] = 0;
+    g.wrap = (int)((long)W * px);
+    g.maxoff = (int)((4L * (a.M - 1) - 2L * (Wo - 1)) * px);
+    const int smem = L::kA + off;
+    if (smem > 160 * 1024) return -1;
+    // steps of a chunk: class (1,1) taps (0,0) (0,2) (2,0) (2,2), class (1,0) taps (0,1) (2,1), class (0,1) taps (1,0) (1,2),
+    // class (0,0) tap (1,1); tap (r, s) sits (r == 0 ? -1 : 0) plane rows and (s == 0 ? -1 : 0) plane columns from the output
+    const int order[9][2] = {{0, 0}, {0, 2}, {2, 0}, {2, 2}, {0, 1}, {2, 1}, {1, 0}, {1, 2}, {1, 1}};
+    for (int t = 0; t < 9; ++t) {
+        const int r = order[t][0], s_ = order[t][1];
+        const int q = ((r & 1) ? 2 : 0) + ((s_ & 1) ? 1 : 0);  // a = !(r & 1), c = !(s & 1)
+        const int d = (r == 0 ? -Wo : 0) + (s_ == 0 ? -1 : 0);
+        g.t_q[t] = (int8_t)q, g.t_rs[t] = (int8_t)(3 * r + s_), g.t_drow[t] = (short)(d - dmins[q]);
+    }
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.Cout + BN - 1) / BN;
+    a.chunk = (a.tiles_m + 7) / 8;
+    const long blocks = (long)8 * a.chunk * a.tiles_n;
+    auto kern = span_kernel<bf16_t, BM, BN, WM, WN, PD, true>;
+    {
+        const int rc = vt_raise_dynamic_lds((const void*)kern, 160 * 1024, "vt_conv_igemm(span, stride 2)");
+        if (rc != VT_OK) return rc;
+    }
+    if (dry) return VT_OK;
+    vt_note_kernel("span_kernel<bf16,%d,%d,%d,%d,%d,s2d>", BM, BN, WM, WN, PD);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NW), smem, st, a, 0, 0, g);
+    VT_CHECK_LAUNCH("vt_conv_igemm(span, stride 2)");
+    return VT_OK;
+}
+
+// 3x3, stride 2, padding 1 on even maps, bf16, Cin a multiple of 32, the taps in raster order
+int span_s2_dispatch(IgemmArgs& a, int dtype, hipStream_t st) {
+    if (dtype != VT_BF16 || a.sh != 2 || a.sw != 2 || a.ntaps != 9 || a.h0 != -1 || a.w0 != -1) return -1;
+    if (a.flags & (VT_CONV_D2S | VT_CONV_NOSTORE)) return -1;
+    if ((a.Hi & 1) || (a.Wi & 1) || a.Ho * 2 != a.Hi || a.Wo * 2 != a.Wi || a.Cin % 32 != 0) return -1;
+    for (int t = 0; t < 9; ++t)
+        if (a.dh[t] != t / 3 || a.dw[t] != t % 3) return -1;
+    if ((long)a.B * a.Hi * a.Wi * a.ldx * 2 >= 0x7fff0000L) return -1;  // (per-lane byte offsets are ints)
+    if ((long)a.B * a.oH * a.oW > 0x7fffffffL) return -1;
+    // VT_SPAN_S2: 0 (default) off, 2 wherever it applies (tests, measurements).  Measured, round 4, batch 256 (us, this kernel
+    // against the gather kernel): 32 -> 64 @224 618 vs 445, 64 -> 128 @112 304 vs 222, 128 -> 256 @56 249 vs 173,
+    // 256 -> 512 @28 225 vs 151, 512 -> 1024 @14 235 vs 145.  It stages each input pixel once (48 KB per 128-row tile
+    // instead of 108), but a one-tile workgroup here waits for four plane spans before its first step and keeps 62 KB of
+    // LDS (two workgroups per CU against the gather kernel's four): on these layers the life of a workgroup is first-access
+    // latency, not staged bytes.
+    const int mode = VT_KNOB("VT_SPAN_S2", 0);
+    if (mode < 2) return -1;
+    if (a.Cout > 64) return launch_s2<128, 128, 2, 2>(a, st, false);
+    if (a.Cout > 32) return launch_s2<128, 64, 4, 1>(a, st, false);
+    return launch_s2<128, 32, 4, 1>(a, st, false);
 }
 
 }  // namespace
@@ -802,9 +754,9 @@ int vt_span_dispatch(IgemmArgs& a, int dtype, void* stream) {
     const int enabled = VT_KNOB("VT_IGEMM_SPAN", 1);
     if (!enabled) return -1;
     const int fast_dma = VT_KNOB("VT_SPAN_FAST_DMA", 1);
-    const int prio = VT_KNOB("VT_SPAN_PRIO", 0);
-    a.fast_dma = (fast_dma & 1) | ((prio & 3) << 1);
+    a.fast_dma = fast_dma & 1;
     const int ch = 4 * vt_epc(dtype);
+    if (a.sh == 2 && a.sw == 2) return span_s2_dispatch(a, dtype, (hipStream_t)stream);
     if (a.sh != 1 || a.sw != 1 || a.Ho != a.Hi || a.Wo != a.Wi) return -1;
     if (a.Cin % ch != 0 || a.ntaps > 32) return -1;
     if ((long)a.M + 2L * a.Wi * VT_MAX_TAPS > 0x7fffffffL) return -1;
@@ -819,10 +771,9 @@ int vt_span_dispatch(IgemmArgs& a, int dtype, void* stream) {
     // Plain GEMMs with a long K or many filter columns (1x1 convs with >= 320 channels on either side: the OSA
     // aggregation convs of VoVNet-39, the 14x14 stage of CSPDarknet-53): the gather kernel's 8-wave 256 x 128 tile stages
     // the rows once per 128 columns for 16 waves per CU and measured 7-20 % faster there (768 -> 256 @56x56, B=256:
-    // 632 -> 570 us; 1472 -> 768 @14x14: 171 -> 136 us; 256 -> 256 @28x28: equal).  VT_SPAN_GEMM=1: keep them here
-    const int gemm_minc = VT_KNOB("VT_SPAN_GEMM_MINC", 320);
-    if (dtype == VT_BF16 && a.ntaps == 1 && (a.Cin >= gemm_minc || a.Cout >= gemm_minc) && !VT_KNOB("VT_SPAN_GEMM", 0) &&
-        (VT_KNOB("VT_IGEMM_W8", 3) & 2) && (long)((a.M + 255) / 256) * ((a.Cout + 127) / 128) >= 256 && enabled < 2)
+    // 632 -> 570 us; 1472 -> 768 @14x14: 171 -> 136 us; 256 -> 256 @28x28: equal).
+    if (dtype == VT_BF16 && a.ntaps == 1 && (a.Cin >= 320 || a.Cout >= 320) && (VT_KNOB("VT_IGEMM_W8", 3) & 2) &&
+        (long)((a.M + 255) / 256) * ((a.Cout + 127) / 128) >= 256 && enabled < 2)
         return -1;
     if (dtype == VT_BF16) {
         // 256-row tiles; maps too small to give every CU a tile (7x7 at batch 256) run the
@@ -835,16 +786,11 @@ int vt_span_dispatch(IgemmArgs& a, int dtype, void* stream) {
             // Two workgroups fit a CU (512 slots).  With batch 256 the pixel counts are 2^k * 49, so
             // 256-row tiles often end in a thin last round (784 tiles = 1.53 rounds); 224-row
             // tiles divide those counts exactly (896 tiles = 1.75 rounds of 7/8 the length).
-            // Pick the height with the smaller rounds x height (VT_SPAN_BM=256/224 overrides).
-            const int bm_env = VT_KNOB("VT_SPAN_BM", 0);
+            // Pick the height with the smaller rounds x height.
             const long t224 = (long)((a.M + 223) / 224) * tiles_n;
             const long c256 = (tiles256 + 511) / 512 * 256, c224 = (t224 + 511) / 512 * 224;
             // (only the 128-wide tiles gain: the narrow ones are bound by their epilogue/HBM traffic)
-            const bool use224 = bm_env ? bm_env == 224 : (c224 < c256 && a.Cout > 64);
-            if (bm_env == 512) {
-                const int rc = launch_span_bn<bf16_t, 512>(a, dmin, 512 + dmax - dmin, st);
-                if (rc != -1) return rc;
-            }
+            const bool use224 = c224 < c256 && a.Cout > 64;
             const int rc = use224 ? launch_span_bn<bf16_t, 224>(a, dmin, 224 + dmax - dmin, st)
                                   : launch_span_bn<bf16_t, 256>(a, dmin, 256 + dmax - dmin, st);
             if (rc != -1) return rc;
