@@ -546,6 +546,10 @@ extern "C" int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w
         if (rc >= 0) return rc;
     }
     {
+        const int rc = vt_pspan_dispatch(a, d->dtype, stream);  // short-K, HBM-bound convs: persistent resident-filter kernel
+        if (rc >= 0) return rc;
+    }
+    {
         const int rc = vt_span_dispatch(a, d->dtype, stream);  // stride-1-grid convs: input-span kernel
         if (rc >= 0) return rc;
     }

@@ -35,6 +35,10 @@ int vt_span_dispatch(IgemmArgs& a, int dtype, void* stream);
 // four loader waves); -1 when it does not apply.
 int vt_span6_dispatch(IgemmArgs& a, int dtype, void* stream);
 
+// vt_igemm_pspan.hip: persistent span kernel with the whole filter resident in LDS (eight compute + four loader waves
+// per CU) for the short-K, HBM-bound convs with <= 128 output channels, stride 1 or 3x3 stride 2; -1 when it does not apply.
+int vt_pspan_dispatch(IgemmArgs& a, int dtype, void* stream);
+
 // vt_stem.hip: 3x3 stride-1 convolution over 8-channel (padded RGB) pixels; -1 when it does not apply.
 int vt_stem_dispatch(IgemmArgs& a, int dtype, void* stream);
 
