@@ -32,6 +32,12 @@
 
 namespace {
 
+// ablations exist only in -DVT_PSPAN_DIAG builds (tools/pspan_ablate.sh): results are wrong by construction, only the time is read
+#ifdef VT_PSPAN_DIAG
+#define VT_PDBG(bit) (a.debug & (bit))
+#else
+#define VT_PDBG(bit) false
+#endif
 constexpr int kMaxSteps = 16;  // K-steps per channel chunk (taps), at most
 constexpr int kMaxP = 8;       // span pieces (16 rows x 64 B) per loader wave and plane, at most
 
@@ -54,6 +60,7 @@ struct PsArgs {
     int wrap;           // s2: extra byte distance when one plane column back leaves the row
     int maxoff;         // s2: byte offset of the block under the last plane position
     int off_filter, off_sets, off_zero;  // LDS layout (bytes)
+    int debug;  // diagnostic builds: 1 no row tables after the first tile, 2 no stores, 4 no MFMA steps, 8 no span DMA after the prologue, 16 no tile_offsets
     short t_drow[kMaxSteps];             // step t of a chunk: row offset of its fragments inside the plane's span,
     int8_t t_q[kMaxSteps], t_rs[kMaxSteps];  // its plane and its filter tap
 };
@@ -73,6 +80,12 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p) {
 __device__ __forceinline__ void glds_s(unsigned voff, const void* sbase, unsigned lds_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1"
                  ::"v"(voff), "s"(uniform_ptr(sbase)), "s"(__builtin_amdgcn_readfirstlane(lds_addr))
+                 : "memory");
+}
+// the same with operands the caller has already made wave-uniform (one readfirstlane per plane, not three per piece)
+__device__ __forceinline__ void glds_u(unsigned voff, const void* sbase_uniform, unsigned lds_addr_uniform) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1"
+                 ::"v"(voff), "s"(sbase_uniform), "s"(lds_addr_uniform)
                  : "memory");
 }
 __device__ __forceinline__ unsigned get_m0() {
@@ -218,12 +231,21 @@ __global__ void __launch_bounds__(768, 3) pspan_kernel(const PsArgs a) {
         // Per tile: the byte offset in x of this lane's row of piece lj + 4 P (plane 0 / the tile's first block), plus its
         // chunk position.  stride 1: pixel m0 + dmin + r clamped into the tensor (a clamped row is only ever read through
         // a masked tap).  stride 2: block (2i, 2j) under plane position m0 + r; bit P of `wrapm`: first block of its row.
-        int poff[kMaxP];
+        // Per tile: the byte offset in x of this lane's row of piece lj + 4 P (plane 0 / the tile's first block), plus its
+        // chunk position.  stride 1: pixel m0 + dmin + r clamped into the tensor (a clamped row is only ever read through
+        // a masked tap).  stride 2: block (2i, 2j) under plane position m0 + r; bit P of `wrapm`: first block of its row.
+        // Tiles of a workgroup are consecutive, so after the first one every quantity advances by additions only
+        // (26 us of a 139 us launch went into eight 64-bit multiplies + clamps / divisions per tile and loader).
+        int poff[kMaxP];    // what issue_set uses
+        int praw[kMaxP];    // stride 1: unclamped byte offset; stride 2: 4 * v0 * ldx2 + chunk position
+        int pj[kMaxP];      // stride 2: column j0 of plane position v0
         unsigned wrapm = 0;
         const unsigned wo_magic = magic_of(p.Wo);
-        auto tile_offsets = [&](int tile) {
+        const int lo_b = cjA * 16, hi_b = (int)((long)(M - 1) * ldx2) + cjA * 16;
+        const int step_b = a.s2 ? 4 * BM * ldx2 : BM * ldx2;
+        const int jstep = a.s2 ? BM % p.Wo : 0;
+        auto tile_offsets_first = [&](int tile) {
             const long m0 = (long)tile * BM;
-            wrapm = 0;
 #pragma unroll
             for (int P = 0; P < kMaxP; ++P) {
                 const long r = 16 * (lj + 4 * P) + (lane >> 2);
@@ -231,12 +253,33 @@ __global__ void __launch_bounds__(768, 3) pspan_kernel(const PsArgs a) {
                     const long v0 = m0 + r;
                     int j0;
                     (void)div_magic((int)v0, p.Wo, wo_magic, j0);
-                    poff[P] = (int)((4 * v0 - 2 * j0) * (long)ldx2) + cjA * 16;
-                    wrapm |= (j0 == 0 ? 1u : 0u) << P;
+                    praw[P] = (int)(4 * v0 * (long)ldx2) + cjA * 16;
+                    pj[P] = j0;
                 } else {
-                    long pix = m0 + a.dmin + r;
-                    pix = pix < 0 ? 0 : (pix > M - 1 ? M - 1 : pix);
-                    poff[P] = (int)(pix * (long)ldx2) + cjA * 16;
+                    praw[P] = (int)((m0 + a.dmin + r) * (long)ldx2) + cjA * 16;
+                    pj[P] = 0;
+                }
+            }
+        };
+        auto tile_offsets_next = [&]() {
+#pragma unroll
+            for (int P = 0; P < kMaxP; ++P) {
+                praw[P] += step_b;
+                if (a.s2) {
+                    pj[P] += jstep;
+                    pj[P] -= pj[P] >= p.Wo ? p.Wo : 0;
+                }
+            }
+        };
+        auto tile_offsets_use = [&]() {
+            wrapm = 0;
+#pragma unroll
+            for (int P = 0; P < kMaxP; ++P) {
+                if (a.s2) {
+                    poff[P] = praw[P] - 2 * pj[P] * ldx2;
+                    wrapm |= (pj[P] == 0 ? 1u : 0u) << P;
+                } else {
+                    poff[P] = min(max(praw[P], lo_b), hi_b);
                 }
             }
         };
@@ -258,18 +301,21 @@ __global__ void __launch_bounds__(768, 3) pspan_kernel(const PsArgs a) {
         const int s2 = a.s2, wrap = a.wrap, maxoff48 = a.maxoff + 48, set_bytes = a.set_bytes;
         auto issue_set = [&](int gcs) {  // set gcs = (tile t0 + gcs / nchunks, chunk gcs % nchunks)
             const int tl = gcs / nchunks, ic = gcs - tl * nchunks;
-            if (tl != off_tile) {
-                tile_offsets(t0 + tl);
+            if (tl != off_tile) {  // (sets are issued in order: the next tile, if not the same one)
+                if (off_tile < 0) tile_offsets_first(t0 + tl);
+                else tile_offsets_next();
+                tile_offsets_use();
                 off_tile = tl;
             }
+            if (VT_PDBG(8) && gcs >= nbuf - 1) return;
             const unsigned buf = s_base + (unsigned)((gcs % nbuf) * set_bytes);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (q >= a.nplanes) break;
-                const char* sb = xg + (pl_off[q] + (long)ic * 64);
+                const void* sb = uniform_ptr(xg + (pl_off[q] + (long)ic * 64));
                 const int np = pl_np[q], dq = pl_dq[q];
                 const bool back1 = s2 && (q == 0 || q == 2);
-                const unsigned lds0 = buf + (unsigned)pl_slot[q];
+                const unsigned lds0 = __builtin_amdgcn_readfirstlane(buf + (unsigned)pl_slot[q] + (unsigned)(lj * 1024));
 #pragma unroll
                 for (int P = 0; P < kMaxP; ++P) {
                     if (lj + 4 * P < np) {
@@ -278,7 +324,7 @@ __global__ void __launch_bounds__(768, 3) pspan_kernel(const PsArgs a) {
                             off -= dq + ((back1 && ((wrapm >> P) & 1u)) ? wrap : 0);
                             off = min(max(off, 0), maxoff48);
                         }
-                        glds_s((unsigned)off, sb, lds0 + (unsigned)((lj + 4 * P) * 1024));
+                        glds_u((unsigned)off, sb, lds0 + (unsigned)(P * 4096));
                     }
                 }
             }
@@ -336,7 +382,7 @@ __global__ void __launch_bounds__(768, 3) pspan_kernel(const PsArgs a) {
             // the next tile's tables, while this tile's last chunk is multiplied (the half they go to was last read by
             // the epilogue of the tile before this one)
             const int tl = gc / nchunks;
-            if (gc - tl * nchunks == nchunks - 1 && tl + 1 < ntile) row_tables(tl + 1);
+            if (gc - tl * nchunks == nchunks - 1 && tl + 1 < ntile && !VT_PDBG(1)) row_tables(tl + 1);
             // set gc+1 (everything but this wave's share of the younger sets) has landed before barrier gc+1
             {
                 const int younger = min(nbuf - 2, max(0, G - 2 - gc));  // sets gc+2 .. issued so far
@@ -408,14 +454,20 @@ __global__ void __launch_bounds__(768, 3) pspan_kernel(const PsArgs a) {
         // the residual rows of the tile (the accumulate of a data gradient, DarknetBlock's shortcut in inference): requested
         // before the steps, used after them (clamped addresses: nothing orders a load behind a store)
         const long m0 = (long)(t0 + tl) * BM;
-        uint4 rres[FM];
+        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+        u32x4_t rres[FM];
+        // (asm: as a C++ load the compiler orders it behind the previous tile's stores -- y and the residual may be the
+        //  same buffer -- with s_waitcnt vmcnt(0) at the head of every tile: 1.3 us of store latency per tile, 32 -> 32 3x3
+        //  @112x112 150 -> 180 us.  A lane's residual element IS the one it stores to later in this tile and nothing else
+        //  in the launch touches it, so no order is needed; the wait in front of the first use is explicit.)
         if (MODE != 1 && has_res) {
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int tr = wrow + i * 16;
                 const long po = (int)tm_[BM + tr];
                 const bool ok = m0 + tr < p.M && col_ok;
-                rres[i] = *(const uint4*)(rg + (ok ? po * p.ldr + rcol : 0l));
+                const bf16_t* src = rg + (ok ? po * p.ldr + rcol : 0l);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rres[i]) : "v"(src) : "memory");
             }
         }
         // (interior tiles: every tap of every row inside the image -- no selects in the steps)
@@ -428,32 +480,89 @@ __global__ void __launch_bounds__(768, 3) pspan_kernel(const PsArgs a) {
             if (ic > 0) wg_barrier();  // barrier gc: set gc has landed
             const char* setb = sS + (gc % nbuf) * a.set_bytes;
             const char* fb = sF + (long)(ic * ntaps) * (BN * 64) + b_lane;
+            if (VT_PDBG(4)) continue;
             if constexpr (NT > 0) {
                 auto chunk = [&](auto maskedc) {
                     constexpr bool MASKED = decltype(maskedc)::value;
+                    // D steps of fragments in flight in a ring of D + 1 register sets: every read of step T + D is issued
+                    // before the MFMAs of step T (left alone the compiler reads one fragment, waits for it and multiplies --
+                    // an LDS round trip per two MFMAs: 0.73 us per 9-step tile instead of 0.15)
+                    // (FM = 4: one step ahead -- two more sets of 24 registers beside 32 accumulators, the residual rows and
+                    //  the per-tap offsets spill at the 168 registers three waves per SIMD leave)
+                    constexpr int D0 = 3;
+                    constexpr int D = D0 < NT ? D0 : (NT - 1 > 0 ? NT - 1 : 1);
+                    if constexpr (FM > 2) {
+                        // (FM = 4: 8 MFMAs per step cover most of a read's latency, and a ring of fragment sets beside 32
+                        //  accumulators, the residual rows / statistics and the per-tap offsets spills at the 168 registers
+                        //  three waves per SIMD leave: the compiler's own order, no ring)
 #pragma unroll
-                    for (int T = 0; T < NT; ++T) {
-                        // (FM = 8: 40 fragment registers per step beside 64 accumulators -- the steps are kept apart, the
-                        //  compiler otherwise keeps several steps' fragments in flight and spills 150-400 bytes per lane)
-                        if constexpr (FM >= 8) __builtin_amdgcn_sched_barrier(0);
+                        for (int T = 0; T < NT; ++T) {
+                            const char* Bt = fb + T * (BN * 64);
+                            const uint4 bf0 = *(const uint4*)(Bt);
+                            const uint4 bf1 = *(const uint4*)(Bt + 256);
+                            const char* A = setb + aoff[T];
+                            uint4 pf[FM];
+#pragma unroll
+                            for (int i = 0; i < FM; ++i) {
+                                const char* src = (!MASKED || ((fmask[i] >> rsv[T]) & 1u)) ? A + i * 1024 : sZ;
+                                pf[i] = *(const uint4*)src;
+                            }
+#pragma unroll
+                            for (int i = 0; i < FM; ++i) {
+                                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf0),
+                                                                                    __builtin_bit_cast(bf16x8, pf[i]), acc[i][0], 0, 0, 0);
+                                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf1),
+                                                                                    __builtin_bit_cast(bf16x8, pf[i]), acc[i][1], 0, 0, 0);
+                            }
+                        }
+                        return;
+                    }
+                    uint4 pfr[D + 1][FM], b0r[D + 1], b1r[D + 1];
+                    auto load_step = [&](auto Tc) {
+                        constexpr int T = decltype(Tc)::value;
+                        constexpr int S = T % (D + 1);
                         const char* Bt = fb + T * (BN * 64);
-                        const uint4 bf0 = *(const uint4*)(Bt);
-                        const uint4 bf1 = *(const uint4*)(Bt + 256);
+                        b0r[S] = *(const uint4*)(Bt);
+                        b1r[S] = *(const uint4*)(Bt + 256);
                         const char* A = setb + aoff[T];
-                        uint4 pf[FM];
 #pragma unroll
                         for (int i = 0; i < FM; ++i) {
                             const char* src = (!MASKED || ((fmask[i] >> rsv[T]) & 1u)) ? A + i * 1024 : sZ;
-                            pf[i] = *(const uint4*)src;
+                            pfr[S][i] = *(const uint4*)src;
                         }
+                    };
+                    auto mma_step = [&](auto Tc) {
+                        constexpr int S = decltype(Tc)::value % (D + 1);
 #pragma unroll
                         for (int i = 0; i < FM; ++i) {
-                            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf0),
-                                                                                __builtin_bit_cast(bf16x8, pf[i]), acc[i][0], 0, 0, 0);
-                            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf1),
-                                                                                __builtin_bit_cast(bf16x8, pf[i]), acc[i][1], 0, 0, 0);
+                            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b0r[S]),
+                                                                                __builtin_bit_cast(bf16x8, pfr[S][i]), acc[i][0], 0, 0, 0);
+                            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b1r[S]),
+                                                                                __builtin_bit_cast(bf16x8, pfr[S][i]), acc[i][1], 0, 0, 0);
                         }
-                    }
+                    };
+                    auto step = [&](auto Tc) {
+                        constexpr int T = decltype(Tc)::value;
+                        if constexpr (T + D < NT) load_step(std::integral_constant<int, (T + D < NT ? T + D : 0)>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                        mma_step(Tc);
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    auto pre = [&](auto Tc) {
+                        constexpr int T = decltype(Tc)::value;
+                        if constexpr (T < D && T < NT) load_step(std::integral_constant<int, (T < NT ? T : 0)>{});
+                    };
+                    pre(std::integral_constant<int, 0>{});
+                    pre(std::integral_constant<int, 1>{});
+                    pre(std::integral_constant<int, 2>{});
+                    auto steps = [&](auto... Ts) { (step(Ts), ...); };
+                    if constexpr (NT == 9)
+                        steps(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{},
+                              std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{},
+                              std::integral_constant<int, 6>{}, std::integral_constant<int, 7>{}, std::integral_constant<int, 8>{});
+                    else
+                        steps(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{},
+                              std::integral_constant<int, 3>{});
                 };
                 if (interior) chunk(std::false_type{});
                 else chunk(std::true_type{});
@@ -485,6 +594,11 @@ __global__ void __launch_bounds__(768, 3) pspan_kernel(const PsArgs a) {
         }
 
         // ---- epilogue: one 16-byte store per row fragment, straight from the accumulators --------------------------------
+        if (MODE != 1 && has_res) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < FM; ++i) asm volatile("" : "+v"(rres[i]));  // (defined from here on: no use moves above the wait)
+        }
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             const int tr = wrow + i * 16;
@@ -512,12 +626,12 @@ __global__ void __launch_bounds__(768, 3) pspan_kernel(const PsArgs a) {
                 if (MODE != 1 && has_res) {
                     float fv[8], fr[8];
                     VecIO<bf16_t>::unpack(out, fv);
-                    VecIO<bf16_t>::unpack(rres[i], fr);
+                    VecIO<bf16_t>::unpack(make_uint4(rres[i][0], rres[i][1], rres[i][2], rres[i][3]), fr);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) fv[e] += fr[e];
                     out = VecIO<bf16_t>::pack(fv);
                 }
-                *(uint4*)(yg + (po * p.ldy + ycol)) = out;
+                if (!VT_PDBG(2)) *(uint4*)(yg + (po * p.ldy + ycol)) = out;
             }
         }
     }
@@ -578,6 +692,7 @@ int ps_launch(PsArgs& a, hipStream_t st, bool dry) {
     a.nbuf = a.nbuf > cap ? cap : a.nbuf;
     if ((a.nbuf - 2) * ((a.set_bytes / 1024 + 3) / 4 + a.nplanes) > 30) a.nbuf = 2 + 30 / ((a.set_bytes / 1024 + 3) / 4 + a.nplanes);
     a.off_zero = a.off_sets + a.nbuf * a.set_bytes;
+    a.debug = VT_KNOB("VT_PSPAN_ABL", 0);
     const int smem = a.off_zero + 64;
     if (a.nbuf * a.set_bytes < 8 * 2 * BN * 4) return -1;  // (the statistics fold reuses the span area)
     a.tiles_m = (p.M + BM - 1) / BM;
@@ -588,6 +703,7 @@ int ps_launch(PsArgs& a, hipStream_t st, bool dry) {
     void (*kern)(const PsArgs) = nullptr;
 #define VT_PS_PICK(NTv)                                                                               \
     kern = mode == 1 ? pspan_kernel<BN, BM, 1, NTv> : (mode == 2 ? pspan_kernel<BN, BM, 2, NTv> : pspan_kernel<BN, BM, 0, NTv>)
+    static_assert(true, "NT is 9 or 4 or 0: the straight-line chunk lists its steps");
     if (a.ntaps == 9) VT_PS_PICK(9);
     else if (a.ntaps == 4) VT_PS_PICK(4);
     else VT_PS_PICK(0);
