@@ -51,11 +51,13 @@ CASES = [
     (2, 16, 24, 20, 28, 16, True),      # small: general kernel, folded addend
     (3, 32, 48, 36, 52, 64, True),      # d(x) is a channel slice of a wider buffer
     (2, 64, 64, 56, 56, 64, False),     # 256 columns
+    (2, 32, 64, 24, 40, 48, True),      # 128 columns, folded addend, channel slice: the persistent span kernel when forced
 ]
 
 
+@pytest.mark.parametrize("pspan", [1, 2], ids=["default_dispatch", "persistent_span_forced"])
 @pytest.mark.parametrize("B,Cin,Cout,H,W,ldx,with_res", CASES)
-def test_depth_to_space_dgrad_equals_the_four_class_launches(B, Cin, Cout, H, W, ldx, with_res):
+def test_depth_to_space_dgrad_equals_the_four_class_launches(B, Cin, Cout, H, W, ldx, with_res, pspan):
     torch.manual_seed(Cin + H)
     dev = "cuda"
     lib = N.lib()
@@ -87,7 +89,14 @@ def test_depth_to_space_dgrad_equals_the_four_class_launches(B, Cin, Cout, H, W,
                 sel.append(rows[u] * K + cols[v] if 0 <= u < len(rows) and 0 <= v < len(cols) else -1)
             _pack(lib, w, wd4[2 * ph + pw], sel, Cout, Cin)
     d = _desc(B, Hz, Wz, Cout, Cout, H, W, 4 * Cin, ldx, ldx, 4, TAPS, N.VT_CONV_D2S | rflag)
-    N.check(lib.vt_conv_igemm(C.byref(d), vp(dz), vp(wd4), vp(dx), None, None, vp(res), None, stream()))
+    N.set_knob("VT_PSPAN", pspan)  # (2: vt_igemm_pspan.hip wherever it applies -- <= 128 columns, dz channels a multiple of 32)
+    try:
+        N.check(lib.vt_conv_igemm(C.byref(d), vp(dz), vp(wd4), vp(dx), None, None, vp(res), None, stream()))
+        name = N.last_kernel_name()
+    finally:
+        N.set_knob("VT_PSPAN", 1)
+    if pspan == 2 and 4 * Cin <= 128 and Cout % 32 == 0:
+        assert "pspan" in name, name
     torch.cuda.synchronize()
     a, b = dx[..., :Cin].float(), dx_ref[..., :Cin].float()
     # same products; the tile shapes of the two launches may order the K chunks differently: one bf16 rounding

@@ -395,7 +395,7 @@ def _module_units(m):
     return [(n, u) for n, u in m.named_modules() if isinstance(u, ConvNormAct)]
 
 
-def _block_case(m, x, ref_forward):
+def _block_case(m, x, ref_forward, dtype=torch.bfloat16):
     """run module m (GPU, bf16, train mode) and the float64 references on x with a random upstream gradient; returns
     {tensor: (rel L2 error vs the storage-emulating reference, regression slope, elements, rel L2 distance of that
     reference from the pure-float64 one)} for the output, the input gradient and every parameter gradient"""
@@ -425,7 +425,7 @@ def _block_case(m, x, ref_forward):
         refs[store] = r
 
     m = m.cuda().train()
-    m.compute_dtype = torch.bfloat16
+    m.compute_dtype = dtype
     xg = x.cuda().requires_grad_(True)
     before = N.launch_count()
     y = m(xg)
@@ -437,7 +437,8 @@ def _block_case(m, x, ref_forward):
         ours[n + ".dw"], ours[n + ".dgamma"], ours[n + ".dbeta"] = u.conv.weight.grad, u.norm.weight.grad, u.norm.bias.grad
 
     out = {}
-    for k, ref in refs[True].items():
+    # (bf16: against the reference that rounds where the bf16 path stores; f32: against the pure float64 one)
+    for k, ref in refs[dtype == torch.bfloat16].items():
         a, b = ours[k].double().cpu().reshape(-1), ref.double().reshape(-1)
         f = refs[False][k].double().reshape(-1)
         out[k] = ((a - b).norm().item() / b.norm().item(), (a @ b).item() / (b @ b).item(), b.numel(),
@@ -518,12 +519,26 @@ def test_darknet_stage_bf16_train_mode_gradients_at_batch_256_are_tight():
     _assert_block(_block_case(m, x, ref))
 
 
-def test_vovnet_stage_boundaries_bf16_train_mode_gradients_at_batch_256_are_tight():
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_vovnet_stage_boundaries_train_mode_gradients_at_batch_256(dtype):
     """A two-stage VoVNet (reference backbones/vovnet.py:73-104) at batch 256 @112: stem (3 -> 32 stride 2, 32 -> 32,
     32 -> 64) -> MaxPool2d(3, 2, 1) -> OSABlock(64, 64, 3, 128) -> MaxPool2d(3, 2, 1) -> OSABlock(128, 80, 3, 256): the
     stride-2 conv -> OSA -> max-pool -> OSA chain, i.e. the max-pool writing into the first slice of a concat buffer, its
     backward (vt_maxpool3x3s2_bwd) routing the slice's accumulated gradient to the arg-max taps, and the stride-2 stem
-    unit's data path, with every gradient's regression slope bounded as in the block tests above."""
+    unit's data path.
+
+    f32 kernels against pure float64: the output and the last unit's BatchNorm gradients to 1e-4, every other gradient
+    within 8e-3 in L2 (measured 2.0e-3 .. 4.7e-3, flat over the depth of the chain: the conditioning of train-mode
+    BatchNorm backward in f32, as in test_trainer_gpu.py) and its regression slope within 2e-3 of 1 (measured <= 1e-3)
+    -- the TIGHT check of the routing: a wrong arg-max tap, a missing or doubled slice contribution moves both by the
+    size of the slip.
+
+    bf16: eleven units and two max-pools deep, two bf16 computations have decorrelated (measured: every gradient 0.07 ..
+    0.19 from the storage-emulating reference in L2, that reference itself 0.12 .. 0.37 from float64 -- a max-pool hands
+    the whole gradient of a window to another pixel when two candidates lie within a rounding of each other), so only
+    what survives that is asserted: the output within the format's noise floor, every gradient closer to the
+    storage-emulating reference than float64 is, and slopes within the deficit random decorrelation gives
+    (slope = 1 - rel^2 / 2 for equal norms: measured 1 - slope <= 2.6e-2 on the filter gradients at rel <= 0.19)."""
     from vision_toolbox.backbones.vovnet import VoVNet
 
     torch.manual_seed(41)
@@ -543,6 +558,16 @@ def test_vovnet_stage_boundaries_bf16_train_mode_gradients_at_batch_256_are_tigh
             h = _ref_unit(torch.cat(feats, 1), p[f"stages.{si}.module_0.out_conv"], 1, 1, store=store)
         return h
 
-    errs = _block_case(m, x, ref)
-    errs.pop("dx", None)  # (the image gradient: 3 channels behind the padded stem filter, not part of any train step)
-    _assert_block(errs)
+    errs = _block_case(m, x, ref, dtype)
+    bad = []
+    for k, (rel, slope, n, floor) in errs.items():
+        if dtype == torch.float32:
+            tight = k == "y" or k.startswith("stages.1.module_0.out_conv.d") and not k.endswith(".dw")
+            ok = rel < (1e-4 if tight else 8e-3) and abs(slope - 1.0) < 2e-3
+        elif k == "y":
+            ok = rel < floor
+        else:
+            ok = rel < floor + 1e-3 and abs(slope - 1.0) < 0.5 * rel * rel + (2e-2 if n >= 1024 else 8e-2)
+        if not ok:
+            bad.append((k, rel, slope, n, floor))
+    assert not bad, bad

@@ -761,6 +761,8 @@ int vt_pspan_dispatch(IgemmArgs& a0, int dtype, void* stream) {
     if (!s1 && !s2) return -1;
     // enough tiles to keep every workgroup busy for a few of them (else the one-tile kernels, which spread better)
     if (enabled < 2 && (long)a0.M < 256L * 256 * 3) return -1;
+    // (1x1: one K-step per channel chunk, i.e. a workgroup barrier per 2-16 MFMAs -- the pointwise kernels' territory)
+    if (enabled < 2 && a0.ntaps < 4) return -1;
     hipStream_t st = (hipStream_t)stream;
     for (int bm = 256; bm >= 128; bm -= 128) {
         if (s2) {
