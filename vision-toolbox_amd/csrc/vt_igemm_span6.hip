@@ -321,18 +321,11 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
         // ---- prologue: both groups' first span chunk, slices 0..2, the first tiles' row tables -----------
         const long S = (long)ntile * nsteps;  // steps of each group
         int m0c[2] = {VT_TILE_U0(0, 0) * 32, VT_TILE_U0(1, 0) * 32};
-        // the first tile's piece sources, then every LDS-DMA of the prologue, then the row tables under their flight
-        tile_bases(m0c[0], ab_cur[0], vm_cur[0]);
-        tile_bases(m0c[1], ab_cur[1], vm_cur[1]);
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int T = 0; T < 7; ++T)
-                if (lj + 4 * T < a.npc) {
-                    set_m0(a_base + (unsigned)((g * 2) * aslot_bytes + (lj + 4 * T) * 1024));
-                    glds_v(ab_cur[g][T]);
-                    ++issued;
-                }
+        // Round 4: the three filter slices go out FIRST (their addresses cost nothing), then each group's piece sources
+        // and pieces: the first loads are in flight while the ~600 vector instructions of the two tile_bases calls run,
+        // instead of behind them (the stamps put the first tick 6.8 us after the launch, 6.0 of them before the last
+        // prologue DMA was issued).  The first wait of the loop is then a full one: its counted form assumes the spans
+        // are older than slice 0.
         int h0 = 0, h1 = 0, h2 = 0;  // `issued` right after this wave's share of slices s, s+1, s+2 went out
         int sic = 0, sT = 0;         // (chunk, tap) of the next slice to issue; slices repeat per tile
         long sg = 0;                 // its step
@@ -351,6 +344,17 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
         next_slice();
         next_slice();
         (void)h0;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            tile_bases(m0c[g], ab_cur[g], vm_cur[g]);
+#pragma unroll
+            for (int T = 0; T < 7; ++T)
+                if (lj + 4 * T < a.npc) {
+                    set_m0(a_base + (unsigned)((g * 2) * aslot_bytes + (lj + 4 * T) * 1024));
+                    glds_v(ab_cur[g][T]);
+                    ++issued;
+                }
+        }
         row_tables(0, 0, m0c[0]);
         row_tables(1, 0, m0c[1]);
         VT_S6_STAMP(1);
@@ -393,8 +397,8 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                         constexpr int kYounger = 4 + 2 * (P(T - 1) + P(T - 2));
                         // ---- even tick 2s: slice s (and everything older: both groups' spans of its chunk) has landed
                         if (!VT_DBG(4)) {
-                            if (sleft > 2) vmw<kYounger>();
-                            else vmw<0>();
+                            if (sleft > 2 && sleft != S) vmw<kYounger>();
+                            else vmw<0>();  // (the first step: the prologue issued the slices before the spans)
                         }
                         VT_TBAR(lwait);
                         if constexpr (T < NTP) if (dma) {
