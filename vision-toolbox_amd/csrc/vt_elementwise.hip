@@ -1044,7 +1044,7 @@ __global__ void __launch_bounds__(kThreads) pack_dgrad_batch_kernel(const PackBa
 // Measured on the full step, every combination: 23.14 .. 23.25 ms against 23.23 .. 23.25 for the default (0) -- no
 // effect beyond noise; the knob stays for experiments.
 inline int vt_bn_order() {
-    const int v = VT_KNOB("VT_BN_REV", 0);
+    const int v = (0);
     return v;
 }
 
@@ -1189,10 +1189,10 @@ int vt_bn_act_bwd_reduce(const void* dy, int32_t lddy, const void* z, int32_t ld
     const int epc = vt_epc(dtype);
     // every block ends with 2*C 64-bit atomics into one of the statistics replicas: ~100 ns each when they queue on the same address,
     // so fewer, longer blocks win over grid-filling ones (measured per step: 1024 -> 23.53, 512 -> 23.36, 256 -> 23.27 ms)
-    const int target = VT_KNOB("VT_REDUCE_BLOCKS", 256);
+    const int target = (256);
     RowMap rm = RowMap::make(C, epc, M, target);
     rm.rev = (vt_bn_order() >> 1) & 1;
-    const int inwave_env = VT_KNOB("VT_REDUCE_INWAVE", 1);
+    const int inwave_env = (1);
     const bool inwave = inwave_env && rm.CT < 64 && (rm.CT & (rm.CT - 1)) == 0;  // (as in the kernel)
     const int smem = (inwave ? kThreads / 64 : rm.RT) * 2 * rm.CT * epc * (int)sizeof(float);
     VT_DISPATCH_T(dtype, "vt_bn_act_bwd_reduce",

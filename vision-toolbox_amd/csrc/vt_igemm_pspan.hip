@@ -688,11 +688,13 @@ int ps_launch(PsArgs& a, hipStream_t st, bool dry) {
     // span sets in flight = nbuf - 1: a tile's period cannot be shorter than (issue -> landed) / (sets in flight), and
     // that latency is 2-4 us under load (measured, 32 -> 32 3x3 @112x112: one set in flight 193 us per launch)
     a.nbuf = budget / a.set_bytes;
-    const int cap = VT_KNOB("VT_PSPAN_NBUF", 4);
+    const int cap = (4);
     a.nbuf = a.nbuf > cap ? cap : a.nbuf;
     if ((a.nbuf - 2) * ((a.set_bytes / 1024 + 3) / 4 + a.nplanes) > 30) a.nbuf = 2 + 30 / ((a.set_bytes / 1024 + 3) / 4 + a.nplanes);
     a.off_zero = a.off_sets + a.nbuf * a.set_bytes;
+#ifdef VT_PSPAN_DIAG
     a.debug = VT_KNOB("VT_PSPAN_ABL", 0);
+#endif
     const int smem = a.off_zero + 64;
     if (a.nbuf * a.set_bytes < 8 * 2 * BN * 4) return -1;  // (the statistics fold reuses the span area)
     a.tiles_m = (p.M + BM - 1) / BM;

@@ -753,7 +753,7 @@ int span_s2_dispatch(IgemmArgs& a, int dtype, hipStream_t st) {
 int vt_span_dispatch(IgemmArgs& a, int dtype, void* stream) {
     const int enabled = VT_KNOB("VT_IGEMM_SPAN", 1);
     if (!enabled) return -1;
-    const int fast_dma = VT_KNOB("VT_SPAN_FAST_DMA", 1);
+    const int fast_dma = (1);
     a.fast_dma = fast_dma & 1;
     const int ch = 4 * vt_epc(dtype);
     if (a.sh == 2 && a.sw == 2) return span_s2_dispatch(a, dtype, (hipStream_t)stream);

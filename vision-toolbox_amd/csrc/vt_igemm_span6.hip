@@ -745,7 +745,7 @@ static int span6_run(IgemmArgs& a0, int dtype, void* stream, bool dry) {
     S6Args a;
     a.p = a0;
     IgemmArgs& p = a.p;
-    a.debug = VT_KNOB("VT_SPAN6_ABL", 0);
+    a.debug = kDiag ? VT_KNOB("VT_SPAN6_ABL", 0) : 0;  // (diagnostic builds only)
     // padded coordinates: every tap within one pixel of the centre (3x3, padding 1: forward and stride-1 data gradient)
     a.Hp = a0.Hi + 1, a.Wp = a0.Wi + 1;
     if ((long)a0.B * a.Hp * a.Wp > 0x3fffffffL) return -1;

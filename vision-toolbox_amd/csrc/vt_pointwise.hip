@@ -494,9 +494,9 @@ int launch_pw(const PwArgs& a, hipStream_t st, const char* who) {
     // per resident slot -- 2 per CU at its register count -- measured best: 64 x 64 at 0.8 M pixels 170 -> 117 us)
     // (round 3, in the step: 768 for every pass 21.49 vs 512 | 1024 21.55 ms at batch 256; at batch 128, where the largest
     //  launch has 100 k units, 512 measured 12.53 vs 12.65 ms: whole multiples of the CU count, three per CU from 160 k units)
-    const int knob = VT_KNOB("VT_PW_BLOCKS", 0);
+    const int knob = (0);
     const int target = knob > 0 ? knob : (a.nunits >= 160000 ? 768 : 512);
-    const int per_wave = VT_KNOB("VT_PW_UNITS_PER_WAVE", 8);
+    const int per_wave = (8);
     long blocks = ((long)a.nunits + 4 * per_wave - 1) / (4 * per_wave);
     if (blocks > target) blocks = target;
     if (blocks < 1) blocks = 1;

@@ -351,7 +351,7 @@ static int run_ops_impl(const vt_op* ops, int32_t n, void* const* bases, int32_t
     static thread_local hipEvent_t eager_mark = nullptr;
     hipEvent_t capture_mark = nullptr;
     hipEvent_t& mark = bag ? capture_mark : eager_mark;
-    const int stop_events = VT_KNOB("VT_FORK_STOP_EVENT", 1);
+    const int stop_events = (1);
     hipEvent_t fork_ev = nullptr;  // completion event of the kernel right before the next FORK (see vt_common.h)
     for (int i = 0; i < n; ++i) {
         vt_op op = ops[i];

@@ -433,7 +433,7 @@ int launch_stem_t(const IgemmArgs& a, hipStream_t st) {
 
 // returns -1 when this kernel does not apply (the caller then uses the general kernels)
 int vt_stem_dispatch(IgemmArgs& a, int dtype, void* stream) {
-    const int enabled = VT_KNOB("VT_STEM_KERNEL", 1);
+    const int enabled = (1);
     if (!enabled || dtype != VT_BF16) return -1;
     if (a.Cin != 8 || a.ldx != 8 || a.ntaps != 9 || a.ldw != 72 || a.Cout > 64 || a.Cout % 8) return -1;
     if (a.sh != 1 || a.sw != 1 || a.Ho != a.Hi || a.Wo != a.Wi || a.h0 != -1 || a.w0 != -1) return -1;

@@ -492,7 +492,7 @@ int vt_stem_bn_bwd_reduce(int32_t dtype, int32_t B, int32_t H, int32_t W, int32_
     VT_REQUIRE(smem <= 64 * 1024, VT_ERR_UNSUPPORTED, "vt_stem_bn_bwd_reduce: image too wide for the LDS ring");
     // one workgroup per resident slot (2 per CU at this register count); a chunk must dwarf the ring warm-up (2*halo rows).
     // (1024 until round 3: 512 measured 21.34 vs 21.42 ms per step, 256 21.81, 768 21.51)
-    const int target = VT_KNOB("VT_STEM_BWD_WGS", 512);
+    const int target = (512);
     long chunk = (NP + target - 1) / target;
     const long min_chunk = 16l * a.halo;
     if (chunk < min_chunk) chunk = min_chunk;

@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(256 * G) wgrad_kernel(const WgradArgs p) {
             const int n = n0 + h * ROWS + nrow, k = k0 + kcol;
             const int gq = ((nrow & 15) >> 2);  // the row's g at write time
             const float v = sAcc[nrow * 128 + (kcol ^ (gq << 4))];
-            if (n < p.Cout && k < p.Ktot && !(p.ablate & 1)) {
+            if (n < p.Cout && k < p.Ktot) {
                 if (p.slab)
                     p.slab[(long)bsplit * p.slab_stride + (long)n * p.ldgw + k] = v;
                 else
@@ -453,9 +453,9 @@ static int wgrad_impl(const vt_conv_desc* d, const void* x, const void* dz, floa
 
     // Split of the pixel range: aim for `target` workgroups (about 2 per CU), but keep >= 8
     // steps per wave group; atomic traffic is (#workgroups x 64 KiB) whatever the layer.
-    const int target = VT_KNOB("VT_WGRAD_TARGET", 512);
-    const int max_split_env = VT_KNOB("VT_WGRAD_MAXSPLIT", 4096);
-    const int variant = VT_KNOB("VT_WGRAD_VARIANT", 0);
+    const int target = (512);
+    const int max_split_env = (4096);
+    const int variant = (0);
     const int G = variant == 1 ? 1 : (variant == 2 ? 4 : 2);
     const int pk = 4 * epc;
     const long tiles = (long)a.tiles_n * a.tiles_k;
@@ -464,7 +464,7 @@ static int wgrad_impl(const vt_conv_desc* d, const void* x, const void* dz, floa
     const int tgt = (d->ntaps == 1 && M <= 262144 && target == 512) ? 256 : target;
     long split = tgt / tiles;
     // steps per wave group and workgroup, at least (8 until round 3; 24 measured 12.29 vs 12.41 ms at batch 128, same at 256)
-    const int min_steps = VT_KNOB("VT_WGRAD_MINSTEPS", 24);
+    const int min_steps = (24);
     const long max_split = (M + (long)min_steps * pk * G - 1) / ((long)min_steps * pk * G);
     if (split > max_split) split = max_split;
     if (split > max_split_env) split = max_split_env;
@@ -476,15 +476,14 @@ static int wgrad_impl(const vt_conv_desc* d, const void* x, const void* dz, floa
     chunk = (chunk + (long)pk * G - 1) / ((long)pk * G) * ((long)pk * G);
     split = (M + chunk - 1) / chunk;
     a.chunk = (int)chunk;
-    const int ablate = VT_KNOB("VT_WGRAD_ABLATE", 0);  // timing experiments
-    a.ablate = ablate;
+    a.ablate = 0;
     const bool use_slabs = slabs && split > 1 && split * slab_stride * 4 <= scratch_bytes;  // (split 1: one writer per element)
     a.slab = use_slabs ? scratch : nullptr;
     a.slab_stride = slab_stride;
 
     hipStream_t st = (hipStream_t)stream;
     a.split = (int)split;
-    a.xcds = VT_KNOB("VT_WGRAD_XCD", 8);
+    a.xcds = (8);
     dim3 grid(vt_xcd_grid(tiles * split));
     const int stage = 2 * pk * 128 * vt_elem_size(d->dtype);  // 16 KiB
     const bool unit = d->ntaps == 1 && d->sh == 1 && d->sw == 1 && d->h0 + d->dh[0] == 0 && d->w0 + d->dw[0] == 0 &&

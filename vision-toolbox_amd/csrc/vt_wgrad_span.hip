@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
             const int img = idx / (NI * NC), e = idx % (NI * NC);
             const int n = e / NC, c = e % NC;
             const int t = img * p.tgn + tt;
-            if (n0 + n < p.Cout && c0 + c < p.Cin && !p.ablate) {
+            if (n0 + n < p.Cout && c0 + c < p.Cin) {
                 long col = (long)t * p.Cin + c0 + c;
                 if (p.cblk) {
                     const int blk = (c0 + c) / p.cblk;
@@ -350,7 +350,7 @@ static_assert(kWsPD >= 2 && kWsPD <= 6, "vm_wait switch covers PD - 1 <= 5");
 template <int FI, int FJ, bool WIDE = false>
 int launch_ws(WsArgs& a, long split, hipStream_t st) {
     a.split = (int)split;
-    a.xcds = VT_KNOB("VT_WGRAD_XCD", 8);
+    a.xcds = (8);
     constexpr int PD = kWsPD;
     const int rings = (PD + 1) * kDzSlot + a.RX * 128;
     const int image = 2 * 32 * FI * (32 * FJ + 4) * 4;
@@ -401,12 +401,12 @@ int launch_ws_taps(WsArgs& a, int ntaps, const int* eh, const int* ew, hipStream
     a.tiles_n = (a.Cout + 32 * FI - 1) / (32 * FI);
     a.tiles_c = (a.Cin + 32 * FJ - 1) / (32 * FJ);
     // pixel split: one 8-wave workgroup per CU, at least 16 steps each (the halo warm-up is NH chunks)
-    const int target = VT_KNOB("VT_WGRAD_SPAN_TARGET", 256);
+    const int target = (256);
     const long tiles = (long)a.tiles_n * a.tiles_c;
     long split = target / tiles;
     // (>= 144 steps per workgroup (96 .. 200 measured alike): at batch 128 the 256-workgroup target cut the 28x28 layers into 52-step pieces, and half
     //  as many workgroups of twice the length measured 12.54 vs 12.65 ms per step; batch 256 is unchanged by this bound)
-    const int min_steps = VT_KNOB("VT_WGRAD_SPAN_MINSTEPS", 144);
+    const int min_steps = (144);
     const long max_split = (NP + 32L * min_steps - 1) / (32L * min_steps);
     if (split > max_split) split = max_split;
     if (scratch && !a.cblk && split * (long)a.Cout * a.ldgw * 4 > scratch_bytes)
@@ -416,14 +416,13 @@ int launch_ws_taps(WsArgs& a, int ntaps, const int* eh, const int* ew, hipStream
     chunk = (chunk + 31) / 32 * 32;
     split = (NP + chunk - 1) / chunk;
     a.chunk = (int)chunk;
-    const int ablate = VT_KNOB("VT_WGRAD_ABLATE", 0);  // timing experiments
-    a.ablate = ablate;
+    a.ablate = 0;
     a.slab_stride = (long)a.Cout * a.ldgw;
     const bool use_slabs = scratch && !a.cblk && split > 1 && split * a.slab_stride * 4 <= scratch_bytes &&
                            (ntaps * a.Cin) % 4 == 0 && a.ldgw % 4 == 0;
     a.slab = use_slabs ? scratch : nullptr;
     int rc;
-    const int wide = VT_KNOB("VT_WGRAD_SPAN_WIDE", 1);
+    const int wide = (1);
     if (FI == 2 && FJ == 2)
         rc = wide ? launch_ws<2, 2, true>(a, split, st) : launch_ws<2, 2>(a, split, st);
     else if (FI == 2)
@@ -442,7 +441,7 @@ int launch_ws_taps(WsArgs& a, int ntaps, const int* eh, const int* ew, hipStream
 // returns -1 when this kernel does not apply (the caller then uses the general kernel)
 int vt_wgrad_span_dispatch(const vt_conv_desc* d, const void* x, const void* dz, float* dw, int32_t ldgw,
                            float* scratch, int64_t scratch_bytes, void* stream) {
-    const int enabled = VT_KNOB("VT_WGRAD_SPAN", 1);
+    const int enabled = (1);
     if (!enabled) return -1;
     if (d->dtype != VT_BF16 || d->ntaps != 9 || d->sh != 1 || d->sw != 1 || d->Ho != d->Hi || d->Wo != d->Wi)
         return -1;
@@ -450,7 +449,7 @@ int vt_wgrad_span_dispatch(const vt_conv_desc* d, const void* x, const void* dz,
     // general kernel, whose operands stay L2 resident there, was faster ALONE (97 vs 115 us at 256ch 14x14) and those
     // layers went to it.  Inside the step the all-taps kernel wins since round 3 (one 8-wave workgroup per CU next to the
     // main stream's kernels: 21.46 vs 21.55 ms, alternating runs): VT_WGRAD_SPAN_MINW = 20 restores the old rule.
-    const int minw_wide = VT_KNOB("VT_WGRAD_SPAN_MINW", 0);
+    const int minw_wide = (0);
     if (enabled < 2 && d->Wi < minw_wide && d->Cin > 64 && d->Cout > 64) return -1;
     int ph = 0, pw = 0, eh[9], ew[9];
     for (int t = 0; t < 9; ++t) {

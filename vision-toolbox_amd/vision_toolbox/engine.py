@@ -238,41 +238,32 @@ class Builder:
         # weights, so their (tiny, launch-bound) pack kernels leave the backward critical path
         # and run on the side stream while the forward list executes
         self.hoist_dgrad_packs = False
-        # release each filter gradient to the side stream after (True) or before (False) the unit's data gradient
-        self.wgrad_late = os.environ.get("VT_WGRAD_LATE", "0") != "0"
-        # FORK split into MARK (before the data gradient) and WAIT (before the filter gradient): measured equal to the
-        # plain FORK (24.65 vs 24.66 ms: the 7 us per unit on the main stream are the event record itself, not the
-        # host's issue order), so off
-        self.fork_split = os.environ.get("VT_FORK_SPLIT", "0") != "0"
-        # ... except for the unit that reads the stem's output (and any unit whose input is at least VT_WGRAD_LATE_MB
-        # large): its data gradient, its filter gradient and the stem's one-pass backward are the HBM-bound tail of a step;
-        # released AFTER the data gradient, the filter gradient runs beside the stem's backward, which otherwise has the
-        # GPU to itself, instead of beside the data gradient (trace: 804 + 628 us; step 21.66 -> 21.54 ms)
-        self.wgrad_late_mb = float(os.environ.get("VT_WGRAD_LATE_MB", "0"))
-        self.wgrad_late_stem = os.environ.get("VT_WGRAD_LATE_STEM", "1") != "0"
-        # stem unit (3 -> 32, s1): BatchNorm-backward reduction and filter gradient in one pass, dz never formed
-        self.stem_fused_bwd = os.environ.get("VT_STEM_FUSED_BWD", "1") != "0"
-        # ... and its pre-activation z (B x 224 x 224 x 32, the largest tensor of a step) is never stored: the conv runs
-        # twice (statistics only, then with the normalise + ReLU epilogue) and backward recovers z from y
-        self.stem_from_y = os.environ.get("VT_STEM_FROM_Y", "1") != "0"
-        # 3x3 stride-2 data gradients whose dz has at most this many channels (the HBM-bound ones) run as ONE
-        # depth-to-space launch instead of four parity-class launches that each re-read dz
-        self.dgrad_d2s_maxc = int(os.environ.get("VT_DGRAD_D2S_MAXC", "128"))
+        # Schedule and decomposition choices, each the winner of an alternating A/B inside the train step (NOTEBOOK.md):
+        #  * a unit's filter gradient is released to the side stream BEFORE its data gradient (after it for every unit:
+        #    22.20 vs 21.27 ms) -- except for the unit that reads the stem's output: its data gradient, its filter gradient
+        #    and the stem's one-pass backward are the HBM-bound tail of a step, and released after the data gradient the
+        #    filter gradient runs beside the stem's backward instead (21.41 -> 21.27 ms);
+        #  * stem unit (3 -> 32, s1): BatchNorm-backward reduction and filter gradient in one pass, dz never formed, and
+        #    its pre-activation z (B x 224 x 224 x 32, the largest tensor of a step) never stored: the conv runs twice
+        #    (statistics only, then with the normalise + ReLU epilogue) and backward works from y (vt_stem_bwd.hip);
+        #  * 3x3 stride-2 data gradients whose dz has at most 128 channels (the HBM-bound ones) run as ONE depth-to-space
+        #    launch instead of four parity-class launches that each re-read dz (256: 21.90 vs 21.70 ms).
+        self.dgrad_d2s_maxc = 128
         # deterministic mode: the last sums still made with f32 atomics take an order-free form -- the filter gradients
         # become two-stage (partial tiles stored into slabs of ONE scratch that every layer reuses, then an ordered
         # reducer), the bias column sums and the one-pass stem kernel's correlations go through fixed point; with
         # the fixed-point BatchNorm statistics every gradient and parameter update is then bit-identical from run to run
         self.deterministic = (os.environ.get("VT_DETERMINISTIC", "0") != "0") if deterministic is None else bool(deterministic)
-        self.wgrad_slab_mb = int(os.environ.get("VT_WGRAD_SLABS_MB", "48" if self.deterministic else "0"))  # 0 = atomics
+        self.wgrad_slab_mb = 48 if self.deterministic else 0  # 0 = atomics
         self._wgrad_slab = None
         # 1x1 ConvNormAct units as four streaming passes that recompute z = W x instead of storing z and dz
         # (vt_pointwise.hip); off in deterministic mode (its filter gradient leaves through float atomics)
-        self.pointwise = os.environ.get("VT_POINTWISE", "1") != "0" and not self.deterministic
+        self.pointwise = not self.deterministic
         # ... where the unit's input is at least this many MB: smaller tensors stay in the memory-side cache between the
         # passes of the unfused path, which is then as fast (measured at batch 256, CSPDarknet-53: 22.40 ms with the 51 MB
-        # tensors of stage 2 included, 22.11 without; 23.32 with the pointwise path off)
+        # tensors of stage 2 included, 22.11 without; 23.32 with the pointwise path off).  VT_PW_MIN_MB (the tests set 0:
+        # their toy tensors would otherwise never reach these kernels)
         self.pointwise_min_mb = float(os.environ.get("VT_PW_MIN_MB", "80"))
-        self.pointwise_inference = os.environ.get("VT_PW_INFERENCE", "1") != "0"
         self._hoisted: list[N.Op] = []
         # SyncBatchNorm (configs/base.yaml:22): the trainer all-reduces every layer's statistics
         # between the kernel that accumulates them and the finalize kernel; the finalize kernels
@@ -583,10 +574,10 @@ class Builder:
         y = out if out is not None else self.act(B, Ho, Wo, Cout, name + ".y")
         z = None
         coef = None
-        stem_fused = (self.stem_fused_bwd and track and padded and has_bn and not fused and residual is None and
+        stem_fused = (track and padded and has_bn and not fused and residual is None and
                       not x.needs_grad and w.requires_grad and dt == N.VT_BF16 and Cout == 32 and k == 3 and s == 1 and
                       pad == 1 and x.C == 8 and x.ld == 8 and x.W <= 888 and B * (x.H + 1) * (x.W + 1) < 0x7fff0000)  # (ring in LDS: halo <= 896 rows)
-        stem_y = stem_fused and unit_training and self.stem_from_y and x.W <= 824  # (one more step of halo)
+        stem_y = stem_fused and unit_training and x.W <= 824  # (one more step of halo)
         if has_bn:
             coef = self.f32(4 * Cout, "bncoef")  # scale, shift, mean, invstd
             cp = [self.bp(coef, i * Cout * 4) for i in range(4)]
@@ -686,14 +677,12 @@ class Builder:
                         else:
                             self.emit(N.OP_COLSUM, [dz.addr(), self.pgrad(conv.bias)], [dz.ld, Cout, dt], [M])
                 # filter gradient: needs only x and dz and nothing in backward waits for it, so it goes to the
-                # side stream.  It is released AFTER this unit's data gradient (wgrad_late): both are MFMA-bound
-                # and only slow each other down, whereas the HBM-bound BatchNorm passes of the next unit in
-                # backward order leave the matrix pipes to it.
-                def emit_wgrad(wait_only=False):
+                # side stream, beside the HBM-bound BatchNorm passes of the units that follow in backward order
+                def emit_wgrad():
                     if not w.requires_grad:
                         return
                     dfwd = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, dz.ld, ldw, 0)
-                    self.emit(N.OP_FORK_WAIT if wait_only else N.OP_FORK)
+                    self.emit(N.OP_FORK)
                     slab, slab_mb = None, 0
                     if self.wgrad_slab_mb > 0:  # two-stage (stored slabs + ordered reducer) instead of f32 atomics
                         if self._wgrad_slab is None:
@@ -709,24 +698,16 @@ class Builder:
                         self.emit(N.OP_CONV_WGRAD, [x.addr(), dz.addr(), self.pgrad(w), slab], desc=dfwd,
                                   extra_ints=[ldw, slab_mb], side=True)
 
-                # Host issue order: [mark the main stream's position: dz is complete] [data gradient, main stream]
-                # [side stream waits for the MARK] [filter gradient].  The filter gradient still depends on dz only,
-                # but the main stream does not sit idle while the host enqueues it (7 us x 66 units in the trace).
-                late = self.wgrad_late or (x.needs_grad and (
-                    (self.wgrad_late_mb > 0 and x.M * x.C * 2 >= self.wgrad_late_mb * 1e6) or
-                    (self.wgrad_late_stem and getattr(x, "stem_out", False))))
-                split = self.fork_split and w.requires_grad and x.needs_grad and not late
-                if split:
-                    self.emit(N.OP_FORK_MARK)
-                elif not late:
+                # Released BEFORE the unit's data gradient, except behind the stem (see __init__): there the data gradient
+                # runs first and the filter gradient beside the stem's one-pass backward.
+                late = x.needs_grad and getattr(x, "stem_out", False)
+                if not late:
                     emit_wgrad()
                 # data gradient
                 if x.needs_grad:
                     self._dgrad(x, dz, wptr if not padded else self.bp(wpack), dt if (padded or dt != N.VT_F32) else N.VT_F32,
                                 ldw, Cout, k, s, pad, Ho, Wo)
-                if split:
-                    emit_wgrad(wait_only=True)
-                elif late:
+                if late:
                     emit_wgrad()
 
             self.nodes.append(bwd)
@@ -752,9 +733,7 @@ class Builder:
         unit_training, _ = next(iter(flags))
         # (inference: the apply pass alone, with the running-statistics coefficients -- it streams x once at ~5.5 TB/s
         #  where the conv launch with the affine + ReLU epilogue stages it through LDS at ~2.7: 160 -> 160 @80x80 x 64
-        #  images, 46 vs 91 us.  VT_PW_INFERENCE=0: the conv launch)
-        if not unit_training and not self.need_grad and not self.pointwise_inference:
-            return 0
+        #  images, 46 vs 91 us)
         if self.need_grad and not x.needs_grad:
             return 0  # (the backward kernel always forms dx)
         if x.M * x.C * 2 < self.pointwise_min_mb * 1e6:

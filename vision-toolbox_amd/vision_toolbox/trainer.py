@@ -461,8 +461,8 @@ class TrainStep:
                         self.bucketer.reduce_bucket(bi)
             else:
                 if self._side is None:
-                    self._side = torch.cuda.Stream(self.device, priority=int(os.environ.get("VT_SIDE_PRIORITY", "0")))
-                side = int(self._side.cuda_stream) if os.environ.get("VT_NO_SIDE_STREAM", "0") == "0" else 0  # (diagnostics: one stream)
+                    self._side = torch.cuda.Stream(self.device)
+                side = int(self._side.cuda_stream)
                 N.run_ops(self.zero_ops, 1, self.bases, s)
                 self._run_list(p.fwd_ops, p.n_fwd, self._fwd_sync, [], {}, s, side, keep_side_open=False)
                 self._run_list(p.bwd_ops, p.n_bwd, self._bwd_sync, self.bwd_cuts,
