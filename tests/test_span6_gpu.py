@@ -134,3 +134,38 @@ def test_160_columns_run_as_128_on_span6_plus_32_on_the_span_kernel(mode):
     assert launches == [2, 1], launches
     assert torch.equal(torch.isnan(outs[0].float()), torch.isnan(outs[1].float()))
     assert torch.equal(torch.nan_to_num(outs[0].float()), torch.nan_to_num(outs[1].float()))
+
+
+@pytest.mark.parametrize("mode", [m for m in MODES if m[0] != "stats"], ids=[m[0] for m in MODES if m[0] != "stats"])
+def test_160_columns_tail_on_the_persistent_span_kernel(mode):
+    """Round 4: from 262144 rows up the 32-column tail of a 128 k + 32 column launch runs on vt_igemm_pspan.hip (default
+    dispatch, forward epilogues included: Darknet-YOLOv5x's 160 -> 160 @80x80 layers).  Same products in the same (chunk,
+    tap) order as the unsplit launch; compared within two bf16 roundings, nothing outside the channel slice."""
+    B, Cin, Cout, H, W = 16, 96, 160, 128, 128
+    flags = mode[1]
+    torch.manual_seed(12)
+    ldx, ldy = Cin + 32, Cout + 64
+    xb = torch.randn(B, H, W, ldx, device="cuda").to(torch.bfloat16)
+    x = xb[..., 16:16 + Cin]
+    w = (torch.randn(Cout, 9, Cin, device="cuda") * (2.0 / (9 * Cin)) ** 0.5).to(torch.bfloat16)
+    res = torch.randn(B, H, W, Cout, device="cuda").to(torch.bfloat16) if flags & N.VT_CONV_RESIDUAL else None
+    scale = torch.rand(Cout, device="cuda") + 0.5 if flags & N.VT_CONV_AFFINE else None
+    shift = torch.randn(Cout, device="cuda") if flags & N.VT_CONV_AFFINE else None
+    d = _desc(B, Cin, Cout, H, W, ldx, ldy, Cout if res is not None else 0, flags, flip=False)
+    outs, launches = [], []
+    try:
+        for split in (1, 0):
+            N.set_knob("VT_SPAN6_SPLIT", split)
+            yb = torch.full((B, H, W, ldy), float("nan"), device="cuda", dtype=torch.bfloat16)
+            before = N.launch_count()
+            name = _run("1", d, x, w, yb[..., 32:32 + Cout], scale, shift, res, None)
+            launches.append(N.launch_count() - before)
+            assert "span6" in name
+            outs.append(yb)
+    finally:
+        N.set_knob("VT_SPAN6_SPLIT", 1)
+    assert launches == [2, 1], launches
+    assert torch.equal(torch.isnan(outs[0].float()), torch.isnan(outs[1].float()))
+    a, b = torch.nan_to_num(outs[0].float()), torch.nan_to_num(outs[1].float())
+    torch.testing.assert_close(a, b, rtol=2.0 ** -6, atol=2e-2)
+    assert torch.equal(a[..., 32:32 + 128], b[..., 32:32 + 128])  # the head columns: the same kernel, the same bits

@@ -756,13 +756,13 @@ int vt_pspan_dispatch(IgemmArgs& a0, int dtype, void* stream) {
     a.ntaps = a0.ntaps;
     const int nsteps = a.nchunks * a.ntaps;
     const int bn = a0.Cout > 64 ? 128 : (a0.Cout > 32 ? 64 : 32);
-    if (nsteps * bn * 64 > 80 * 1024) return -1;  // the resident filter
+    if (nsteps * bn * 64 > 96 * 1024) return -1;  // the resident filter (the span sets must still fit twice: ps_launch)
     const bool s1 = a0.sh == 1 && a0.sw == 1 && a0.Ho == a0.Hi && a0.Wo == a0.Wi;
     const bool s2 = a0.sh == 2 && a0.sw == 2 && a0.ntaps == 9 && a0.h0 == -1 && a0.w0 == -1 && !(a0.Hi & 1) && !(a0.Wi & 1) &&
                     a0.Ho * 2 == a0.Hi && a0.Wo * 2 == a0.Wi && !d2s;
     if (!s1 && !s2) return -1;
     // enough tiles to keep every workgroup busy for a few of them (else the one-tile kernels, which spread better)
-    if (enabled < 2 && (long)a0.M < 256L * 256 * 3) return -1;
+    if (enabled < 2 && (long)a0.M < 256L * 256 * 4) return -1;
     // (1x1: one K-step per channel chunk, i.e. a workgroup barrier per 2-16 MFMAs -- the pointwise kernels' territory)
     if (enabled < 2 && a0.ntaps < 4) return -1;
     hipStream_t st = (hipStream_t)stream;

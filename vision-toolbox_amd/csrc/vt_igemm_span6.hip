@@ -827,16 +827,12 @@ static int span6_run(IgemmArgs& a0, int dtype, void* stream, bool dry) {
 // returns -1 when this kernel does not apply (the caller then tries the other span kernels)
 int vt_span6_dispatch(IgemmArgs& a0, int dtype, void* stream) {
     // 128 k + 32 output channels (160: Darknet-YOLOv5x, VoVNet-39): the filter tiles are 128 wide, so the last one would
-    // be a quarter full and cost as much as a full one.  The first 128 k columns run here, the last 32 on the input-span
-    // kernel's 32-wide tile as a second launch over the same input (160 -> 160 @80x80 x 64 images, residual epilogue:
-    // 360 -> 186 + 110 us alone).  Not with batch statistics (their buffer is indexed by the launch's own channel count),
-    // not for 64 remaining columns (192 @14x14: 60 us whole, 42 + 32 split).  By default (VT_SPAN6_SPLIT=1) only the data
-    // gradients take it (VoVNet-39 step 25.87 -> 25.70 ms); inside the YOLOv5x forward the pair measured no faster than
-    // the whole launch (305 vs 320 us per layer in the trace, 13.64 vs 13.56 ms per forward): =2 splits those too, =0 none
+    // be a quarter full and cost as much as a full one.  The first 128 k columns run here, the last 32 as a second launch
+    // over the same input.  Not with batch statistics (their buffer is indexed by the launch's own channel count), not for
+    // 64 remaining columns (192 @14x14: 60 us whole, 42 + 32 split).  VT_SPAN6_SPLIT=0: never.
     const int rem = a0.Cout % 128;
     const int split = VT_KNOB("VT_SPAN6_SPLIT", 1);
-    if (split && a0.Cout > 128 && rem == 32 && dtype == VT_BF16 && (split >= 2 || !(a0.flags & VT_CONV_AFFINE)) &&
-        !(a0.flags & (VT_CONV_STATS | VT_CONV_D2S | VT_CONV_NOSTORE))) {
+    if (split && a0.Cout > 128 && rem == 32 && dtype == VT_BF16 && !(a0.flags & (VT_CONV_STATS | VT_CONV_D2S | VT_CONV_NOSTORE))) {
         const int head = a0.Cout - rem;
         IgemmArgs a1 = a0;
         a1.Cout = head;
@@ -848,7 +844,12 @@ int vt_span6_dispatch(IgemmArgs& a0, int dtype, void* stream) {
             if (a0.res) a2.res = (const char*)a0.res + (long)head * 2;
             if (a0.scale) a2.scale = a0.scale + head;
             if (a0.shift) a2.shift = a0.shift + head;
-            const int rc2 = vt_span_dispatch(a2, dtype, stream);
+            // The 32-column tail.  Round 4: on the persistent resident-filter kernel where it applies (>= 262k rows, a filter
+            // of <= 96 KB: 160 -> 160 @80x80 x 64 images -- 63 us, the pair 292 us against 364 whole; Darknet-YOLOv5x forward
+            // 13.33 -> 13.06 ms), forward launches included.  Else on the input-span kernel's 32-wide tile, data gradients
+            // only (inside the YOLOv5x forward that pair measured no faster than the whole launch; VT_SPAN6_SPLIT=2: those too).
+            int rc2 = vt_pspan_dispatch(a2, dtype, stream);
+            if (rc2 == -1 && (split >= 2 || !(a0.flags & VT_CONV_AFFINE))) rc2 = vt_span_dispatch(a2, dtype, stream);
             if (rc2 == VT_OK) return span6_run(a1, dtype, stream, false);
             if (rc2 != -1) return rc2;
         }
