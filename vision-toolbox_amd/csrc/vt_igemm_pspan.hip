@@ -63,8 +63,6 @@ struct PsArgs {
     int debug;  // diagnostic builds: 1 no row tables after the first tile, 2 no stores, 4 no MFMA steps, 8 no span DMA after the prologue, 16 no tile_offsets
     short t_drow[kMaxSteps];             // step t of a chunk: row offset of its fragments inside the plane's span,
     int8_t t_q[kMaxSteps], t_rs[kMaxSteps];  // its plane and its filter tap
-    int8_t t_c[kMaxSteps];                   // its channel chunk inside the set (1x1 launches: a set = all chunks of a tile)
-    int cps;                                 // channel chunks per set: 1, or Cin / 32 for the 1x1 launches
 };
 
 __device__ __forceinline__ int swz4(int g) { return (0x1320 >> ((g & 3) * 4)) & 3; }  // filter-slice image
@@ -220,7 +218,7 @@ __global__ void __launch_bounds__(768, 3) pspan_kernel(const PsArgs a) {
                 const int n = min(16 * q + (lane >> 2), p.Cout - 1);  // (rows past Cout: their outputs are never stored)
                 const int cj = (lane & 3) ^ swz4(2 * q + (lane >> 5));
                 const unsigned voff = (unsigned)((n * p.ldw + cj * 8) * 2);
-                const char* sb = wg + ((long)a.t_rs[it] * p.Cin + ((long)ic * a.cps + a.t_c[it]) * 32) * 2;
+                const char* sb = wg + ((long)a.t_rs[it] * p.Cin + (long)ic * 32) * 2;
                 glds_s(voff, sb, f_base + (unsigned)(id * 1024));
                 if (++inflight == 24) {  // (the counter is 6 bits wide)
                     vmw<8>();
@@ -300,7 +298,7 @@ __global__ void __launch_bounds__(768, 3) pspan_kernel(const PsArgs a) {
             pl_off[q] = on ? (long)a.plane_off[q] : 0l;
             set_pieces += on ? (pl_np[q] - lj + 3) / 4 : 0;
         }
-        const int s2 = a.s2, wrap = a.wrap, maxoff48 = a.maxoff + 48, set_bytes = a.set_bytes, cps64 = a.cps * 64;
+        const int s2 = a.s2, wrap = a.wrap, maxoff48 = a.maxoff + 48, set_bytes = a.set_bytes;
         auto issue_set = [&](int gcs) {  // set gcs = (tile t0 + gcs / nchunks, chunk gcs % nchunks)
             const int tl = gcs / nchunks, ic = gcs - tl * nchunks;
             if (tl != off_tile) {  // (sets are issued in order: the next tile, if not the same one)
@@ -314,7 +312,7 @@ __global__ void __launch_bounds__(768, 3) pspan_kernel(const PsArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (q >= a.nplanes) break;
-                const void* sb = uniform_ptr(xg + (pl_off[q] + (long)ic * cps64));
+                const void* sb = uniform_ptr(xg + (pl_off[q] + (long)ic * 64));
                 const int np = pl_np[q], dq = pl_dq[q];
                 const bool back1 = s2 && (q == 0 || q == 2);
                 const unsigned lds0 = __builtin_amdgcn_readfirstlane(buf + (unsigned)pl_slot[q] + (unsigned)(lj * 1024));
@@ -354,9 +352,9 @@ __global__ void __launch_bounds__(768, 3) pspan_kernel(const PsArgs a) {
                     const int b = div_magic((int)m, ghw, ghw_magic, rem);
                     const int oi = div_magic(rem, gw, gw_magic, oj);
                     const int ih0 = oi * p.sh, iw0 = oj * p.sw;
-                    if (NT > 0 && p.ntaps == NT) {
+                    if constexpr (NT > 0) {
 #pragma unroll
-                        for (int T = 0; T < (NT > 0 ? NT : 1); ++T)  // bit = filter tap index (the taps of a launch are T = 0 .. NT-1)
+                        for (int T = 0; T < NT; ++T)  // bit = filter tap index (the taps of a launch are T = 0 .. NT-1)
                             if ((unsigned)(ih0 + th[T]) < (unsigned)p.Hi && (unsigned)(iw0 + tw[T]) < (unsigned)p.Wi) bits |= 1u << T;
                     } else {
                         for (int t = 0; t < p.ntaps; ++t) {
@@ -558,9 +556,7 @@ __global__ void __launch_bounds__(768, 3) pspan_kernel(const PsArgs a) {
                     pre(std::integral_constant<int, 1>{});
                     pre(std::integral_constant<int, 2>{});
                     auto steps = [&](auto... Ts) { (step(Ts), ...); };
-                    if constexpr (NT == 2)
-                        steps(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-                    else if constexpr (NT == 9)
+                    if constexpr (NT == 9)
                         steps(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{},
                               std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{},
                               std::integral_constant<int, 6>{}, std::integral_constant<int, 7>{}, std::integral_constant<int, 8>{});
@@ -709,10 +705,9 @@ int ps_launch(PsArgs& a, hipStream_t st, bool dry) {
     void (*kern)(const PsArgs) = nullptr;
 #define VT_PS_PICK(NTv)                                                                               \
     kern = mode == 1 ? pspan_kernel<BN, BM, 1, NTv> : (mode == 2 ? pspan_kernel<BN, BM, 2, NTv> : pspan_kernel<BN, BM, 0, NTv>)
-    static_assert(true, "NT is 9, 4, 2 or 0: the straight-line chunk lists its steps");
+    static_assert(true, "NT is 9 or 4 or 0: the straight-line chunk lists its steps");
     if (a.ntaps == 9) VT_PS_PICK(9);
     else if (a.ntaps == 4) VT_PS_PICK(4);
-    else if (a.ntaps == 2) VT_PS_PICK(2);
     else VT_PS_PICK(0);
 #undef VT_PS_PICK
     {
@@ -744,9 +739,7 @@ int ps_launch_bn(PsArgs& a, hipStream_t st) {
 // returns -1 when this kernel does not apply (the caller then tries the other conv kernels)
 int vt_pspan_dispatch(IgemmArgs& a0, int dtype, void* stream) {
     // VT_PSPAN: 0 off, 1 (default) the layers it measured faster on, 2 wherever it applies (tests)
-    const int knob = VT_KNOB("VT_PSPAN", 1);
-    const int enabled = knob & 3;
-    const bool one_by_one = (knob & 4) != 0;  // (measurement: +4 = the 1x1 launches with 64-128 input channels too)
+    const int enabled = VT_KNOB("VT_PSPAN", 1);
     if (!enabled || dtype != VT_BF16) return -1;
     if (vt_device_cus() != 256) return -1;  // (the grid and the tile ranges are built for 8 XCDs x 32 CUs)
     if (a0.flags & VT_CONV_NOSTORE) return -1;
@@ -761,7 +754,6 @@ int vt_pspan_dispatch(IgemmArgs& a0, int dtype, void* stream) {
     a.p = a0;
     a.nchunks = a0.Cin / 32;
     a.ntaps = a0.ntaps;
-    a.cps = 1;
     const int nsteps = a.nchunks * a.ntaps;
     const int bn = a0.Cout > 64 ? 128 : (a0.Cout > 32 ? 64 : 32);
     if (nsteps * bn * 64 > 96 * 1024) return -1;  // the resident filter (the span sets must still fit twice: ps_launch)
@@ -770,13 +762,11 @@ int vt_pspan_dispatch(IgemmArgs& a0, int dtype, void* stream) {
                     a0.Ho * 2 == a0.Hi && a0.Wo * 2 == a0.Wi && !d2s;
     if (!s1 && !s2) return -1;
     // enough tiles to keep every workgroup busy for a few of them (else the one-tile kernels, which spread better)
-    if (enabled < 2 && (long)a0.M < (one_by_one && a0.ntaps == 1 ? 256L * 256 * 2 : 256L * 256 * 4)) return -1;
+    if (enabled < 2 && (long)a0.M < 256L * 256 * 4) return -1;
     // (1x1: one K-step per channel chunk, i.e. a workgroup barrier per 2-16 MFMAs -- the pointwise kernels' territory)
-    if (enabled < 2 && a0.ntaps < 4 && !(one_by_one && a0.ntaps == 1 && a0.Cin >= 64 && a0.Cin <= 128)) return -1;
+    if (enabled < 2 && a0.ntaps < 4) return -1;
     hipStream_t st = (hipStream_t)stream;
     for (int bm = 256; bm >= 128; bm -= 128) {
-        a.nchunks = a0.Cin / 32, a.ntaps = a0.ntaps, a.cps = 1;
-        memset(a.t_c, 0, sizeof(a.t_c));
         if (s2) {
             for (int t = 0; t < 9; ++t)
                 if (a0.dh[t] != t / 3 || a0.dw[t] != t % 3) return -1;
@@ -798,18 +788,6 @@ int vt_pspan_dispatch(IgemmArgs& a0, int dtype, void* stream) {
                 const int q = ((r & 1) ? 2 : 0) + ((s_ & 1) ? 1 : 0);
                 const int d = (r == 0 ? -Wo : 0) + (s_ == 0 ? -1 : 0);
                 a.t_q[t] = (int8_t)q, a.t_rs[t] = (int8_t)(3 * r + s_), a.t_drow[t] = (short)(d - dmins[q]);
-            }
-        } else if (a0.ntaps == 1 && a0.h0 + a0.dh[0] == 0 && a0.w0 + a0.dw[0] == 0 && a0.Cin / 32 >= 2 && a0.Cin / 32 <= 4) {
-            // 1x1, 64-128 input channels: ONE set per tile holding all channel chunks as planes (plane q = chunk q: the
-            // same rows, 64 bytes further into the pixel), one step per chunk -- one barrier per tile instead of one per
-            // chunk, and with 2 or 4 chunks the steps are straight-line code
-            const int nc = a0.Cin / 32;
-            a.s2 = 0, a.nplanes = nc, a.dmin = 0, a.nchunks = 1, a.ntaps = nc, a.cps = nc;
-            for (int q = 0; q < nc; ++q) {
-                a.plane_np[q] = (bm + 15) / 16;
-                a.plane_off[q] = q * 64;
-                a.delta[q] = 0;
-                a.t_q[q] = (int8_t)q, a.t_rs[q] = 0, a.t_c[q] = (int8_t)q, a.t_drow[q] = 0;
             }
         } else {
             int dmin = 1 << 30, dmax = -(1 << 30);
