@@ -126,3 +126,41 @@ except Exception as ex:  # keep whatever was collected
 json.dump(summary, open(f"{out}/{tag}_dominant_kernel_pmc.json", "w"), indent=1)
 print(json.dumps(summary, indent=1))
 EOF
+
+# 5. (round 4) HBM bytes of the persistent span kernel on its layers: 32->32 3x3 @112x112 and 32->64 3x3 stride 2 @224x224
+for grp in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/${TAG}_pspan_pmc_$grp" -- \
+        python3 "$ROOT/tools/bench_conv.py" fwd 32,32,3,1,112 32,64,3,2,224 64,64,3,1,56 > "$OUT/${TAG}_pspan_pmc_$grp.log" 2>&1
+    echo "pspan pmc $grp exit $?"
+done
+python3 - "$OUT" "$TAG" <<'EOF3'
+import csv, glob, json, sys
+out, tag = sys.argv[1], sys.argv[2]
+LAY = [("conv3x3 s1 32->32 @112x112 B=256", 256 * 112 * 112 * (32 + 32) * 2 + 32 * 288 * 2),
+       ("conv3x3 s2 32->64 @224x224 B=256", 256 * (224 * 224 * 32 + 112 * 112 * 64) * 2 + 64 * 288 * 2),
+       ("conv3x3 s1 64->64 @56x56 B=256", 256 * 56 * 56 * (64 + 64) * 2 + 64 * 576 * 2)]
+res = []
+try:
+    vals = {}
+    for grp in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = glob.glob(f"{out}/{tag}_pspan_pmc_{grp}/*/*counter_collection.csv")[0]
+        rows = [r for r in csv.DictReader(open(f)) if "pspan_kernel" in r["Kernel_Name"] and r["Counter_Name"] == grp]
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        vals[grp] = [float(r["Counter_Value"]) for r in rows]
+    f = glob.glob(f"{out}/{tag}_pspan_pmc_FETCH_SIZE/*/*kernel_trace.csv")[0]
+    tr = [r for r in csv.DictReader(open(f)) if "pspan_kernel" in r["Kernel_Name"]]
+    tr.sort(key=lambda r: int(r["Start_Timestamp"]))
+    n = len(tr) // len(LAY)
+    for k, (name, alg) in enumerate(LAY):
+        sl = slice(k * n + 5, (k + 1) * n)
+        fe = sum(vals["FETCH_SIZE"][sl]) / max(1, len(vals["FETCH_SIZE"][sl]))
+        wr = sum(vals["WRITE_SIZE"][sl]) / max(1, len(vals["WRITE_SIZE"][sl]))
+        du = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr[sl]]
+        res.append({"layer": name, "kernel": tr[k * n]["Kernel_Name"][:80], "launches": len(du), "avg_duration_us_pmc_pass": sum(du) / len(du),
+                    "FETCH_SIZE_KB_raw": fe, "WRITE_SIZE_KB": wr, "hbm_traffic_bytes": fe * 2048 + wr * 1024,
+                    "algorithmic_bytes": alg, "traffic_over_algorithmic": (fe * 2048 + wr * 1024) / alg})
+except Exception as ex:
+    res.append({"error": repr(ex)})
+json.dump(res, open(f"{out}/{tag}_pspan_pmc.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
+EOF3
