@@ -197,6 +197,91 @@ def insitu_layer_times(ts, Cin, Cout, ntaps, HW, reps=4, which="fwd"):
     return sum(ms) / len(ms), len(ms), name
 
 
+def insitu_op_times(ts, which, match, reps=3):
+    """HIP-event time of the ops of the forward (`which` = "fwd") or backward list selected by `match(op)`, INSIDE the step's
+    own lists (as insitu_layer_times); returns (mean ms, launches timed)"""
+    from vision_toolbox import _native as N
+
+    p = ts.prog
+    ops, n = (p.fwd_ops, p.n_fwd) if which == "fwd" else (p.bwd_ops, p.n_bwd)
+    idxs = [i for i in range(n) if match(ops[i])]
+    if not idxs:
+        return None, 0
+    s = int(torch.cuda.current_stream().cuda_stream)
+    side = int(ts._side.cuda_stream) if ts._side is not None else 0
+    sz = ctypes.sizeof(N.Op)
+
+    def run(lst, lo, hi, use_side):
+        if hi > lo:
+            sub = (N.Op * (hi - lo)).from_address(ctypes.addressof(lst) + lo * sz)
+            N.run_ops(sub, hi - lo, ts.bases, s, side=side if use_side else 0)
+
+    pairs = []
+    for _ in range(reps):
+        N.run_ops(ts.zero_ops, 1, ts.bases, s)
+        if which != "fwd":
+            run(p.fwd_ops, 0, p.n_fwd, True)
+        lo = 0
+        for i in idxs:
+            run(ops, lo, i, which == "fwd")
+            e0, e1 = N.Event(), N.Event()
+            e0.record(s)
+            run(ops, i, i + 1, False)
+            e1.record(s)
+            pairs.append((e0, e1))
+            lo = i + 1
+        run(ops, lo, n, which == "fwd")
+    torch.cuda.synchronize()
+    ms = [a.elapsed_ms(b) for a, b in pairs]
+    return sum(ms) / len(ms), len(ms)
+
+
+def hbm_layers_insitu(ts, batch):
+    """the HBM-bound layers of stages 0-1 as the step runs them (HBM fraction on the 1x1 and early-stage convs),
+    IN SITU, against 8 TB/s: the short-K 3x3 convs on the persistent resident-filter span kernel (vt_igemm_pspan.hip) and
+    the passes of a pointwise 1x1 unit (vt_pointwise.hip; bytes = the operands of the pass, once)"""
+    from vision_toolbox import _native as N
+
+    def conv_match(Cin, Cout, ntaps, HW, stride):
+        def m(op):
+            if (op.kind & 0xFFFF) != N.OP_CONV_IGEMM:
+                return False
+            d = N.ConvDesc.from_buffer_copy(bytes(op.i)[: ctypes.sizeof(N.ConvDesc)])
+            return (d.Cin, d.Cout, d.ntaps, d.Hi, d.Wi, d.sh) == (Cin, Cout, ntaps, HW, HW, stride)
+        return m
+
+    def pw_match(kind, K, C0, C1, M):
+        def m(op):  # i: K, groups, relu, C0, C1, ldx, ...; f: M
+            return (op.kind & 0xFFFF) == kind and (op.i[0], op.i[3], op.i[4]) == (K, C0, C1) and int(op.f[0]) == M
+        return m
+
+    out = []
+    px = lambda hw: batch * hw * hw
+    rows = [
+        ("conv3x3 s1 32->32 @112x112 forward (statistics epilogue)", "fwd", conv_match(32, 32, 9, 112, 1), 2.0 * (px(112) * 64 + 32 * 288)),
+        ("conv3x3 s2 32->64 @224x224 forward (space-to-depth view)", "fwd", conv_match(32, 64, 9, 224, 2),
+         2.0 * (px(224) * 32 + px(112) * 64 + 64 * 288)),
+        ("data gradient of conv3x3 s2 32->64: 2x2 taps over dz 64 ch @112x112, depth-to-space store of 32 ch @224x224", "bwd",
+         conv_match(64, 128, 4, 112, 1), 2.0 * (px(112) * 64 + px(224) * 32 + 128 * 256)),
+        ("conv3x3 s1 64->64 @56x56 forward", "fwd", conv_match(64, 64, 9, 56, 1), 2.0 * (px(56) * 128 + 64 * 576)),
+        ("pointwise pair 64->32|32 @112x112, statistics pass (reads x)", "fwd", pw_match(N.OP_PW_STATS, 64, 32, 32, px(112)), 2.0 * px(112) * 64),
+        ("pointwise pair 64->32|32 @112x112, normalise pass (reads x, writes both outputs)", "fwd", pw_match(N.OP_PW_APPLY, 64, 32, 32, px(112)),
+         2.0 * px(112) * 128),
+        ("pointwise pair 64->32|32 @112x112, backward reduction (reads x, dy)", "bwd", pw_match(N.OP_PW_REDUCE, 64, 32, 32, px(112)),
+         2.0 * px(112) * 128),
+        ("pointwise pair 64->32|32 @112x112, backward apply (reads x, dy; writes dx; dW in registers)", "bwd",
+         pw_match(N.OP_PW_BWD, 64, 32, 32, px(112)), 2.0 * px(112) * 192),
+    ]
+    for name, which, match, nbytes in rows:
+        ms, n = insitu_op_times(ts, which, match)
+        if not ms:
+            continue
+        out.append({"layer": name + f" B={batch}", "ms": round(ms, 4), "gbs": round(nbytes / ms / 1e6, 1),
+                    "frac": round(nbytes / ms / 1e6 / PEAK_HBM_GBS, 4), "algorithmic_bytes": int(nbytes), "launches_timed": n,
+                    "measured": "in situ"})
+    return out
+
+
 def time_train_step(model, batch, image_size, steps, warmup, dev):
     """ms per fused train step of `model` at per-GPU batch `batch` on this GPU alone (data_parallel=False: the
     single-GPU program even when this process is a rank of a larger job)"""
@@ -586,9 +671,8 @@ def main():
         if world == 1 and not args.no_pmc:
             # (the rocprof rows are matched by the name the dispatcher reported for this layer, e.g. "span6_kernel")
             traffic = pmc_traffic_live("128,128,3,1,28", (standalone_name or dom["kernel"]).split("<")[0])
-        # HBM-bound layers of stages 0-2 (HBM fraction on the 1x1 and early-stage convs)
-        hbm_layers = [conv_roofline(args.batch, 64, 112, N.VT_BF16, k=1), conv_roofline(args.batch, 128, 56, N.VT_BF16, k=1),
-                      conv_roofline(args.batch, 8, 224, N.VT_BF16, k=3, Cout=32)]
+        # HBM-bound layers of stages 0-1 as the step runs them, in situ (HBM fraction on the early-stage convs)
+        hbm_layers = hbm_layers_insitu(ts, args.batch) if args.model == "cspdarknet53" and args.image_size == 224 else []
         cfg = ("BASELINE configs[1]" if (world == 1 and args.batch == 256) else
                f"BASELINE configs[2] (data parallel over RCCL, {args.batch} images per GPU, global batch {args.batch * world})"
                if world > 1 else f"single GPU, batch {args.batch}")
@@ -629,9 +713,7 @@ def main():
             "roofline_layers": layers,
             "ms_per_step_p10_p50_p90": [round(float(v), 3) for v in
                                         _percentiles([marks[i].elapsed_ms(marks[i + 1]) for i in range(args.steps)])],
-            "roofline_hbm_layers": [{"layer": l["shape"], "ms": round(l["ms"], 4), "gbs": round(l["gbs"], 1),
-                                     "frac": round(l["gbs"] / PEAK_HBM_GBS, 4), "algorithmic_bytes": int(l["bytes"])}
-                                    for l in hbm_layers],
+            "roofline_hbm_layers": hbm_layers,
             "train_step_tflops": round(28.0e9 * (args.batch / 1.0) * world / (ms * 1e-3) / 1e12, 1)
             if args.model == "cspdarknet53" and args.image_size == 224 else None,
         }
