@@ -267,6 +267,20 @@ int vt_pw_bwd_apply(const vt_pw_desc* d, const float* coef, const void* const* d
                     float* const* dw, const int32_t* lddw, void* const* dz, const int32_t* lddz, void* stream);
 
 /* ---- pooling ------------------------------------------------------------ */
+/* The normalise pass fused with the MaxPool2d(3, 2, 1) that reads its output (VoVNet: `stage.max_pool` on the previous
+ * stage's last ConvNormAct, vovnet.py:94 after components.py:36-44): writes y, the pooled map and the arg-max taps in one
+ * pass over z; and the unit's BatchNorm-backward passes reading the POOLED gradient through the arg-max taps instead of
+ * a materialised d(y) (only when the pool is y's sole consumer).  Same values as the separate calls. */
+int vt_bn_act_apply_pool(const void* z, int32_t ldz, const float* scale, const float* shift, const void* residual,
+                         int32_t ldr, void* y, int32_t ldy, void* pooled, int32_t ldp, uint8_t* argmax, int32_t B,
+                         int32_t H, int32_t W, int32_t C, int32_t relu, int32_t dtype, void* stream);
+int vt_bn_act_bwd_reduce_pool(const void* dp, int32_t lddp, const uint8_t* argmax, const void* z, int32_t ldz,
+                              const float* scale, const float* shift, const float* mean, const float* invstd, int32_t B,
+                              int32_t H, int32_t W, int32_t C, int32_t relu, int32_t dtype, float* sums, void* stream);
+int vt_bn_act_bwd_apply_pool(const void* dp, int32_t lddp, const uint8_t* argmax, const void* z, int32_t ldz,
+                             const float* scale, const float* shift, const float* coef, void* dz, int32_t lddz, int32_t B,
+                             int32_t H, int32_t W, int32_t C, int32_t relu, int32_t dtype, void* stream);
+
 /* nn.MaxPool2d(3, 2, 1) at the head of every VoVNet stage (vovnet.py:94). */
 int vt_maxpool3x3s2_fwd(const void* x, int32_t ldx, void* y, int32_t ldy, uint8_t* argmax,
                         int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype,

@@ -648,3 +648,67 @@ def test_filter_repack_batch_equals_the_single_launches():
     torch.cuda.synchronize()
     for (w, out2), out1 in zip(keep, ref):
         assert torch.equal(out1, out2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DNAME.get)
+@pytest.mark.parametrize("shape", [(2, 16, 12, 10), (3, 24, 7, 9), (1, 64, 56, 56), (2, 8, 2, 2), (2, 40, 15, 16)],
+                         ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("with_res", [False, True], ids=["plain", "residual"])
+def test_bn_apply_fused_with_the_max_pool_and_its_backward(dtype, shape, with_res):
+    """Round 4: vt_bn_act_apply_pool / vt_bn_act_bwd_reduce_pool / vt_bn_act_bwd_apply_pool (the normalise pass of the unit
+    whose output VoVNet's `stage.max_pool` reads, vovnet.py:94, fused with that pool; the unit's BatchNorm backward reading
+    the POOLED gradient through the arg-max taps) against the separate launches they replace -- vt_bn_act_apply +
+    vt_maxpool3x3s2_fwd, vt_maxpool3x3s2_bwd + vt_bn_act_bwd_reduce / _apply -- on the same operands: every tensor
+    output bit-equal (the same roundings at the same points), the channel sums to f32 summation order; channel-slice
+    operands, odd maps, a map smaller than a window."""
+    B, Cc, H, W = shape
+    L = N.lib()
+    epc = 8 if dtype == N.VT_BF16 else 4
+    if Cc % epc:
+        pytest.skip("channel count not a multiple of the 16-byte chunk")
+    z = nhwc(filler.tensor(f"fpz{shape}", shape), dtype, ld=Cc + 2 * epc, coff=epc)
+    res = nhwc(filler.tensor(f"fpr{shape}", shape), dtype) if with_res else None
+    scale = (filler.tensor(f"fps{shape}", (Cc,)).abs() + 0.5).cuda()
+    shift = (filler.tensor(f"fpf{shape}", (Cc,)) * 0.3).cuda()
+    mean = (filler.tensor(f"fpm{shape}", (Cc,)) * 0.1).cuda()
+    invstd = (filler.tensor(f"fpi{shape}", (Cc,)).abs() + 0.5).cuda()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    ldz = z.stride(2)
+
+    def fresh(h, w, c=Cc):
+        return torch.full((B, h, w, c + epc), float("nan"), device="cuda", dtype=TD[dtype])
+
+    # reference: separate launches
+    y0, p0 = fresh(H, W), fresh(Ho, Wo)
+    am0 = torch.zeros(B * Ho * Wo * Cc, dtype=torch.uint8, device="cuda")
+    N.check(L.vt_bn_act_apply(vp(z), ldz, vp(scale), vp(shift), vp(res), Cc, vp(y0), Cc + epc, B * H * W, Cc, 1, dtype, stream()))
+    N.check(L.vt_maxpool3x3s2_fwd(vp(y0), Cc + epc, vp(p0), Cc + epc, vp(am0), B, H, W, Cc, dtype, stream()))
+    # fused
+    y1, p1 = fresh(H, W), fresh(Ho, Wo)
+    am1 = torch.zeros_like(am0)
+    N.check(L.vt_bn_act_apply_pool(vp(z), ldz, vp(scale), vp(shift), vp(res), Cc, vp(y1), Cc + epc, vp(p1), Cc + epc, vp(am1), B, H, W,
+                                   Cc, 1, dtype, stream()))
+    torch.cuda.synchronize()
+    for a, b in ((y0, y1), (p0, p1)):
+        assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float()))
+    assert torch.equal(am0, am1)
+    # backward: the pooled gradient through the taps
+    dp = nhwc(filler.tensor(f"fpd{shape}", (B, Cc, Ho, Wo)), dtype)
+    dy = torch.zeros(B, H, W, Cc, device="cuda", dtype=TD[dtype])
+    N.check(L.vt_maxpool3x3s2_bwd(vp(dp), Cc, vp(am0), vp(dy), Cc, B, H, W, Cc, 0, dtype, stream()))
+    s0, s1 = N.stats_buffer(Cc), N.stats_buffer(Cc)
+    M = B * H * W
+    N.check(L.vt_bn_act_bwd_reduce(vp(dy), Cc, vp(z), ldz, vp(scale), vp(shift), vp(mean), vp(invstd), M, Cc, 1, dtype, vp(s0), stream()))
+    N.check(L.vt_bn_act_bwd_reduce_pool(vp(dp), Cc, vp(am1), vp(z), ldz, vp(scale), vp(shift), vp(mean), vp(invstd), B, H, W, Cc, 1,
+                                        dtype, vp(s1), stream()))
+    torch.cuda.synchronize()
+    # (per-thread f32 partial sums run over different row sets in the two kernels: equal to f32 summation noise)
+    d0, d1 = N.stats_decode(s0), N.stats_decode(s1)
+    assert torch.allclose(d0, d1, rtol=2e-5, atol=2e-5 * float(d0.abs().max()))
+    coef = (filler.tensor(f"fpc{shape}", (3 * Cc,)) * 0.5).cuda()
+    dz0, dz1 = fresh(H, W), fresh(H, W)
+    N.check(L.vt_bn_act_bwd_apply(vp(dy), Cc, vp(z), ldz, vp(scale), vp(shift), vp(coef), vp(dz0), Cc + epc, M, Cc, 1, dtype, stream()))
+    N.check(L.vt_bn_act_bwd_apply_pool(vp(dp), Cc, vp(am1), vp(z), ldz, vp(scale), vp(shift), vp(coef), vp(dz1), Cc + epc, B, H, W, Cc,
+                                       1, dtype, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(torch.isnan(dz0), torch.isnan(dz1)) and torch.equal(torch.nan_to_num(dz0.float()), torch.nan_to_num(dz1.float()))

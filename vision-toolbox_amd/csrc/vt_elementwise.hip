@@ -199,6 +199,226 @@ bn_act_apply_kernel(const T* __restrict__ z, int ldz, const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------
+// BatchNorm apply fused with the MaxPool2d(3, 2, 1) that reads its output (VoVNet: every stage opens with the pool of
+// the previous stage's last unit, reference backbones/vovnet.py:94), round 4.
+//   forward:  one thread per pooled pixel and 16-byte channel chunk normalises the nine pre-activations of its window
+//             (clamped loads, the rounding of the unfused path), writes the pooled maximum + arg-max tap AND the unit's
+//             output y for the four pixels (2ho, 2wo) .. (2ho+1, 2wo+1) it owns -- every pixel has exactly one owner.
+//             The separate pool pass (read y: 822 MB behind VoVNet-39's stem at batch 256) disappears.
+//   backward: the unit's gradient dy is never formed: the BatchNorm-backward reduce / apply passes gather it from the
+//             pooled gradient and the arg-max taps (at most four windows contain a pixel) -- a quarter of the bytes, and
+//             the pool's backward pass (write dy) disappears.  Only when nothing else contributes to dy.
+// ---------------------------------------------------------------------------------
+// BatchNorm backward of such a unit from the POOLED gradient.  One thread per pooled position (ho, wo) and 16-byte
+// channel chunk handles the four pixels (2ho + a, 2wo + b) it owns: the windows that contain them are (ho + da, wo + db),
+// da <= a, db <= b -- four pooled gradients + arg-max words serve four pixels (a per-pixel gather loads four per pixel and
+// measured SLOWER than the separate pool backward: bn_bwd_reduce 1.69 -> 2.19 ms, bn_bwd_apply 2.43 -> 3.09 ms on
+// VoVNet-39).  d(y) of a pixel = sum of the windows whose arg-max tap it is, rounded where the unfused pool backward
+// stores it.  APPLY: dz = a*g - b*z + d; else the reduction sum g, sum g*(z - mean) (folded as in bn_bwd_reduce_kernel).
+template <typename T, bool APPLY>
+__global__ void __launch_bounds__(kThreads)
+bn_bwd_pool_kernel(const T* __restrict__ dp, int lddp, const uint8_t* __restrict__ amax, const T* __restrict__ z, int ldz,
+                   const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ c2,
+                   const float* __restrict__ invstd, T* __restrict__ dz, int lddz, int H, int W, int Ho, int Wo, int C, long Mo,
+                   RowMap rm, int relu, float* __restrict__ sums) {
+    constexpr int EPC = VecIO<T>::EPC;
+    extern __shared__ __attribute__((aligned(16))) float sred[];
+    const int t = threadIdx.x;
+    const int r = t / rm.CT;
+    const int tc = t % rm.CT;
+    const int Wc = rm.CT * EPC;
+    const long row0 = (long)blockIdx.x * rm.RT * rm.iters + r;
+    const int rep = blockIdx.x % kStatReplicas;
+    for (int cbase = 0; cbase < rm.CPR; cbase += rm.CT) {
+        const int col = cbase + tc;
+        const bool active = (r < rm.RT) && (col < rm.CPR);
+        float s1[EPC], s2[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
+        if (active) {
+            float sc[EPC], sf[EPC], ca[EPC], cb[EPC], cd[EPC];  // REDUCE: cb = mean
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const int c = col * EPC + e;
+                sc[e] = scale[c], sf[e] = shift[c];
+                if (APPLY) ca[e] = c2[c], cb[e] = c2[C + c], cd[e] = c2[2 * C + c];
+                else ca[e] = 0.f, cb[e] = c2[c], cd[e] = 0.f;
+            }
+            for (int it = 0; it < rm.iters; ++it) {
+                const long row = row0 + (long)it * rm.RT;
+                if (row >= Mo) break;
+                const int wo = (int)(row % Wo);
+                const long t2 = row / Wo;
+                const int ho = (int)(t2 % Ho);
+                const long b = t2 / Ho;
+                // the four windows (clamped coordinates: every load unconditional) and the four owned pixels
+                uint4 gw[4], vz[4];
+                unsigned aw[4][EPC / 4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const long orow = (b * Ho + min(ho + (k >> 1), Ho - 1)) * Wo + min(wo + (k & 1), Wo - 1);
+                    gw[k] = ld16(dp + orow * lddp + col * EPC);
+                    const unsigned* ap = (const unsigned*)(amax + orow * C + col * EPC);
+#pragma unroll
+                    for (int q = 0; q < EPC / 4; ++q) aw[k][q] = ap[q];
+                    const long pix = (b * H + min(2 * ho + (k >> 1), H - 1)) * W + min(2 * wo + (k & 1), W - 1);
+                    vz[k] = ld16(z + pix * ldz + col * EPC);
+                }
+                float gf[4][EPC];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) VecIO<T>::unpack(gw[k], gf[k]);
+#pragma unroll
+                for (int pk = 0; pk < 4; ++pk) {  // pixel (a, b) = (pk >> 1, pk & 1)
+                    const int a = pk >> 1, bb = pk & 1;
+                    const int h = 2 * ho + a, w = 2 * wo + bb;
+                    if (h >= H || w >= W) continue;
+                    float acc[EPC];
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {  // window (ho + da, wo + db)
+                        const int da = k >> 1, db = k & 1;
+                        if (da > a || db > bb) continue;
+                        if (ho + da >= Ho || wo + db >= Wo) continue;
+                        const unsigned tap = (unsigned)((a - 2 * da + 1) * 3 + (bb - 2 * db + 1));
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e)
+                            if (((aw[k][e >> 2] >> (8 * (e & 3))) & 0xffu) == tap) acc[e] += gf[k][e];
+                    }
+                    float g[EPC], zz[EPC];
+                    VecIO<T>::unpack(VecIO<T>::pack(acc), g);  // (the rounding of the stored d(y))
+                    VecIO<T>::unpack(vz[pk], zz);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const float gg = (!relu || fmaf(zz[e], sc[e], sf[e]) > 0.f) ? g[e] : 0.f;
+                        if (APPLY) {
+                            g[e] = fmaf(ca[e], gg, fmaf(-cb[e], zz[e], cd[e]));
+                        } else {
+                            s1[e] += gg;
+                            s2[e] = fmaf(gg, zz[e] - cb[e], s2[e]);
+                        }
+                    }
+                    if (APPLY) st16(dz + ((b * H + h) * W + w) * lddz + col * EPC, VecIO<T>::pack(g));
+                }
+            }
+        }
+        if constexpr (!APPLY) {
+            // fold of the row lanes: as bn_bwd_reduce_kernel (in-wave shuffles where CT is a power of two below 64)
+            const bool inwave = rm.CT < 64 && (rm.CT & (rm.CT - 1)) == 0;
+            int rows_l = rm.RT, r_l = r;
+            if (inwave) {
+                for (int off = rm.CT; off < 64; off <<= 1) {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        s1[e] += __shfl_xor(s1[e], off, 64);
+                        s2[e] += __shfl_xor(s2[e], off, 64);
+                    }
+                }
+                rows_l = kThreads / 64;
+                r_l = (t & 63) < rm.CT ? (t >> 6) : -1;
+            } else if (r >= rm.RT) {
+                r_l = -1;
+            }
+            if (r_l >= 0) {
+                float4* d1 = (float4*)(sred + ((long)(r_l * 2 + 0) * Wc + tc * EPC));
+                float4* d2 = (float4*)(sred + ((long)(r_l * 2 + 1) * Wc + tc * EPC));
+#pragma unroll
+                for (int q = 0; q < EPC / 4; ++q) {
+                    d1[q] = make_float4(s1[4 * q], s1[4 * q + 1], s1[4 * q + 2], s1[4 * q + 3]);
+                    d2[q] = make_float4(s2[4 * q], s2[4 * q + 1], s2[4 * q + 2], s2[4 * q + 3]);
+                }
+            }
+            __syncthreads();
+            for (int i = t; i < 2 * Wc; i += kThreads) {
+                const int which = i / Wc, lc = i % Wc;
+                const int c = cbase * EPC + lc;
+                if (c < C) {
+                    float acc = 0.f;
+                    for (int rr = 0; rr < rows_l; ++rr) acc += sred[(long)(rr * 2 + which) * Wc + lc];
+                    if (which) acc *= invstd[c];
+                    vt_stat_add(sums, ((long)rep * 2 + which) * C + c, acc);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <typename T, bool kRes>
+__global__ void __launch_bounds__(kThreads)
+bn_act_apply_pool_kernel(const T* __restrict__ z, int ldz, const float* __restrict__ scale, const float* __restrict__ shift,
+                         const T* __restrict__ res, int ldr, T* __restrict__ y, int ldy, T* __restrict__ pooled, int ldp,
+                         uint8_t* __restrict__ amax, int H, int W, int Ho, int Wo, int C, long Mo, RowMap rm, int relu) {
+    constexpr int EPC = VecIO<T>::EPC;
+    const int t = threadIdx.x;
+    const int r = t / rm.CT;
+    if (r >= rm.RT) return;
+    const long row0 = (long)blockIdx.x * rm.RT * rm.iters + r;
+    for (int col = t % rm.CT; col < rm.CPR; col += rm.CT) {
+        float sc[EPC], sf[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) sc[e] = scale[col * EPC + e], sf[e] = shift[col * EPC + e];
+        for (int it = 0; it < rm.iters; ++it) {
+            const long row = row0 + (long)it * rm.RT;
+            if (row >= Mo) break;
+            const int wo = (int)(row % Wo);
+            const long t2 = row / Wo;
+            const int ho = (int)(t2 % Ho);
+            const long b = t2 / Ho;
+            uint4 rz[9], rr[kRes ? 9 : 1];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int h = min(max(ho * 2 - 1 + k / 3, 0), H - 1), w = min(max(wo * 2 - 1 + k % 3, 0), W - 1);
+                const long pix = (b * H + h) * W + w;
+                rz[k] = ld16(z + pix * ldz + col * EPC);
+                if (kRes) rr[k] = ld16(res + pix * ldr + col * EPC);
+            }
+            float best[EPC];
+            int bi[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) best[e] = -INFINITY, bi[e] = 0;
+            bool first = true;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int h = ho * 2 - 1 + k / 3, w = wo * 2 - 1 + k % 3;
+                if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+                    float v[EPC];
+                    VecIO<T>::unpack(rz[k], v);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        v[e] = fmaf(v[e], sc[e], sf[e]);
+                        v[e] = relu ? fmaxf(v[e], 0.f) : v[e];
+                    }
+                    if (kRes) {
+                        float q[EPC];
+                        VecIO<T>::unpack(rr[kRes ? k : 0], q);
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) v[e] += q[e];
+                    }
+                    const uint4 yv = VecIO<T>::pack(v);  // what the unfused normalise pass stores ...
+                    if (k / 3 >= 1 && k % 3 >= 1) st16(y + ((b * H + h) * W + w) * ldy + col * EPC, yv);  // (an owned pixel)
+                    VecIO<T>::unpack(yv, v);             // ... and the pool reads
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        // ATen: first max in (kh, kw) scan order wins; NaN propagates
+                        if (first || v[e] > best[e] || v[e] != v[e]) {
+                            best[e] = v[e];
+                            bi[e] = k;
+                        }
+                    }
+                    first = false;
+                }
+            }
+            st16(pooled + row * ldp + col * EPC, VecIO<T>::pack(best));
+            unsigned* ap = (unsigned*)(amax + row * C + col * EPC);
+#pragma unroll
+            for (int q = 0; q < EPC / 4; ++q)
+                ap[q] = (unsigned)bi[4 * q] | ((unsigned)bi[4 * q + 1] << 8) | ((unsigned)bi[4 * q + 2] << 16) | ((unsigned)bi[4 * q + 3] << 24);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // BN backward, pass 1: per-channel sum(g) and sum(g*xhat), g = dy * [z*scale+shift > 0]
 // ---------------------------------------------------------------------------------
 template <typename T>
@@ -1232,6 +1452,72 @@ int vt_bn_act_bwd_apply(const void* dy, int32_t lddy, const void* z, int32_t ldz
 }
 
 static inline int pool_out(int n) { return (n + 2 - 3) / 2 + 1; }
+
+int vt_bn_act_apply_pool(const void* z, int32_t ldz, const float* scale, const float* shift, const void* residual,
+                         int32_t ldr, void* y, int32_t ldy, void* pooled, int32_t ldp, uint8_t* argmax, int32_t B,
+                         int32_t H, int32_t W, int32_t C, int32_t relu, int32_t dtype, void* stream) {
+    VT_REQUIRE(B > 0 && H > 0 && W > 0 && argmax && scale && shift, VT_ERR_INVALID, "vt_bn_act_apply_pool: bad argument");
+    VT_TRY(check_mat("vt_bn_act_apply_pool(z)", z, ldz, C, dtype));
+    VT_TRY(check_mat("vt_bn_act_apply_pool(y)", y, ldy, C, dtype));
+    VT_TRY(check_mat("vt_bn_act_apply_pool(pooled)", pooled, ldp, C, dtype));
+    if (residual) VT_TRY(check_mat("vt_bn_act_apply_pool(residual)", residual, ldr, C, dtype));
+    const int Ho = pool_out(H), Wo = pool_out(W);
+    const long Mo = (long)B * Ho * Wo;
+    RowMap rm = RowMap::make(C, vt_epc(dtype), Mo);
+    if (residual) {
+        VT_DISPATCH_T(dtype, "vt_bn_act_apply_pool",
+                      hipLaunchKernelGGL((bn_act_apply_pool_kernel<T, true>), dim3(rm.blocks(Mo)), dim3(kThreads), 0,
+                                         (hipStream_t)stream, (const T*)z, ldz, scale, shift, (const T*)residual, ldr, (T*)y,
+                                         ldy, (T*)pooled, ldp, argmax, H, W, Ho, Wo, C, Mo, rm, relu));
+    } else {
+        VT_DISPATCH_T(dtype, "vt_bn_act_apply_pool",
+                      hipLaunchKernelGGL((bn_act_apply_pool_kernel<T, false>), dim3(rm.blocks(Mo)), dim3(kThreads), 0,
+                                         (hipStream_t)stream, (const T*)z, ldz, scale, shift, (const T*)residual, ldr, (T*)y,
+                                         ldy, (T*)pooled, ldp, argmax, H, W, Ho, Wo, C, Mo, rm, relu));
+    }
+    VT_CHECK_LAUNCH("vt_bn_act_apply_pool");
+    return VT_OK;
+}
+
+int vt_bn_act_bwd_reduce_pool(const void* dp, int32_t lddp, const uint8_t* argmax, const void* z, int32_t ldz,
+                              const float* scale, const float* shift, const float* mean, const float* invstd, int32_t B,
+                              int32_t H, int32_t W, int32_t C, int32_t relu, int32_t dtype, float* sums, void* stream) {
+    VT_REQUIRE(B > 0 && H > 0 && W > 0 && argmax && scale && shift && mean && invstd && sums, VT_ERR_INVALID,
+               "vt_bn_act_bwd_reduce_pool: bad argument");
+    VT_TRY(check_mat("vt_bn_act_bwd_reduce_pool(dp)", dp, lddp, C, dtype));
+    VT_TRY(check_mat("vt_bn_act_bwd_reduce_pool(z)", z, ldz, C, dtype));
+    const int Ho = pool_out(H), Wo = pool_out(W);
+    const long Mo = (long)B * Ho * Wo;
+    const int epc = vt_epc(dtype);
+    RowMap rm = RowMap::make(C, epc, Mo, 256);
+    const bool inwave = rm.CT < 64 && (rm.CT & (rm.CT - 1)) == 0;  // (as in the kernel)
+    const int smem = (inwave ? kThreads / 64 : rm.RT) * 2 * rm.CT * epc * (int)sizeof(float);
+    VT_DISPATCH_T(dtype, "vt_bn_act_bwd_reduce_pool",
+                  hipLaunchKernelGGL((bn_bwd_pool_kernel<T, false>), dim3(rm.blocks(Mo)), dim3(kThreads), smem,
+                                     (hipStream_t)stream, (const T*)dp, lddp, argmax, (const T*)z, ldz, scale, shift, mean, invstd,
+                                     (T*)nullptr, 0, H, W, Ho, Wo, C, Mo, rm, relu, sums));
+    VT_CHECK_LAUNCH("vt_bn_act_bwd_reduce_pool");
+    return VT_OK;
+}
+
+int vt_bn_act_bwd_apply_pool(const void* dp, int32_t lddp, const uint8_t* argmax, const void* z, int32_t ldz,
+                             const float* scale, const float* shift, const float* coef, void* dz, int32_t lddz, int32_t B,
+                             int32_t H, int32_t W, int32_t C, int32_t relu, int32_t dtype, void* stream) {
+    VT_REQUIRE(B > 0 && H > 0 && W > 0 && argmax && scale && shift && coef, VT_ERR_INVALID,
+               "vt_bn_act_bwd_apply_pool: bad argument");
+    VT_TRY(check_mat("vt_bn_act_bwd_apply_pool(dp)", dp, lddp, C, dtype));
+    VT_TRY(check_mat("vt_bn_act_bwd_apply_pool(z)", z, ldz, C, dtype));
+    VT_TRY(check_mat("vt_bn_act_bwd_apply_pool(dz)", dz, lddz, C, dtype));
+    const int Ho = pool_out(H), Wo = pool_out(W);
+    const long Mo = (long)B * Ho * Wo;
+    RowMap rm = RowMap::make(C, vt_epc(dtype), Mo);
+    VT_DISPATCH_T(dtype, "vt_bn_act_bwd_apply_pool",
+                  VT_LAUNCH_STOP((bn_bwd_pool_kernel<T, true>), dim3(rm.blocks(Mo)), dim3(kThreads), 0, (hipStream_t)stream,
+                                 (const T*)dp, lddp, argmax, (const T*)z, ldz, scale, shift, coef, (const float*)nullptr, (T*)dz,
+                                 lddz, H, W, Ho, Wo, C, Mo, rm, relu, (float*)nullptr));
+    VT_CHECK_LAUNCH("vt_bn_act_bwd_apply_pool");
+    return VT_OK;
+}
 
 int vt_maxpool3x3s2_fwd(const void* x, int32_t ldx, void* y, int32_t ldy, uint8_t* argmax, int32_t B,
                         int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {

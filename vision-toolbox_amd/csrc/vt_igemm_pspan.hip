@@ -691,10 +691,12 @@ int ps_launch(PsArgs& a, hipStream_t st, bool dry) {
     const int cap = (4);
     a.nbuf = a.nbuf > cap ? cap : a.nbuf;
     if ((a.nbuf - 2) * ((a.set_bytes / 1024 + 3) / 4 + a.nplanes) > 30) a.nbuf = 2 + 30 / ((a.set_bytes / 1024 + 3) / 4 + a.nplanes);
-    a.off_zero = a.off_sets + a.nbuf * a.set_bytes;
 #ifdef VT_PSPAN_DIAG
     a.debug = VT_KNOB("VT_PSPAN_ABL", 0);
+    if ((a.debug & 32) && a.nbuf > 2) a.nbuf = 2;  // (measurement: span sets in flight)
+    if ((a.debug & 64) && a.nbuf > 3) a.nbuf = 3;
 #endif
+    a.off_zero = a.off_sets + a.nbuf * a.set_bytes;
     const int smem = a.off_zero + 64;
     if (a.nbuf * a.set_bytes < 8 * 2 * BN * 4) return -1;  // (the statistics fold reuses the span area)
     a.tiles_m = (p.M + BM - 1) / BM;

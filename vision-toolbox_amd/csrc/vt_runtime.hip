@@ -151,17 +151,27 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
             return vt_bn_eval_coeffs((const float*)P[0], (const float*)P[1], (const float*)P[2],
                                      (const float*)P[3], (float)F[0], I[0], (float*)P[4], (float*)P[5],
                                      (float*)P[6], (float*)P[7], st);
-        case VT_OP_BN_ACT_APPLY:  // ptr: z scale shift residual y | i: ldz ldr ldy C relu dtype | f: M
+        case VT_OP_BN_ACT_APPLY:  // ptr: z scale shift residual y [pooled argmax] | i: ldz ldr ldy C relu dtype [ldp B H W] | f: M
+            if (P[5])  // fused with the max-pool that reads y
+                return vt_bn_act_apply_pool(P[0], I[0], (const float*)P[1], (const float*)P[2], P[3], I[1], P[4], I[2], P[5], I[6],
+                                            (uint8_t*)P[6], I[7], I[8], I[9], I[3], I[4], I[5], st);
             return vt_bn_act_apply(P[0], I[0], (const float*)P[1], (const float*)P[2], P[3], I[1], P[4], I[2],
                                    (int64_t)F[0], I[3], I[4], I[5], st);
-        case VT_OP_BN_BWD_REDUCE:  // ptr: dy z scale shift mean invstd sums | i: lddy ldz C relu dtype | f: M
+        case VT_OP_BN_BWD_REDUCE:  // ptr: dy z scale shift mean invstd sums [argmax] | i: lddy ldz C relu dtype [B H W] | f: M
+            if (P[7])  // dy = the gradient of the POOLED output, gathered through the arg-max taps
+                return vt_bn_act_bwd_reduce_pool(P[0], I[0], (const uint8_t*)P[7], P[1], I[1], (const float*)P[2], (const float*)P[3],
+                                                 (const float*)P[4], (const float*)P[5], I[5], I[6], I[7], I[2], I[3], I[4],
+                                                 (float*)P[6], st);
             return vt_bn_act_bwd_reduce(P[0], I[0], P[1], I[1], (const float*)P[2], (const float*)P[3],
                                         (const float*)P[4], (const float*)P[5], (int64_t)F[0], I[2], I[3],
                                         I[4], (float*)P[6], st);
         case VT_OP_BN_BWD_FINALIZE:  // ptr: sums scale mean invstd dgamma dbeta coef | i: C train | f: count pscale(0 = 1)
             return vt_bn_bwd_finalize((const float*)P[0], I[0], F[0], F[1] == 0.0 ? 1.0 : F[1], (const float*)P[1], (const float*)P[2],
                                       (const float*)P[3], I[1], (float*)P[4], (float*)P[5], (float*)P[6], st);
-        case VT_OP_BN_BWD_APPLY:  // ptr: dy z scale shift coef dz | i: lddy ldz lddz C relu dtype | f: M
+        case VT_OP_BN_BWD_APPLY:  // ptr: dy z scale shift coef dz [argmax] | i: lddy ldz lddz C relu dtype [B H W] | f: M
+            if (P[6])
+                return vt_bn_act_bwd_apply_pool(P[0], I[0], (const uint8_t*)P[6], P[1], I[1], (const float*)P[2], (const float*)P[3],
+                                                (const float*)P[4], P[5], I[2], I[6], I[7], I[8], I[3], I[4], I[5], st);
             return vt_bn_act_bwd_apply(P[0], I[0], P[1], I[1], (const float*)P[2], (const float*)P[3],
                                        (const float*)P[4], P[5], I[2], (int64_t)F[0], I[3], I[4], I[5], st);
         case VT_OP_STEM_BWD_REDUCE:  // ptr: x dy z scale shift mean invstd sums gzx | i: dtype B H W C lddy ldz relu fixed

@@ -225,6 +225,12 @@ SYMBOLS = {
     "vt_pw_bwd_reduce": (_i32, [C.POINTER(PwDesc), _vp, C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_vp), _vp]),
     "vt_pw_bwd_apply": (_i32, [C.POINTER(PwDesc), _vp, C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_vp), _vp, _i32, _vp, _i32,
                                C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_vp), C.POINTER(_i32), _vp]),
+    "vt_bn_act_apply_pool": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
+                                    _vp]),
+    "vt_bn_act_bwd_reduce_pool": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp,
+                                         _vp]),
+    "vt_bn_act_bwd_apply_pool": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                        _vp]),
     "vt_maxpool3x3s2_fwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vt_maxpool3x3s2_bwd": (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vt_global_avgpool_fwd": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -65,8 +65,9 @@ class OSABlock(HipModule):
     def _vt_alloc_concat(self, b, B, H, W, name: str):
         return b.act(B, H, W, self.out_conv.conv.in_channels, name + ".cat")
 
-    def _vt_emit_from_concat(self, b, joined, out=None, name: str = "osa"):
-        """`joined[:, :in]` already holds the block input; fill the rest and aggregate."""
+    def _vt_emit_from_concat(self, b, joined, out=None, name: str = "osa", pool_out=None):
+        """`joined[:, :in]` already holds the block input; fill the rest and aggregate.  `pool_out`: the next stage's
+        max-pool of this block's output goes there (fused into out_conv's normalise pass: ConvNormAct._vt_emit)."""
         cin = self._in_channels
         x = joined.sl(0, cin)
         prev, off = x, cin
@@ -76,9 +77,12 @@ class OSABlock(HipModule):
             off += mid
         shortcut = x if self.residual else None
         if self.ese is None:
-            return self.out_conv._vt_emit(b, joined, out=out, residual=shortcut, name=name + ".out_conv")
+            return self.out_conv._vt_emit(b, joined, out=out, residual=shortcut, name=name + ".out_conv", pool_out=pool_out)
         t = self.out_conv._vt_emit(b, joined, name=name + ".out_conv")
-        return self.ese._vt_emit(b, t, out=out, residual=shortcut, name=name + ".ese")
+        y = self.ese._vt_emit(b, t, out=out, residual=shortcut, name=name + ".ese")
+        if pool_out is not None:
+            b.maxpool3x3s2(y, out=pool_out, name=name + ".max_pool")
+        return y
 
     def _vt_emit(self, b, x, out=None, name: str = "osa"):
         joined = self._vt_alloc_concat(b, x.B, x.H, x.W, name)
@@ -137,24 +141,40 @@ class VoVNet(BaseBackbone):
             self.stages.append(stage)
 
     def _vt_emit_maps(self, b, x):
+        stage_blocks = [[m for m in stage.children() if isinstance(m, OSABlock)] for stage in self.stages]
+
+        def pooled_concat(src_B, src_H, src_W, si):
+            """the aggregation buffer of stage si's first block, whose first slice the stage's max-pool fills"""
+            return stage_blocks[si][0]._vt_alloc_concat(b, src_B, _pooled(src_H), _pooled(src_W), f"stages.{si}.module_0")
+
         o = x
-        for i, unit in enumerate(self.stem):
+        stem = list(self.stem)
+        for i, unit in enumerate(stem[:-1]):
             o = unit._vt_emit(b, o, name=f"stem.{i}")
+        # every stage opens with MaxPool2d(3, 2, 1) of the previous stage's output (ref :94): it is written by the unit
+        # that produces that output -- the last stem unit, then each stage's last block -- straight into the first slice
+        # of the next aggregation buffer
+        last = stem[-1]
+        s_ = last.conv.stride[0]
+        Ho0 = (o.H + 2 * last.conv.padding[0] - last.conv.kernel_size[0]) // s_ + 1
+        Wo0 = (o.W + 2 * last.conv.padding[0] - last.conv.kernel_size[0]) // s_ + 1
+        joined = pooled_concat(o.B, Ho0, Wo0, 0) if stage_blocks else None
+        o = last._vt_emit(b, o, name=f"stem.{len(stem) - 1}",
+                          pool_out=joined.sl(0, last.conv.out_channels) if joined is not None else None)
         maps = [o]
-        for si, stage in enumerate(self.stages):
-            blocks = [m for m in stage.children() if isinstance(m, OSABlock)]
-            src = maps[-1]
-            H, W = _pooled(src.H), _pooled(src.W)
-            joined = blocks[0]._vt_alloc_concat(b, src.B, H, W, f"stages.{si}.module_0")
-            b.maxpool3x3s2(src, out=joined.sl(0, src.C), name=f"stages.{si}.max_pool")
-            o = None
+        for si, blocks in enumerate(stage_blocks):
+            H, W = joined.H, joined.W
             for bi, blk in enumerate(blocks):
-                nxt = None
+                nxt, pool_next, joined_next_stage = None, None, None
+                out_ch = blk.out_conv.conv.out_channels
                 if bi + 1 < len(blocks):
-                    nxt = blocks[bi + 1]._vt_alloc_concat(b, src.B, H, W, f"stages.{si}.module_{bi + 1}")
-                out = nxt.sl(0, blk.out_conv.conv.out_channels) if nxt is not None else None
-                o = blk._vt_emit_from_concat(b, joined, out=out, name=f"stages.{si}.module_{bi}")
-                joined = nxt
+                    nxt = blocks[bi + 1]._vt_alloc_concat(b, joined.B, H, W, f"stages.{si}.module_{bi + 1}")
+                elif si + 1 < len(stage_blocks):
+                    joined_next_stage = pooled_concat(joined.B, H, W, si + 1)
+                    pool_next = joined_next_stage.sl(0, out_ch)
+                out = nxt.sl(0, out_ch) if nxt is not None else None
+                o = blk._vt_emit_from_concat(b, joined, out=out, name=f"stages.{si}.module_{bi}", pool_out=pool_next)
+                joined = nxt if nxt is not None else joined_next_stage
             maps.append(o)
         return maps
 

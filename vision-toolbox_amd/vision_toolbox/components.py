@@ -115,9 +115,11 @@ class ConvNormAct(nn.Sequential, HipModule):
             "default ReLU (and 'none'); other activations are outside the Darknet/VoVNet path"
         )
 
-    def _vt_emit(self, b, x, out=None, residual=None, name: str = "cna"):
+    def _vt_emit(self, b, x, out=None, residual=None, name: str = "cna", pool_out=None):
+        """`pool_out`: also write MaxPool2d(3, 2, 1) of the unit's output there (VoVNet's `stage.max_pool`, vovnet.py:94):
+        fused into the unit's normalise pass where one exists, else a pool launch"""
         norm = self.norm if isinstance(self.norm, nn.BatchNorm2d) else None
-        return b.conv_unit(x, self.conv, norm, self._vt_relu(), residual=residual, out=out, name=name)
+        return b.conv_unit(x, self.conv, norm, self._vt_relu(), residual=residual, out=out, name=name, pool_out=pool_out)
 
     def _vt_emit_maps(self, b, x):
         return [self._vt_emit(b, x)]

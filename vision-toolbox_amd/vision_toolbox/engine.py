@@ -504,8 +504,11 @@ class Builder:
         return d
 
     def conv_unit(self, x: TRef, conv: nn.Conv2d, norm: Optional[nn.Module], relu: bool,
-                  residual: Optional[TRef] = None, out: Optional[TRef] = None, name: str = "") -> TRef:
-        """y = [relu]([bn](conv(x))) [+ residual], written to `out` when given."""
+                  residual: Optional[TRef] = None, out: Optional[TRef] = None, name: str = "",
+                  pool_out: Optional[TRef] = None) -> TRef:
+        """y = [relu]([bn](conv(x))) [+ residual], written to `out` when given.  `pool_out`: MaxPool2d(3, 2, 1) of y goes
+        there as well -- from the unit's own normalise pass where it has one (vt_bn_act_apply_pool), and then the unit's
+        BatchNorm backward reads the pooled gradient through the arg-max taps instead of a materialised d(y)."""
         self.tag += 1
         self.n_units += 1
         dt, epc = self.dtype, _EPC[self.dtype]
@@ -540,7 +543,10 @@ class Builder:
             if self._pw_ok(x, [spec]):
                 self.tag -= 1  # (pw_units takes its own tag)
                 self.n_units -= 1
-                return self.pw_units(x, [spec])[0]
+                y_pw = self.pw_units(x, [spec])[0]
+                if pool_out is not None:
+                    self.maxpool3x3s2(y_pw, out=pool_out, name=name + ".max_pool")
+                return y_pw
 
         # ---- filter operand ---------------------------------------------------------
         w = conv.weight
@@ -612,9 +618,18 @@ class Builder:
                 d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, z.ld, ldw, 0)
                 self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, z.addr(), None, None, None, None], desc=d)
                 self.emit(N.OP_BN_EVAL_COEFFS, [g, b_, rm, rv, *cp], [Cout], [norm.eps])
-            self.emit(N.OP_BN_ACT_APPLY,
-                      [z.addr(), cp[0], cp[1], residual.addr() if residual else None, y.addr()],
-                      [z.ld, residual.ld if residual else 0, y.ld, Cout, int(relu), dt], [M])
+            pool_am = None
+            if pool_out is not None:
+                assert (pool_out.B, pool_out.H, pool_out.W, pool_out.C) == (B, (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1, Cout)
+                pool_am = self.alloc(B * pool_out.H * pool_out.W * Cout, "argmax")
+                self.emit(N.OP_BN_ACT_APPLY,
+                          [z.addr(), cp[0], cp[1], residual.addr() if residual else None, y.addr(), pool_out.addr(),
+                           self.bp(pool_am)],
+                          [z.ld, residual.ld if residual else 0, y.ld, Cout, int(relu), dt, pool_out.ld, B, Ho, Wo], [M])
+            else:
+                self.emit(N.OP_BN_ACT_APPLY,
+                          [z.addr(), cp[0], cp[1], residual.addr() if residual else None, y.addr()],
+                          [z.ld, residual.ld if residual else 0, y.ld, Cout, int(relu), dt], [M])
         else:
             # plain conv (+bias): ESE gate conv (vovnet.py:24), classifier head (classifier.py:63)
             flags = (N.VT_CONV_AFFINE if conv.bias is not None else 0) | (N.VT_CONV_RESIDUAL if residual else 0)
@@ -623,14 +638,36 @@ class Builder:
                       [x.addr(), wptr, y.addr(), None, self.pref(conv.bias) if conv.bias is not None else None,
                        residual.addr() if residual else None, None], desc=d)
 
+        pool_fused = pool_out is not None and has_bn and not fused and not stem_y
+        if pool_out is not None and not pool_fused:
+            self.maxpool3x3s2(y, out=pool_out, name=name + ".max_pool")  # (no normalise pass to fuse it into)
+
         if track:
             tag = self.tag
             training = unit_training
 
             def bwd():
                 self.tag = tag
-                dy = self.grad_read(y)
-                if dy is None:
+                pool_grad = None  # (fused pool: the gradient of the pooled map, read through the arg-max taps)
+                if pool_fused:
+                    dp = self.grad_read(pool_out)
+                    if dp is not None:
+                        if residual is None and not stem_fused and self.grad_read(y) is None:
+                            pool_grad = dp  # the pool is y's only consumer: d(y) is never formed
+                        else:  # y feeds something else too (a returned feature map, a shortcut): form d(y) as the pool's backward would
+                            gy, res_ = self.grad_target(y)
+                            acc = 0
+                            if res_ is not None:
+                                if res_ is gy or (res_.buf is gy.buf and res_.coff == gy.coff):
+                                    acc = 1
+                                else:
+                                    self._add_into(gy, res_, False)
+                                    acc = 1
+                            self.emit(N.OP_MAXPOOL_BWD, [dp.addr(), self.bp(pool_am), gy.addr()],
+                                      [dp.ld, gy.ld, B, Ho, Wo, Cout, acc, dt])
+                            self.grad_written(y)
+                dy = self.grad_read(y) if pool_grad is None else None
+                if dy is None and pool_grad is None:
                     return
                 if residual is not None:
                     self.grad_add(residual, dy)
@@ -656,17 +693,20 @@ class Builder:
                     return
                 if has_bn:
                     sums = self.zeroed_f32(N.stat_floats(Cout), "bwdsums")
+                    g_ = pool_grad if pool_grad is not None else dy
+                    am_ = [self.bp(pool_am)] if pool_grad is not None else []
+                    geo = [B, Ho, Wo] if pool_grad is not None else []
                     self.emit(N.OP_BN_BWD_REDUCE,
-                              [dy.addr(), z.addr(), cp[0], cp[1], cp[2], cp[3], self.bp(sums)],
-                              [dy.ld, z.ld, Cout, int(relu), dt], [M])
+                              [g_.addr(), z.addr(), cp[0], cp[1], cp[2], cp[3], self.bp(sums)] + am_,
+                              [g_.ld, z.ld, Cout, int(relu), dt] + geo, [M])
                     bcoef = self.f32(3 * Cout, "bwdcoef")
                     self.emit(N.OP_BN_BWD_FINALIZE,
                               [self.bp(sums), cp[0], cp[2], cp[3], self.pgrad(norm.weight), self.pgrad(norm.bias),
                                self.bp(bcoef)], [Cout, int(training)], [M * self.bn_world, 1.0 / self.bn_world])
                     dz = self.act(B, Ho, Wo, Cout, name + ".dz")
                     self.emit(N.OP_BN_BWD_APPLY,
-                              [dy.addr(), z.addr(), cp[0], cp[1], self.bp(bcoef), dz.addr()],
-                              [dy.ld, z.ld, dz.ld, Cout, int(relu), dt], [M])
+                              [g_.addr(), z.addr(), cp[0], cp[1], self.bp(bcoef), dz.addr()] + am_,
+                              [g_.ld, z.ld, dz.ld, Cout, int(relu), dt] + geo, [M])
                 else:
                     dz = dy
                     if conv.bias is not None and conv.bias.requires_grad:
