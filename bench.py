@@ -343,7 +343,34 @@ def secondary_configs(dev):
                 "roofline_frac": round(127.599 * 64 / ms / PEAK_BF16_TFLOPS, 4), "maps": [list(t.shape) for t in maps]})
     del m, x, maps
     torch.cuda.empty_cache()
+    # the reference recipe's `sync_batchnorm: true` (configs/base.yaml:22) at N = 1: the data-parallel schedule over a
+    # one-rank RCCL communicator with the collectives as ops of the launch lists, with and without the 67 + 67
+    # statistics exchanges (a child process: it needs a process group of its own)
+    sb = syncbn_child()
+    if sb:
+        out.append(sb)
     return out
+
+
+def syncbn_child(timeout_s: int = 240):
+    import subprocess
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29000 + os.getpid() % 2000))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run([sys.executable, str(ROOT / "tools" / "bench_syncbn.py"), "256", "10", "rccl"], env=env,
+                           capture_output=True, text=True, timeout=timeout_s)
+        line = next(l for l in reversed(r.stdout.splitlines()) if l.startswith("{"))
+        d = json.loads(line)
+    except Exception as e:  # noqa: BLE001 -- a secondary number: report its absence, do not fail the line
+        return {"config": "sync_batchnorm at N=1", "error": repr(e)[:200]}
+    plain, sync = min(d["inlist_plain_ms"]), min(d["inlist_sync_bn_ms"])
+    return {"config": "CSPDarknet-53 train step, batch 256, `sync_batchnorm: true` (configs/base.yaml:22) at N=1: one-rank RCCL "
+                      "communicator, statistics exchanges + bucket all-reduces as launch-list ops (vt_stat_sync / "
+                      "vt_allreduce_bucket)",
+            "plain_dp_schedule_ms": plain, "sync_bn_step_ms": sync, "sync_bn_overhead": round(sync / plain - 1.0, 4),
+            "runs_ms": d}
 
 
 def pmc_traffic_live(layer: str, kernel_substr: str, timeout_s: int = 150):
@@ -472,6 +499,10 @@ def main():
     ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "sharded"],
                     help="gradient exchange: f32 all-reduce per bucket (default) or reduce-scatter -> sharded SGD -> "
                          "bf16 all-gather of the weights (SURVEY 8e)")
+    ap.add_argument("--collectives", default="auto", choices=["auto", "torch", "rccl"],
+                    help="who issues the collectives for N > 1: torch.distributed between list segments, or the library's own "
+                         "RCCL communicator with the collectives as ops of the launch lists (auto: rccl on the nccl backend "
+                         "with the all-reduce exchange)")
     ap.add_argument("--model", default="cspdarknet53")
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--graphs", action="store_true",
@@ -564,9 +595,14 @@ def main():
 
     torch.manual_seed(0)
     bb = getattr(backbones, args.model)()
+    coll = args.collectives
+    if coll == "auto":
+        coll = "rccl" if (world > 1 and backend == "nccl" and args.exchange == "allreduce" and not args.graphs) else "torch"
     ts = TrainStep(bb, 1000, args.batch, args.image_size, torch.bfloat16, lr=0.05, momentum=0.9, weight_decay=2e-5,
                    label_smoothing=0.1, device=dev, bucket_mb=args.bucket_mb, use_graphs=args.graphs,
-                   sync_bn=args.sync_bn, deterministic=True if args.deterministic else None, exchange=args.exchange)
+                   sync_bn=args.sync_bn, deterministic=True if args.deterministic else None, exchange=args.exchange,
+                   collectives=coll)
+    ts_collectives = ts.collectives
     ts.broadcast_parameters(0)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
@@ -695,6 +731,7 @@ def main():
                        "rccl_ranks": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
                        "backend": backend if world > 1 else None, "local_device": f"cuda:{local}",
                        "gradient_exchange": args.exchange if world > 1 else None,
+                       "collectives": (ts_collectives if world > 1 else None),
                        "hip_graphs": bool(args.graphs), "main_stream_priority": args.main_priority,
                        "sync_bn": bool(args.sync_bn), "deterministic": bool(ts.deterministic),
                        "final_loss": round(loss, 4)},

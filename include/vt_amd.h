@@ -40,6 +40,7 @@ extern "C" {
 
 #define VT_F32 0
 #define VT_BF16 1
+#define VT_I64 2 /* collectives only (vt_allreduce_bucket): the fixed-point BatchNorm sums */
 
 #define VT_MAX_TAPS 36 /* 6x6 stem of DarknetYOLOv5 (darknet.py:109) */
 
@@ -421,6 +422,8 @@ enum vt_op_kind {
     VT_OP_PW_REDUCE,        /* vt_pw_bwd_reduce */
     VT_OP_PW_BWD,           /* vt_pw_bwd_apply */
     VT_OP_STEM_BWD_S2,      /* vt_stem_bn_bwd_s2 */
+    VT_OP_ALLREDUCE,        /* vt_allreduce_bucket (a gradient bucket, in place) */
+    VT_OP_STAT_SYNC,        /* vt_stat_sync (one BatchNorm layer's sums over all ranks) */
     VT_OP_KIND_END
 };
 
@@ -466,6 +469,23 @@ int vt_graph_create(const vt_op* ops, int32_t n, void* const* bases, int32_t nba
                     void** graph_out);
 int vt_graph_launch(void* graph, void* stream);
 int vt_graph_destroy(void* graph);
+
+/* ---- data-parallel collectives (RCCL over xGMI, bound at run time) ------------------------------------------------
+ * The reference leaves these to DistributedDataParallel / SyncBatchNorm (`strategy: ddp`, `sync_batchnorm: true`,
+ * configs/base.yaml:17-22).  Here they are stream-ordered entry points, so a launch list carries them as ops
+ * (VT_OP_ALLREDUCE, VT_OP_STAT_SYNC) between the kernels that produce and consume their operands.  One communicator per
+ * process (= per GPU): rank 0 draws an id, the host side hands it to every rank (any out-of-band channel), every rank
+ * calls vt_comm_init with the device current.  The RCCL image already mapped into the process is used when there is
+ * one (PyTorch's), else librccl.so.1 is loaded. */
+#define VT_COMM_ID_BYTES 128
+int vt_comm_unique_id(void* id128);
+int vt_comm_init(const void* id128, int32_t rank, int32_t world);
+int vt_comm_world(void); /* ranks of this process's communicator, 0 without one */
+int vt_comm_destroy(void);
+/* in-place sum all-reduce of `count` elements (VT_F32 / VT_BF16 gradients, VT_I64 fixed-point sums) on `stream` */
+int vt_allreduce_bucket(void* buf, int64_t count, int32_t dtype, void* stream);
+/* SyncBatchNorm exchange of one layer: vt_stat_fold, then the int64 all-reduce of the folded 32*C bytes */
+int vt_stat_sync(float* stats, int32_t C, void* stream);
 
 /* ---- timing helpers for bench.py (HIP events on the launch stream) ------- */
 int vt_event_create(void** ev);

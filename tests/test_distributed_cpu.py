@@ -259,3 +259,62 @@ def test_sharded_exchange_equals_the_allreduce_path_bit_for_bit(world):
     assert sorted(r[0] for r in results) == list(range(world))
     for r in results:
         assert all(r[1:]), r
+
+
+def test_inlist_collectives_layout_of_the_launch_lists(monkeypatch):
+    """collectives="rccl" (round 4; include/vt_amd.h vt_allreduce_bucket / vt_stat_sync): the data-parallel collectives are
+    ops OF the launch lists.  Host logic only (plan_only, a one-rank gloo group stands in for the job): every gradient
+    bucket is one VT_OP_ALLREDUCE on the filter-gradient stream behind a FORK, the buckets tile the flat gradient buffer
+    exactly once, a JOIN follows the last of them, no op that writes into a bucket comes after its all-reduce, and with
+    sync_bn=True a VT_OP_STAT_SYNC on the finalize kernel's own sums sits directly in front of every BatchNorm finalize
+    (forward and backward) -- the reference's `sync_batchnorm: true` / DDP reducer (configs/base.yaml:17-22)."""
+    from vision_toolbox import _native as N
+    from vision_toolbox import backbones
+    from vision_toolbox import engine as E
+    from vision_toolbox.trainer import TrainStep, _grad_write_offsets
+
+    monkeypatch.setenv("VT_DP_WORLD1", "1")
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+    try:
+        ts = TrainStep(backbones.darknet_yolov5n(), 16, 2, 64, torch.bfloat16, device="cpu", plan_only=True, bucket_mb=0.5,
+                       sync_bn=True, collectives="rccl")
+        plain = TrainStep(backbones.darknet_yolov5n(), 16, 2, 64, torch.bfloat16, device="cpu", plan_only=True,
+                          data_parallel=False)
+    finally:
+        dist.destroy_process_group()
+    assert ts.collectives == "rccl" and ts.bucketer is None and ts.bwd_cuts == [ts.prog.n_bwd]
+    for ops, n, fin, n_plain in ((ts.prog.fwd_ops, ts.prog.n_fwd, N.OP_BN_FINALIZE, plain.prog.n_fwd),
+                                 (ts.prog.bwd_ops, ts.prog.n_bwd, N.OP_BN_BWD_FINALIZE, plain.prog.n_bwd)):
+        kinds = [ops[i].kind & 0xFFFF for i in range(n)]
+        nfin = kinds.count(fin)
+        assert nfin > 10 and kinds.count(N.OP_STAT_SYNC) == nfin
+        for i, k in enumerate(kinds):
+            if k == fin:
+                s, f = ops[i - 1], ops[i]
+                assert (s.kind & 0xFFFF) == N.OP_STAT_SYNC and (s.kind & N.OP_SIDE_STREAM) == (f.kind & N.OP_SIDE_STREAM)
+                assert (s.ptr[0].base, s.ptr[0].offset, s.i[0]) == (f.ptr[0].base, f.ptr[0].offset, f.i[0])
+        extra = kinds.count(N.OP_STAT_SYNC) + kinds.count(N.OP_ALLREDUCE)
+        assert n - extra - (kinds.count(N.OP_FORK) + kinds.count(N.OP_JOIN)) == \
+            n_plain - sum((plain.prog.fwd_ops if fin == N.OP_BN_FINALIZE else plain.prog.bwd_ops)[i].kind & 0xFFFF in
+                          (N.OP_FORK, N.OP_JOIN) for i in range(n_plain))  # nothing else was added or lost
+    ops, n = ts.prog.bwd_ops, ts.prog.n_bwd
+    covered = []
+    last_ar = -1
+    for i in range(n):
+        if (ops[i].kind & 0xFFFF) == N.OP_ALLREDUCE:
+            assert ops[i].kind & N.OP_SIDE_STREAM and ops[i].ptr[0].base == E.GRADS and ops[i].i[0] == N.VT_F32
+            j = i - 1
+            while (ops[j].kind & 0xFFFF) == N.OP_ALLREDUCE:
+                j -= 1
+            assert (ops[j].kind & 0xFFFF) == N.OP_FORK  # the side stream is ordered behind the bucket's producers
+            lo = ops[i].ptr[0].offset // 4
+            hi = lo + int(ops[i].f[0])
+            covered.append((lo, hi))
+            last_ar = i
+            for k in range(i + 1, n):  # nothing writes into the bucket afterwards
+                for off in _grad_write_offsets(ops[k]):
+                    assert not (lo <= off < hi), (i, k, off)
+    covered.sort()
+    assert covered[0][0] == 0 and covered[-1][1] == ts.gflat.numel() and len(covered) > 2
+    assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    assert any((ops[i].kind & 0xFFFF) == N.OP_JOIN for i in range(last_ar + 1, n))

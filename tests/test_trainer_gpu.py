@@ -203,15 +203,19 @@ def test_two_ranks_on_one_gpu_match_ddp_semantics(sync_bn, model):
     N.check(N.lib().vt_memset(buf.data_ptr(), 0, 64, int(torch.cuda.current_stream().cuda_stream)))
 
 
-@pytest.mark.parametrize("sync_bn,exchange", [("0", "allreduce"), ("1", "allreduce"), ("0", "sharded")],
-                         ids=["rccl", "rccl_syncbn", "rccl_sharded"])
-def test_one_rank_rccl_group_runs_the_data_parallel_schedule(sync_bn, exchange):
+@pytest.mark.parametrize("sync_bn,exchange,collectives",
+                         [("0", "allreduce", "torch"), ("1", "allreduce", "torch"), ("0", "sharded", "torch"),
+                          ("0", "allreduce", "rccl"), ("1", "allreduce", "rccl")],
+                         ids=["rccl", "rccl_syncbn", "rccl_sharded", "inlist", "inlist_syncbn"])
+def test_one_rank_rccl_group_runs_the_data_parallel_schedule(sync_bn, exchange, collectives):
     """the N > 1 schedule of TrainStep over a ONE-rank `nccl` (= RCCL) process group on this GPU: bucket all-reduces
     issued from the filter-gradient stream between list segments, SyncBatchNorm collectives, broadcasts -- the calls
     go through torch's RCCL process group exactly as on N GPUs (tools/rccl_world1_check.py); numbers must equal the
     plain schedule's (a one-rank all-reduce is the identity).  `rccl_sharded`: the reduce-scatter -> sharded SGD ->
     all-gather exchange (in-place reduce_scatter_tensor / all_gather_into_tensor on views of the flat buffers);
-    `rccl_syncbn` folds the statistics replicas on the device before every all-reduce (vt_stat_fold)."""
+    `rccl_syncbn` folds the statistics replicas on the device before every all-reduce (vt_stat_fold).  `inlist*` (round 4):
+    collectives="rccl" -- the library's own communicator (vt_comm_init over an id torch.distributed carries once), the
+    bucket all-reduces and statistics exchanges as ops of the launch lists (VT_OP_ALLREDUCE / VT_OP_STAT_SYNC)."""
     import os
     import subprocess
     import sys
@@ -222,7 +226,8 @@ def test_one_rank_rccl_group_runs_the_data_parallel_schedule(sync_bn, exchange):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    r = subprocess.run([sys.executable, str(root / "tools" / "rccl_world1_check.py"), sync_bn, exchange], capture_output=True,
+    r = subprocess.run([sys.executable, str(root / "tools" / "rccl_world1_check.py"), sync_bn, exchange, collectives],
+                       capture_output=True,
                        text=True, timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
     assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     buf = torch.zeros(16, device="cuda")  # the launch-count guard of this module wants a launch here too

@@ -5,7 +5,7 @@ identity, so what this proves is that torch's RCCL process group accepts the cal
 them (streams, async work handles, in-place views of the flat buffers) and that the cut schedule leaves the numbers
 alone -- not the exchange itself (gloo world-2: tests/test_distributed_cpu.py, tools/ddp_check.py).
 
-    python tools/rccl_world1_check.py [sync_bn=0|1] [exchange=allreduce|sharded]        (GPU box)
+    python tools/rccl_world1_check.py [sync_bn=0|1] [exchange=allreduce|sharded] [collectives=torch|rccl]    (GPU box)
 
 exchange=sharded: reduce_scatter_tensor / all_gather_into_tensor on in-place views of the flat buffers (the sharded
 optimiser path); sync_bn=1: the statistics replicas are folded on the device (vt_stat_fold) before each all-reduce."""
@@ -23,12 +23,22 @@ from vision_toolbox import backbones
 from vision_toolbox.trainer import TrainStep
 
 
-def run(dp: bool, sync_bn: bool, exchange: str = "allreduce"):
+def run(dp: bool, sync_bn: bool, exchange: str = "allreduce", collectives: str = "torch"):
     torch.manual_seed(0)
     ts = TrainStep(backbones.darknet_yolov5n(), 16, 8, 64, torch.float32, lr=0.01, bucket_mb=0.25, sync_bn=sync_bn,
                    use_graphs=os.environ.get("RCCL_CHECK_GRAPHS", "0") != "0",  # bench.py runs without graphs
-                   exchange=exchange)
-    if dp:
+                   exchange=exchange, collectives=collectives)
+    if dp and collectives == "rccl":
+        # the collectives are ops of the lists: one all-reduce per bucket on the filter-gradient stream, a statistics
+        # exchange in front of every finalize kernel, no torch bucketer, one segment
+        from vision_toolbox import _native as N
+        kinds = [ts.prog.bwd_ops[i].kind & 0xFFFF for i in range(ts.prog.n_bwd)]
+        assert ts.bucketer is None and ts.bwd_cuts == [ts.prog.n_bwd] and kinds.count(N.OP_ALLREDUCE) > 2
+        assert sum(b1 - b0 for b0, b1 in ts.inline_buckets) == ts.gflat.numel()
+        nsync = kinds.count(N.OP_STAT_SYNC)
+        assert nsync == (kinds.count(N.OP_BN_BWD_FINALIZE) if sync_bn else 0)
+        ts.broadcast_parameters(0)
+    elif dp:
         assert ts.bucketer is not None and len(ts.bucketer.buckets) > 2 and len(ts.bwd_cuts) > 2
         ts.broadcast_parameters(0)
     else:
@@ -47,6 +57,7 @@ def run(dp: bool, sync_bn: bool, exchange: str = "allreduce"):
 def main():
     sync_bn = len(sys.argv) > 1 and sys.argv[1] == "1"
     exchange = sys.argv[2] if len(sys.argv) > 2 else "allreduce"
+    collectives = sys.argv[3] if len(sys.argv) > 3 else "torch"
     ref_losses, ref_p = run(False, False)
     again_losses, again_p = run(False, False)
     nl = max(abs(a - b) for a, b in zip(again_losses, ref_losses))
@@ -57,7 +68,7 @@ def main():
     os.environ["VT_DP_WORLD1"] = "1"
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    losses, p = run(True, sync_bn, exchange)
+    losses, p = run(True, sync_bn, exchange, collectives)
     dist.barrier()
     dist.destroy_process_group()
     dl = max(abs(a - b) for a, b in zip(losses, ref_losses))

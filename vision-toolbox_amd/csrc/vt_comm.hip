@@ -1,0 +1,141 @@
+// vt_comm.hip -- the data-parallel collectives of the path as C entry points: sum all-reduce of a gradient bucket
+// (reference: DistributedDataParallel's bucketed all-reduce behind `strategy: ddp`, configs/base.yaml:17-19) and of one
+// BatchNorm layer's folded statistics (SyncBatchNorm, configs/base.yaml:22), issued on the caller's HIP stream so that a
+// launch list can carry them as ordinary ops (VT_OP_ALLREDUCE / VT_OP_STAT_SYNC): no host round trip, no second library
+// stream, no event hop per collective.
+//
+// RCCL is bound at run time (dlopen + dlsym), not at link time: a process that already holds an RCCL (PyTorch's
+// libtorch_hip.so brings its own librccl.so.1) must talk to THAT instance -- two RCCL images in one process would each
+// run their own bootstrap and proxy threads -- and a consumer that never goes multi-GPU needs no RCCL at all.  One
+// communicator per process (one process per GPU).
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enumerators only; no symbol of it is linked
+
+#include <mutex>
+
+#include "vt_common.h"
+
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+std::mutex g_mu;
+Rccl g_rccl;
+ncclComm_t g_comm = nullptr;
+int g_world = 0, g_rank = -1;
+
+int bind_rccl() {
+    if (g_rccl.handle) return VT_OK;
+    // the soname first: if the process already mapped an RCCL under it (PyTorch), the loader hands back that image
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        if (h) break;
+    }
+    for (int k = 0; !h && k < 3; ++k) h = dlopen(names[k], RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+        vt_set_error("vt_comm: RCCL not found (librccl.so.1): %s", dlerror());
+        return VT_ERR_UNSUPPORTED;
+    }
+    Rccl r;
+    r.handle = h;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString) {
+        vt_set_error("vt_comm: the RCCL image lacks an entry point this library binds");
+        return VT_ERR_UNSUPPORTED;
+    }
+    g_rccl = r;
+    return VT_OK;
+}
+
+int rccl_error(const char* what, ncclResult_t rc) {
+    vt_set_error("%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error");
+    return VT_ERR_HIP;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vt_comm_unique_id(void* id128) {
+    VT_REQUIRE(id128, VT_ERR_INVALID, "vt_comm_unique_id: null id");
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int rc = bind_rccl();
+    if (rc != VT_OK) return rc;
+    ncclUniqueId id;
+    const ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) return rccl_error("vt_comm_unique_id", r);
+    static_assert(sizeof(id) == VT_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    memcpy(id128, &id, sizeof(id));
+    return VT_OK;
+}
+
+int vt_comm_init(const void* id128, int32_t rank, int32_t world) {
+    VT_REQUIRE(id128 && world >= 1 && rank >= 0 && rank < world, VT_ERR_INVALID, "vt_comm_init: bad argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    VT_REQUIRE(g_comm == nullptr, VT_ERR_INVALID, "vt_comm_init: this process already holds a communicator");
+    const int rc = bind_rccl();
+    if (rc != VT_OK) return rc;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t c = nullptr;
+    const ncclResult_t r = g_rccl.CommInitRank(&c, world, id, rank);  // (collective over the `world` processes; current device)
+    if (r != ncclSuccess) return rccl_error("vt_comm_init", r);
+    g_comm = c, g_world = world, g_rank = rank;
+    return VT_OK;
+}
+
+int vt_comm_world(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_comm ? g_world : 0;
+}
+
+int vt_comm_destroy(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_comm) return VT_OK;
+    const ncclResult_t r = g_rccl.CommDestroy(g_comm);
+    g_comm = nullptr, g_world = 0, g_rank = -1;
+    return r == ncclSuccess ? VT_OK : rccl_error("vt_comm_destroy", r);
+}
+
+int vt_allreduce_bucket(void* buf, int64_t count, int32_t dtype, void* stream) {
+    VT_REQUIRE(buf && count > 0, VT_ERR_INVALID, "vt_allreduce_bucket: bad argument");
+    ncclDataType_t t;
+    switch (dtype) {
+        case VT_F32: t = ncclFloat32; break;
+        case VT_BF16: t = ncclBfloat16; break;
+        case VT_I64: t = ncclInt64; break;
+        default: vt_set_error("vt_allreduce_bucket: dtype %d", dtype); return VT_ERR_UNSUPPORTED;
+    }
+    ncclComm_t c;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        c = g_comm;
+    }
+    VT_REQUIRE(c != nullptr, VT_ERR_INVALID, "vt_allreduce_bucket: no communicator (vt_comm_init first)");
+    const ncclResult_t r = g_rccl.AllReduce(buf, buf, (size_t)count, t, ncclSum, c, (hipStream_t)stream);
+    return r == ncclSuccess ? VT_OK : rccl_error("vt_allreduce_bucket", r);
+}
+
+int vt_stat_sync(float* stats, int32_t C, void* stream) {
+    // one layer's BatchNorm sums over all ranks: fold the replicas into replica 0 (exact integer adds), then an int64 sum
+    // all-reduce of those 4 C words (two 128-bit fixed-point sums per channel as independent 64-bit halves) -- the
+    // algorithmic payload, exact and order-free, so every rank finalises identical statistics
+    const int rc = vt_stat_fold(stats, C, stream);
+    if (rc != VT_OK) return rc;
+    return vt_allreduce_bucket(stats, 4 * (int64_t)C, VT_I64, stream);
+}
+
+}  // extern "C"

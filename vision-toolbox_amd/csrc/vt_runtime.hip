@@ -181,6 +181,10 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
         case VT_OP_STEM_BWD_S2:  // ptr: gzx w mean invstd sums | i: C fixed
             return vt_stem_bn_bwd_s2(I[0], (const float*)P[0], P[1], (const float*)P[2], (const float*)P[3], (float*)P[4], I[1],
                                      st);
+        case VT_OP_ALLREDUCE:  // ptr: buf | i: dtype | f: count
+            return vt_allreduce_bucket(P[0], (int64_t)F[0], I[0], st);
+        case VT_OP_STAT_SYNC:  // ptr: stats | i: C
+            return vt_stat_sync((float*)P[0], I[0], st);
         case VT_OP_STEM_BWD_COMBINE:  // ptr: gzx coef dw [w: the reduction read y, not z] | i: C cin fixed
             if (P[3])
                 return vt_stem_bn_bwd_combine_y(I[0], I[1], (const float*)P[0], (const float*)P[1], P[3], (float*)P[2], I[2],

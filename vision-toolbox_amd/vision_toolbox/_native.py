@@ -15,7 +15,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("VT_AMD_LIB", _HERE.parent / "csrc" / "libvt_amd.so"))
 
 VT_OK, VT_ERR_INVALID, VT_ERR_UNSUPPORTED, VT_ERR_HIP = 0, 1, 2, 3
-VT_F32, VT_BF16 = 0, 1
+VT_F32, VT_BF16, VT_I64 = 0, 1, 2  # (VT_I64: collectives only)
 VT_MAX_TAPS = 36
 VT_CONV_RELU, VT_CONV_STATS, VT_CONV_RESIDUAL, VT_CONV_AFFINE, VT_CONV_D2S, VT_CONV_NOSTORE = 1, 2, 4, 8, 16, 32
 VT_STAT_REPLICAS = 16
@@ -89,7 +89,9 @@ VT_OP_MAX_PTR, VT_OP_MAX_INT, VT_OP_MAX_FLT, VT_MAX_BASES = 16, 110, 8, 16
     OP_PW_REDUCE,
     OP_PW_BWD,
     OP_STEM_BWD_S2,
-) = range(1, 37)
+    OP_ALLREDUCE,
+    OP_STAT_SYNC,
+) = range(1, 39)
 OP_SIDE_STREAM = 0x10000  # OR-ed into Op.kind: enqueue on the side stream
 
 OP_NAMES = {
@@ -129,6 +131,8 @@ OP_NAMES = {
     OP_PW_REDUCE: "pw_reduce",
     OP_PW_BWD: "pw_bwd",
     OP_STEM_BWD_S2: "stem_bwd_s2",
+    OP_ALLREDUCE: "allreduce",
+    OP_STAT_SYNC: "stat_sync",
 }
 
 
@@ -206,6 +210,12 @@ SYMBOLS = {
     "vt_pack_dgrad_filter": (_i32, [_vp, _i32, _i32, _vp, _i32, C.POINTER(_i32), _i32, _i32, _i32, _i32, _vp]),
     "vt_bn_finalize": (_i32, [_vp, _i32, _f64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vt_stat_fold": (_i32, [_vp, _i32, _vp]),
+    "vt_stat_sync": (_i32, [_vp, _i32, _vp]),
+    "vt_comm_unique_id": (_i32, [_vp]),
+    "vt_comm_init": (_i32, [_vp, _i32, _i32]),
+    "vt_comm_world": (_i32, []),
+    "vt_comm_destroy": (_i32, []),
+    "vt_allreduce_bucket": (_i32, [_vp, C.c_int64, _i32, _vp]),
     "vt_bn_eval_coeffs": (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "vt_bn_act_apply": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "vt_bn_act_bwd_reduce": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),

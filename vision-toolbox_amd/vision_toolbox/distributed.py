@@ -57,6 +57,38 @@ def plan_buckets(total_elems: int, bucket_elems: int, align: int = 64, head_elem
     return bounds
 
 
+def ensure_library_comm(group=None, device: Optional[torch.device] = None) -> int:
+    """The library's own RCCL communicator over the ranks of `group` (vt_comm_init, include/vt_amd.h): rank 0 draws the
+    id, torch.distributed carries its 128 bytes to the other ranks (any backend: this is the out-of-band channel the
+    header speaks of, used once), every rank joins with its device current.  Returns the world size.  With it a launch
+    list carries its collectives as ops (VT_OP_ALLREDUCE / VT_OP_STAT_SYNC): nothing of torch sits between two kernels."""
+    import ctypes
+
+    from . import _native as N
+
+    L = N.lib()
+    world = dist.get_world_size(group)
+    have = L.vt_comm_world()
+    if have:
+        if have != world:
+            raise RuntimeError(f"the library communicator spans {have} ranks, the process group {world}")
+        return world
+    rank = dist.get_rank(group)
+    ident = ctypes.create_string_buffer(128)
+    if rank == 0:
+        N.check(L.vt_comm_unique_id(ident))
+    box = [bytes(ident.raw)]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    ident = ctypes.create_string_buffer(box[0], 128)
+    ctx = torch.cuda.device(device) if device is not None and device.type == "cuda" else None
+    if ctx is not None:
+        with ctx:
+            N.check(L.vt_comm_init(ident, rank, world))
+    else:
+        N.check(L.vt_comm_init(ident, rank, world))
+    return world
+
+
 class GradBucketer:
     def __init__(self, flat: torch.Tensor, buckets: Sequence[tuple[int, int]], group=None):
         assert flat.dim() == 1 and flat.is_contiguous()

@@ -17,6 +17,11 @@ side stream current).  hipGraph replay of the same segments is available (graphs
 measured slower than eager two-stream execution.  BatchNorm uses per-rank batch statistics by
 default; sync_bn=True gives the reference recipe's SyncBatchNorm (configs/base.yaml:22) at the
 cost of 134 small collectives per step.
+
+collectives="rccl" (round 4): the library's own RCCL communicator (vt_comm_init) instead of
+torch.distributed -- the statistics exchanges and the bucket all-reduces are ops of the launch
+lists (VT_OP_STAT_SYNC, VT_OP_ALLREDUCE), a step is three host calls for any world size, and a
+SyncBatchNorm exchange stays on the stream of the kernels around it.
 """
 from __future__ import annotations
 
@@ -136,6 +141,7 @@ class TrainStep:
         exchange: str = "allreduce",
         head_bucket_kb: float = 256.0,
         data_parallel: Optional[bool] = None,
+        collectives: str = "torch",
     ):
         N.lib()
         self.device = torch.device(device if device is not None else "cuda")
@@ -175,6 +181,21 @@ class TrainStep:
         if exchange not in ("allreduce", "sharded"):
             raise ValueError(exchange)
         self.exchange = exchange if self.dp else "allreduce"
+        # who issues the collectives: "torch" = torch.distributed calls between segments of the launch lists (any
+        # backend: gloo in the CPU tests); "rccl" = the library's own RCCL communicator (vt_comm_init), the collectives are
+        # OPS of the lists (VT_OP_STAT_SYNC in front of every BatchNorm finalize, FORK + VT_OP_ALLREDUCE on the
+        # filter-gradient stream behind the op that completes a bucket): a step is three host calls whatever the
+        # number of ranks and layers, and no collective hops to another library's stream and back
+        if collectives not in ("torch", "rccl"):
+            raise ValueError(collectives)
+        self.collectives = collectives if self.dp else "torch"
+        if self.collectives == "rccl":
+            if self.exchange != "allreduce":
+                raise ValueError("collectives='rccl' carries the all-reduce exchange only")
+            if not plan_only:
+                from .distributed import ensure_library_comm
+
+                ensure_library_comm(self.pg, self.device)
         self._align = 64 * self.world if self.exchange == "sharded" else 64
         st.pad_multiple = self._align
         with self._dev_ctx():
@@ -213,6 +234,11 @@ class TrainStep:
         # sync points: the statistics a finalize kernel reads must be all-reduced right before it
         self._fwd_sync = self._sync_points(self.prog.fwd_ops, self.prog.n_fwd, N.OP_BN_FINALIZE) if self.sync_bn else []
         self._bwd_sync = self._sync_points(self.prog.bwd_ops, self.prog.n_bwd, N.OP_BN_BWD_FINALIZE) if self.sync_bn else []
+        if self.collectives == "rccl" and self.sync_bn:
+            # the statistics exchange becomes an op in front of each finalize kernel (same stream: ordered by position)
+            self.prog.fwd_ops, self.prog.n_fwd = self._with_stat_sync(self.prog.fwd_ops, self.prog.n_fwd, self._fwd_sync)
+            self.prog.bwd_ops, self.prog.n_bwd = self._with_stat_sync(self.prog.bwd_ops, self.prog.n_bwd, self._bwd_sync)
+            self._fwd_sync, self._bwd_sync = [], []
 
         # ---- optimiser launch list: one SGD launch per weight-decay group ---------------------
         wd_of = {GROUP_OTHER: weight_decay, GROUP_NORM: norm_weight_decay, GROUP_BIAS: bias_weight_decay}
@@ -268,6 +294,8 @@ class TrainStep:
             self.bwd_cuts = [c for c in cuts if c > 0]
             self.cut_buckets = [[bi for bi, r in enumerate(ready) if r == c or (c == self.bwd_cuts[0] and r == 0)]
                                 for c in self.bwd_cuts]
+            if self.collectives == "rccl":
+                self._inline_buckets(buckets)
 
         with self._dev_ctx():
             self.arena = torch.empty(1 if plan_only else self.prog.arena_bytes, dtype=torch.uint8, device=self.device)
@@ -325,6 +353,70 @@ class TrainStep:
         if self._master_stale:
             raise RuntimeError("exchange='sharded': the f32 master parameters of the slices other ranks own are stale "
                                "on this rank; call TrainStep.gather_master() on every rank before state_dict()")
+
+    @staticmethod
+    def _with_stat_sync(ops, n, points):
+        """the launch list with a VT_OP_STAT_SYNC in front of every finalize op of `points` (on that op's stream)"""
+        at = {idx for idx, *_ in points}
+        out = []
+        for idx in range(n):
+            op = ops[idx]
+            if idx in at:
+                so = N.Op()
+                so.kind = N.OP_STAT_SYNC | (op.kind & N.OP_SIDE_STREAM)
+                so.tag = op.tag
+                for k in range(N.VT_OP_MAX_PTR):
+                    so.ptr[k].base = -1
+                so.ptr[0].base, so.ptr[0].offset = op.ptr[0].base, op.ptr[0].offset
+                so.i[0] = op.i[0]
+                out.append(so)
+            cp = N.Op()
+            ctypes.memmove(ctypes.addressof(cp), ctypes.addressof(op), ctypes.sizeof(N.Op))
+            out.append(cp)
+        return E.ops_array(out), len(out)
+
+    def _inline_buckets(self, buckets):
+        """collectives='rccl': behind the op that completes a bucket, FORK (the filter-gradient stream waits for the main
+        stream's position: BatchNorm / bias gradients are written there) and the bucket's all-reduce ON that stream --
+        the main stream waits for nothing, the list's own JOIN closes the side stream before the optimiser.  The
+        segments collapse into one list again."""
+        p = self.prog
+        after = dict(zip(self.bwd_cuts, self.cut_buckets))
+        out = []
+
+        def blank(kind):
+            o = N.Op()
+            o.kind = kind
+            for k in range(N.VT_OP_MAX_PTR):
+                o.ptr[k].base = -1
+            return o
+
+        open_side = False
+        for idx in range(p.n_bwd):
+            op = p.bwd_ops[idx]
+            cp = N.Op()
+            ctypes.memmove(ctypes.addressof(cp), ctypes.addressof(op), ctypes.sizeof(N.Op))
+            out.append(cp)
+            if (op.kind & 0xFFFF) == N.OP_JOIN:
+                open_side = False
+            bis = after.get(idx + 1, [])
+            if bis:
+                out.append(blank(N.OP_FORK))
+                for bi in bis:
+                    b0, b1 = buckets[bi]
+                    o = blank(N.OP_ALLREDUCE | N.OP_SIDE_STREAM)
+                    o.ptr[0].base, o.ptr[0].offset = E.GRADS, b0 * 4
+                    o.i[0] = N.VT_F32
+                    o.f[0] = float(b1 - b0)
+                    out.append(o)
+                open_side = True
+        if open_side:  # (the head bucket completes with the last ops, behind the list's own JOIN)
+            out.append(blank(N.OP_JOIN))
+        self._bwd_without_exchange = (p.bwd_ops, p.n_bwd)  # (skip_exchange: the measurement of what the exchange exposes)
+        p.bwd_ops, p.n_bwd = E.ops_array(out), len(out)
+        self.bwd_cuts, self.cut_buckets = [p.n_bwd], [[]]
+        self.bucketer = None
+        self.inline_buckets = [buckets[bi] for bis in after.values() for bi in bis]
 
     @staticmethod
     def _sync_points(ops, n, kind):
@@ -451,7 +543,7 @@ class TrainStep:
                 self.labels.copy_(labels, non_blocking=True)
             s = current_stream_handle()
             p = self.prog
-            if self.use_graphs and not self.sync_bn:
+            if self.use_graphs and not self.sync_bn and self.collectives != "rccl":
                 if self._graphs is None:
                     self._build_graphs()
                 self._graphs["head"].launch(s)
@@ -465,11 +557,14 @@ class TrainStep:
                 side = int(self._side.cuda_stream)
                 N.run_ops(self.zero_ops, 1, self.bases, s)
                 self._run_list(p.fwd_ops, p.n_fwd, self._fwd_sync, [], {}, s, side, keep_side_open=False)
-                self._run_list(p.bwd_ops, p.n_bwd, self._bwd_sync, self.bwd_cuts,
+                bwd_ops, n_bwd = p.bwd_ops, p.n_bwd
+                if self.skip_exchange and self.collectives == "rccl" and getattr(self, "_bwd_without_exchange", None):
+                    bwd_ops, n_bwd = self._bwd_without_exchange
+                self._run_list(bwd_ops, n_bwd, self._bwd_sync, [n_bwd] if self.collectives == "rccl" else self.bwd_cuts,
                                dict(zip(self.bwd_cuts, self.cut_buckets)), s, side)
             if self.bucketer is not None and not self.skip_exchange:
                 self.bucketer.finish()
-            if self.use_graphs and not self.sync_bn:
+            if self.use_graphs and not self.sync_bn and self.collectives != "rccl":
                 self._graphs["opt"].launch(s)
             else:
                 N.run_ops(self.opt_ops, self.n_opt, self.bases, s)
