@@ -77,11 +77,24 @@ def main():
             if kind in (N.OP_CONV_IGEMM, N.OP_CONV_WGRAD):
                 algo_bytes[name] += nb
             elif kind == N.OP_BN_ACT_APPLY:  # i: ldz ldr ldy C relu dtype | f: M ; ptr 3 = residual
-                algo_bytes[name] += 2.0 * op.f[0] * op.i[3] * (2 + (1 if op.ptr[3].base >= 0 else 0))
+                nb = 2.0 * op.f[0] * op.i[3] * (2 + (1 if op.ptr[3].base >= 0 else 0))
+                if op.ptr[5].base >= 0:  # fused max-pool: + pooled map and arg-max bytes
+                    nb += (2.0 + 1.0) * op.f[0] * op.i[3] / 4
+                algo_bytes[name] += nb
+                desc = f"C {op.i[3]:4d} M {int(op.f[0])}{' +res' if op.ptr[3].base >= 0 else ''}{' +pool' if op.ptr[5].base >= 0 else ''}"
+                work = f"{nb / ms / 1e9:6.2f} TB/s ideal {nb / PEAK_HBM * 1e3:6.3f} excess {ms - nb / PEAK_HBM * 1e3:6.3f}"
             elif kind == N.OP_BN_BWD_REDUCE:  # i: lddy ldz C relu dtype | f: M
-                algo_bytes[name] += 2.0 * op.f[0] * op.i[2] * 2
+                pooled = op.ptr[7].base >= 0
+                nb = 2.0 * op.f[0] * op.i[2] * (1.25 + 0.125 if pooled else 2)
+                algo_bytes[name] += nb
+                desc = f"C {op.i[2]:4d} M {int(op.f[0])}{' pooled-dy' if pooled else ''}"
+                work = f"{nb / ms / 1e9:6.2f} TB/s ideal {nb / PEAK_HBM * 1e3:6.3f} excess {ms - nb / PEAK_HBM * 1e3:6.3f}"
             elif kind == N.OP_BN_BWD_APPLY:  # i: lddy ldz lddz C relu dtype | f: M
-                algo_bytes[name] += 2.0 * op.f[0] * op.i[3] * 3
+                pooled = op.ptr[6].base >= 0
+                nb = 2.0 * op.f[0] * op.i[3] * (2.25 + 0.125 if pooled else 3)
+                algo_bytes[name] += nb
+                desc = f"C {op.i[3]:4d} M {int(op.f[0])}{' pooled-dy' if pooled else ''}"
+                work = f"{nb / ms / 1e9:6.2f} TB/s ideal {nb / PEAK_HBM * 1e3:6.3f} excess {ms - nb / PEAK_HBM * 1e3:6.3f}"
             elif kind in (N.OP_PW_STATS, N.OP_PW_APPLY, N.OP_PW_REDUCE, N.OP_PW_BWD):
                 # i: K ngroups relu C0 C1 ldx ... | f: M.  x once; y / dy once; residual / addend and dz where present
                 K, Nn, M_ = op.i[0], op.i[3] + op.i[4], op.f[0]
@@ -124,6 +137,16 @@ def main():
     print("-- pointwise ops (bytes = operands of the pass, once)")
     for ms, phase, idx, name, desc, work in sorted([r for r in rows if r[3].startswith("pw_")], key=lambda r: -r[0])[:top]:
         print(f"  {phase}[{idx:4d}] {name:11s} {desc}  {ms:7.4f} ms {work}")
+    print("-- BatchNorm streaming passes by shape (bytes = operands of the pass, once; against 6.3 TB/s)")
+    bagg = defaultdict(lambda: [0, 0.0, 0.0])
+    for ms, phase, idx, name, desc, work in rows:
+        if name.startswith("bn_") and desc:
+            a = bagg[(name, desc)]
+            a[0] += 1
+            a[1] += ms
+            a[2] += float(work.split("ideal")[1].split()[0])
+    for (name, desc), (cnt, ms, ideal) in sorted(bagg.items(), key=lambda kv: -(kv[1][1] - kv[1][2]))[:top]:
+        print(f"  {name:14s} {desc:34s} x{cnt:2d}  {ms:7.3f} ms ideal {ideal:7.3f} excess {ms - ideal:7.3f}  ({ideal / ms * 6.3:4.2f} TB/s)")
     print("-- conv ops by time")
     conv = [r for r in rows if r[3].startswith("conv")]
     for ms, phase, idx, name, desc, work in sorted(conv, key=lambda r: -r[0])[:top]:

@@ -34,6 +34,13 @@
 #ifndef VT_WS_PD
 #define VT_WS_PD 2
 #endif
+// ablations exist only in -DVT_WS_ABL=<bits> builds (tools/ws_ablate.sh; compile-time, so that the measured kernel keeps
+// the shipped one's registers and schedule): results are wrong by construction, only the time is read
+//   1 no LDS-DMA inside the loop, 2 no MFMAs, 4 no fragment reads, 8 no flush, 16 no barrier
+#ifndef VT_WS_ABL
+#define VT_WS_ABL 0
+#endif
+#define VT_WSDBG(bit) ((VT_WS_ABL & (bit)) != 0)
 
 namespace {
 
@@ -234,7 +241,7 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
         constexpr int NTL = decltype(ntl_c)::value;
         // dz(s) and x chunk s+NH must have landed; the younger steps (1 instruction per wave each) may stay in flight
         vm_wait<decltype(younger_c)::value>();
-        __builtin_amdgcn_s_barrier();
+        if (!VT_WSDBG(16)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 
         // all of the step's fragment reads first (18 in flight), the DMA issue's address arithmetic under their latency,
@@ -243,6 +250,10 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
         s16x4 alo[WI], ahi[WI];
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
+            if (VT_WSDBG(4)) {
+                alo[i] = ahi[i] = s16x4{(short)s, 1, 2, 3};
+                continue;
+            }
             alo[i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(dzs + a_off[i]));
             ahi[i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(dzs + a_off[i] + 16 * 128));
         }
@@ -254,13 +265,17 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
             const unsigned hi_o = (lo_o + 16u * 128u) & xmask;
 #pragma unroll
             for (int j = 0; j < WJ; ++j) {
+                if (VT_WSDBG(4)) {
+                    blo[tt][j] = bhi[tt][j] = s16x4{(short)lo_o, 1, 2, 3};
+                    continue;
+                }
                 // the next 16 input channels sit one 32-byte group over: chunk index ^ 2
                 blo[tt][j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sX + (lo_o ^ (32u * j))));
                 bhi[tt][j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sX + (hi_o ^ (32u * j))));
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (s + PD < nsteps) VT_WS_ISSUE_STEP(nxt);
+        if (s + PD < nsteps && !VT_WSDBG(1)) VT_WS_ISSUE_STEP(nxt);
         __builtin_amdgcn_sched_barrier(0);
         bf16x8 af[WI];
 #pragma unroll
@@ -272,8 +287,13 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
             for (int j = 0; j < WJ; ++j) {
                 const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(blo[tt][j], bhi[tt][j], 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-                for (int i = 0; i < WI; ++i)
+                for (int i = 0; i < WI; ++i) {
+                    if (VT_WSDBG(2)) {
+                        asm volatile("" ::"v"(af[i]), "v"(bf));
+                        continue;
+                    }
                     acc[tt][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[tt][i][j], 0, 0, 0);
+                }
             }
         }
         cur = (cur + 1 == NS) ? 0 : cur + 1;
@@ -302,6 +322,17 @@ __global__ void __launch_bounds__(512, 1) wgrad_span_kernel(const WsArgs p) {
     constexpr int PITCH = NC + 4;
     constexpr int IMG = NI * PITCH;
     float* sAcc = (float*)smem;
+    if (VT_WSDBG(8)) {
+        float keep = 0.f;
+#pragma unroll
+        for (int t = 0; t < TG; ++t)
+#pragma unroll
+            for (int i = 0; i < WI; ++i)
+#pragma unroll
+                for (int j = 0; j < WJ; ++j) keep += acc[t][i][j][0] + acc[t][i][j][1] + acc[t][i][j][2] + acc[t][i][j][3];
+        if (keep == 12345.678f) p.dw[0] = keep;
+        return;
+    }
 #pragma unroll
     for (int tt = 0; tt < TG; ++tt) {
         __syncthreads();
