@@ -146,7 +146,7 @@ def host_cpu():
     return ncores, model
 
 
-def insitu_layer_times(ts, Cin, Cout, ntaps, HW, reps=4, which="fwd"):
+def insitu_layer_times(ts, Cin, Cout, ntaps, HW, reps=4, which="fwd", stride=1):
     """HIP-event time of every launch of one conv layer shape (Cin -> Cout, ntaps, HW x HW, stride 1) INSIDE the step's own
     launch lists: the list is run in pieces with events around those ops, so each launch reads what the previous kernels
     of the step left behind a 20 GB arena (not a cache-resident toy).  which = "fwd" (forward list), "dgrad" (the data
@@ -163,7 +163,7 @@ def insitu_layer_times(ts, Cin, Cout, ntaps, HW, reps=4, which="fwd"):
         if (op.kind & 0xFFFF) != kind:
             continue
         d = N.ConvDesc.from_buffer_copy(bytes(op.i)[: ctypes.sizeof(N.ConvDesc)])
-        if (d.Cin, d.Cout, d.ntaps, d.Hi, d.Wi, d.sh) == (Cin, Cout, ntaps, HW, HW, 1):
+        if (d.Cin, d.Cout, d.ntaps, d.Hi, d.Wi, d.sh) == (Cin, Cout, ntaps, HW, HW, stride):
             idxs.append(i)
     if not idxs:
         return None, 0, ""
@@ -282,7 +282,7 @@ def hbm_layers_insitu(ts, batch):
     return out
 
 
-def time_train_step(model, batch, image_size, steps, warmup, dev):
+def time_train_step(model, batch, image_size, steps, warmup, dev, keep=False):
     """ms per fused train step of `model` at per-GPU batch `batch` on this GPU alone (data_parallel=False: the
     single-GPU program even when this process is a rank of a larger job)"""
     from vision_toolbox import backbones
@@ -305,9 +305,30 @@ def time_train_step(model, batch, image_size, steps, warmup, dev):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     loss = ts.loss()
+    if keep:
+        return ms, loss, ts
     del ts
     torch.cuda.empty_cache()
     return ms, loss
+
+
+def layer_rows(ts, batch, shapes):
+    """`roofline_layers` rows measured in situ (insitu_layer_times): shapes = (Cin, Cout, taps, H, stride, launches per step,
+    which passes).  The data gradient of a layer Cin -> Cout is the stride-1 conv Cout -> Cin over dz."""
+    rows = []
+    for (ci, co, nt, hw, st, cnt, passes) in shapes:
+        ho = hw // st
+        fl = 2.0 * batch * ho * ho * co * nt * ci
+        row = {"layer": f"conv{'3x3' if nt == 9 else '1x1'} s{st} {ci}->{co} @{hw}x{hw} B={batch} (M={batch * ho * ho} N={co} K={nt * ci})",
+               "launches_per_step": cnt, "gflop": round(fl / 1e9, 2)}
+        for which in passes:
+            a, b = (co, ci) if which == "dgrad" else (ci, co)
+            ms_l, n_l, kname = insitu_layer_times(ts, a, b, nt, hw, reps=2, which=which, stride=st)
+            if ms_l:
+                row[which] = {"ms": round(ms_l, 4), "tflops": round(fl / ms_l / 1e9, 1),
+                              "frac": round(fl / ms_l / 1e9 / PEAK_BF16_TFLOPS, 4), "kernel": kname, "launches_timed": n_l}
+        rows.append(row)
+    return rows
 
 
 def secondary_configs(dev):
@@ -316,11 +337,17 @@ def secondary_configs(dev):
 
     out = []
     # configs[3]: VoVNet-39 forward+backward bf16, batch 256 (the same fused train step); 3 x 15.530 GFLOP per image
-    ms, loss = time_train_step("vovnet39", 256, 224, 8, 3, dev)
+    ms, loss, ts = time_train_step("vovnet39", 256, 224, 8, 3, dev, keep=True)
+    ts.step()  # (creates the side stream the in-situ pieces run on)
+    # VoVNet-39's dominant layer (128 -> 128 3x3 @56x56, five per step, 29.8 % of its MACs) and the first concat 1x1
+    vrows = layer_rows(ts, 256, [(128, 128, 9, 56, 1, 5, ("fwd", "dgrad", "wgrad")),
+                                 (768, 256, 1, 56, 1, 1, ("fwd", "dgrad", "wgrad"))])
+    del ts
+    torch.cuda.empty_cache()
     out.append({"config": "BASELINE configs[3]: VoVNet-39 train step (fwd+CE+bwd+SGD) bf16, batch 256 @224",
                 "ms": round(ms, 3), "images_per_sec": round(256 / ms * 1e3, 1),
                 "tflops": round(3 * 15.530 * 256 / ms, 1), "roofline_frac": round(3 * 15.530 * 256 / ms / PEAK_BF16_TFLOPS, 4),
-                "final_loss": round(loss, 4)})
+                "final_loss": round(loss, 4), "roofline_layers": vrows})
     # configs[4]: Darknet-YOLOv5x get_feature_maps() multi-scale forward, batch 64 @640 (module API, eval, no_grad)
     torch.manual_seed(0)
     m = backbones.darknet_yolov5x().to(dev).eval()
@@ -699,6 +726,11 @@ def main():
                 if which == "fwd" and insitu is None:
                     insitu = {"ms": ms_l, "n": n_l, "kernel": kname, "tflops": fl / ms_l / 1e9, "flops": fl, "shape": row["layer"]}
             layers.append(row)
+        if args.model == "cspdarknet53" and args.image_size == 224:
+            # the stride-2 3x3 convs that open the stages (24.8 % of the MACs): forward and filter gradient in situ
+            layers += layer_rows(ts, args.batch, [(32, 64, 9, 224, 2, 1, ("fwd", "wgrad")), (64, 128, 9, 112, 2, 1, ("fwd", "wgrad")),
+                                                  (128, 256, 9, 56, 2, 1, ("fwd", "wgrad")), (256, 512, 9, 28, 2, 1, ("fwd", "wgrad")),
+                                                  (512, 1024, 9, 14, 2, 1, ("fwd", "wgrad"))])
         standalone = conv_roofline(args.batch, 128, 28, N.VT_BF16)
         standalone_name = N.last_kernel_name()
         dom = insitu or {"ms": standalone["ms"], "n": 30, "kernel": standalone_name, "tflops": standalone["tflops"],
