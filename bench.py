@@ -625,6 +625,24 @@ def main():
     coll = args.collectives
     if coll == "auto":
         coll = "rccl" if (world > 1 and backend == "nccl" and args.exchange == "allreduce" and not args.graphs) else "torch"
+    if coll == "rccl" and args.collectives == "auto":
+        # the library's communicator is collective to create: agree on the outcome, and fall back to torch.distributed on
+        # EVERY rank if it could not be made on any of them (the line reports which form ran: config.collectives)
+        from vision_toolbox.distributed import ensure_library_comm
+
+        ok = 1
+        try:
+            ensure_library_comm(None, dev)
+        except Exception as e:  # noqa: BLE001
+            ok = 0
+            print(f"[bench rank {rank}] library RCCL communicator unavailable ({e!r}); falling back to torch.distributed",
+                  file=sys.stderr, flush=True)
+        flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            coll = "torch"
+            if ok:
+                N.lib().vt_comm_destroy()
     ts = TrainStep(bb, 1000, args.batch, args.image_size, torch.bfloat16, lr=0.05, momentum=0.9, weight_decay=2e-5,
                    label_smoothing=0.1, device=dev, bucket_mb=args.bucket_mb, use_graphs=args.graphs,
                    sync_bn=args.sync_bn, deterministic=True if args.deterministic else None, exchange=args.exchange,

@@ -38,19 +38,27 @@ def main():
     deep = name == "cspdarknet53"
     ncls, B, S, steps, lr, wd = (16, 8, 96, 2, 2e-4, 1e-3) if deep else (16, 4, 64, 2, 2e-3, 1e-3)
     sync_bn = os.environ.get("DDP_CHECK_SYNCBN", "0") == "1"
+    # DDP_CHECK_COLLECTIVES=rccl: the collectives as launch-list ops through the library's own RCCL communicator -- TWO RCCL
+    # ranks on one device; RCCL builds that refuse a duplicate device end here with its error text (then only the
+    # one-rank check, tools/rccl_world1_check.py, covers that path on a one-GPU box)
+    collectives = os.environ.get("DDP_CHECK_COLLECTIVES", "torch")
     torch.cuda.set_device(0)
     xs = [filler.images(B, S, seed=1000 + r) for r in range(world)]
     ys = [filler.labels(B, ncls, seed=2000 + r) for r in range(world)]
 
     torch.manual_seed(rank)  # ranks start from DIFFERENT weights; the broadcast must fix that
     ts = TrainStep(getattr(backbones, name)(), ncls, B, S, torch.float32, lr=lr, momentum=0.9, weight_decay=wd,
-                   label_smoothing=0.1, device="cuda:0", bucket_mb=8.0 if deep else 0.25, use_graphs=False, sync_bn=sync_bn)
+                   label_smoothing=0.1, device="cuda:0", bucket_mb=8.0 if deep else 0.25, use_graphs=False, sync_bn=sync_bn,
+                   collectives=collectives)
     if rank == 0:
         filler.fill_module(ts.model, "ddp.")
         ts.weights_changed()
     ts.broadcast_parameters(0)
-    assert ts.world == world and ts.bucketer is not None and len(ts.bucketer.buckets) >= 3, "want several buckets"
-    assert len(ts.bwd_cuts) >= 2, "backward must be cut into bucket-completing segments"
+    if collectives == "rccl":
+        assert ts.world == world and ts.bucketer is None and len(ts.inline_buckets) >= 3, "want several buckets"
+    else:
+        assert ts.world == world and ts.bucketer is not None and len(ts.bucketer.buckets) >= 3, "want several buckets"
+        assert len(ts.bwd_cuts) >= 2, "backward must be cut into bucket-completing segments"
     init = {k: v.detach().clone().cpu() for k, v in ts.model.state_dict().items()}
     before = N.launch_count()
     for _ in range(steps):
