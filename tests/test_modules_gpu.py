@@ -435,3 +435,27 @@ def test_accumulates_into_existing_grad_and_works_with_torch_optim():
     assert not torch.equal(w0, m.conv.weight.detach())
     y = m(x)  # runs with the updated weights without any manual sync
     assert torch.isfinite(y).all()
+
+
+@pytest.mark.parametrize("training", [True, False], ids=["train", "eval"])
+@pytest.mark.parametrize("name,shape", [("darknet19", (2, 3, 75, 91)), ("cspdarknet53", (3, 3, 160, 96)),
+                                        ("vovnet27_slim", (2, 3, 75, 91)), ("darknet_yolov5s", (5, 3, 64, 200)),
+                                        ("vovnet39", (2, 3, 130, 130)), ("cspdarknet53", (1, 3, 33, 47))],
+                         ids=lambda v: v if isinstance(v, str) else "x".join(map(str, v)))
+def test_odd_input_shapes_match_the_oracle(name, shape, training):
+    """The reference takes any image size (backbones/darknet.py:83-87, vovnet.py:100-104: stride-2 convs and
+    MaxPool2d(3, 2, 1) on odd maps, non-square images, batch sizes that are no multiple of anything): every feature map
+    of the f32 path against the CPU oracle on inputs that are not 224 x 224 (tools/odd_shapes_check.py runs the full
+    grid of 5 models x 5 shapes x 2 modes)."""
+    m = getattr(backbones, name)()
+    filler.fill_module(m, f"odd.{name}.")
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = filler.tensor(f"odd{shape}", shape)
+    ref = R.feature_maps(name, sd, x, training)
+    m = m.cuda().train(training)
+    with torch.no_grad():
+        maps = m.get_feature_maps(x.cuda())
+    assert [tuple(t.shape) for t in maps] == [tuple(t.shape) for t in ref]
+    for got, want in zip(maps, ref):
+        # (a train-mode map of four values per channel -- 33 x 47 at stride 32 -- amplifies f32 rounding: 2e-3 there)
+        assert rel_err(got.cpu(), want) < (2e-3 if min(want.shape[2:]) <= 2 and training else 2e-4)
