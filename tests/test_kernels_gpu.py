@@ -712,3 +712,19 @@ def test_bn_apply_fused_with_the_max_pool_and_its_backward(dtype, shape, with_re
                                        1, dtype, stream()))
     torch.cuda.synchronize()
     assert torch.equal(torch.isnan(dz0), torch.isnan(dz1)) and torch.equal(torch.nan_to_num(dz0.float()), torch.nan_to_num(dz1.float()))
+
+
+def test_collective_entry_points_through_the_c_abi_in_subprocess():
+    """vt_comm_unique_id / vt_comm_init / vt_allreduce_bucket / vt_stat_sync / vt_comm_destroy (include/vt_amd.h; DDP's
+    bucket all-reduce and SyncBatchNorm's statistics exchange, configs/base.yaml:17-22) driven through ctypes alone over a
+    one-rank communicator, their error returns included (tools/comm_abi_check.py; a child process: the communicator is
+    per process)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / "tools" / "comm_abi_check.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "COMM_ABI_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    buf = torch.zeros(16, device="cuda")
+    N.check(N.lib().vt_memset(vp(buf), 0, 64, stream()))
