@@ -258,6 +258,9 @@ typedef struct vt_pw_desc {
     int32_t ldw[2];
 } vt_pw_desc;
 int vt_pw_supported(int32_t dtype, int32_t K, int32_t C0, int32_t C1);
+/* the apply pass ALONE (inference: folded running statistics), one output group: additionally the 80-channel shapes of
+ * YOLOv5x's first stage (80 -> 80, 160 -> 80), which are no multiples of 32 (darknet.py:124-133 at width 1.25) */
+int vt_pw_apply_supported(int32_t dtype, int32_t K, int32_t C0);
 int vt_pw_fwd_stats(const vt_pw_desc* d, float* const* stats, void* stream);
 int vt_pw_fwd_apply(const vt_pw_desc* d, const float* coef, void* const* y, const int32_t* ldy,
                     const void* const* res, const int32_t* ldr, void* stream);

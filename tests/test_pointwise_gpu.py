@@ -206,3 +206,40 @@ def test_pointwise_passes_agree_with_the_unfused_kernels():
     torch.cuda.synchronize()
     neq = (y_u != y_f).float().mean().item()
     assert neq < 0.02 and rel_err(y_f, y_u.double()) < 2e-3, neq
+
+
+@pytest.mark.parametrize("M,K,slack,relu,with_res", [(1555, 80, 0, True, True), (2048, 80, 16, False, False),
+                                                     (1111, 160, 0, True, False), (16 * 64, 160, 32, True, True)],
+                         ids=lambda v: str(v))
+def test_apply_pass_on_the_80_channel_shapes(M, K, slack, relu, with_res):
+    """Round 4: the apply pass ALONE on channel counts that are no multiples of 32 -- YOLOv5x's first stage in inference
+    (80 -> 80 bottleneck conv1, 160 -> 80 CSP conv1 / conv2: darknet.py:124-133 at width 1.25; components.py:26-44 with
+    running statistics) -- against float64 on the same bf16 operands.  The kernel is 96 wide: filter rows / columns and
+    coefficients beyond 80 do not exist, stores beyond them are masked and x / residual loads beyond them read the pixel's
+    first bytes; operands sit in NaN-filled wider buffers (slices) and the outputs' neighbours must stay NaN."""
+    Cout = 80
+    lib = N.lib()
+    assert lib.vt_pw_apply_supported(N.VT_BF16, K, Cout) == 1 and lib.vt_pw_supported(N.VT_BF16, K, Cout, 0) == 0
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(M + K)
+    x = _rows(M, K, slack, gen)
+    w = (torch.randn(Cout, K, device="cuda", generator=gen) * (2.0 / K) ** 0.5).to(BF)
+    d = _desc(x, [w], relu)
+    zb = (x.double() @ w.double().T).to(BF).double()
+    scale = torch.rand(Cout, device="cuda", generator=gen) + 0.5
+    shift = torch.randn(Cout, device="cuda", generator=gen) * 0.3
+    coef = torch.stack([scale, shift, torch.zeros_like(scale), torch.ones_like(scale)]).contiguous()
+    ywide = torch.full((M, Cout + 32), float("nan"), device="cuda", dtype=BF)
+    y = ywide[:, 16: 16 + Cout]
+    res = _rows(M, Cout, slack, gen, 0.5) if with_res else None
+    N.check(lib.vt_pw_fwd_apply(C.byref(d), coef.data_ptr(), _vps([y]), _arr(C.c_int32, [y.stride(0)]), _vps([res]),
+                                _arr(C.c_int32, [res.stride(0) if res is not None else 0]), stream()))
+    torch.cuda.synchronize()
+    pre = zb * scale.double() + shift.double()
+    ref = (torch.relu(pre) if relu else pre) + (res.double() if res is not None else 0.0)
+    assert not torch.isnan(y.float()).any()
+    assert rel_err(y, ref) < 4e-3 and ((y.double() - ref).abs() / (ref.abs() + 1.0)).max().item() < 0.05
+    assert torch.isnan(ywide[:, :16].float()).all() and torch.isnan(ywide[:, 16 + Cout:].float()).all()
+    # the statistics / backward passes have no such shapes: they must refuse, not run a wrong kernel
+    stats = N.stats_buffer(Cout)
+    assert lib.vt_pw_fwd_stats(C.byref(d), _vps([stats]), stream()) == N.VT_ERR_UNSUPPORTED

@@ -89,6 +89,11 @@ struct PwArgs {
     int lddz[2];
     int relu;
     int nunits;  // ceil(M / 16)
+    // apply pass with channel counts that are no multiples of 32 (YOLOv5x's 80-channel stage in inference, round 4): the
+    // kernel is the next multiple of 32 wide and these are the real widths -- filter rows / columns, coefficients and
+    // outputs beyond them do not exist (zero rows / columns of the LDS image, masked stores), and an x or residual load
+    // beyond them reads the pixel's first 16 bytes instead (times a zero filter column / never stored)
+    int Nr, Kr;
 };
 
 __device__ __forceinline__ uint4 ldg16(const bf16_t* p) { return *(const uint4*)p; }
@@ -139,7 +144,8 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwArgs a) {
         const int n = idx / (K / 8), ch = idx - n * (K / 8);
         const int g = n >= N0;
         const bf16_t* src = a.w[g] + (long)(n - (g ? N0 : 0)) * a.ldw[g] + ch * 8;
-        *(uint4*)(sW + n * PITCH + ch * 16) = ldg16(src);
+        const bool real = n < a.Nr && ch * 8 < a.Kr;
+        *(uint4*)(sW + n * PITCH + ch * 16) = real ? ldg16(src) : make_uint4(0, 0, 0, 0);
     }
     if (MODE != PW_STATS) {
         for (int i = tid; i < 5 * N; i += 256) {
@@ -153,8 +159,8 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwArgs a) {
                     const int g = n >= N0, Cg = g ? N - N0 : N0;
                     v = a.bcoef[g][(which - 2) * Cg + (n - (g ? N0 : 0))];
                 }
-            } else if (which < 4) {
-                v = a.coef[which * N + n];  // scale | shift | mean | invstd
+            } else if (which < 4 && n < a.Nr) {
+                v = a.coef[which * a.Nr + n];  // scale | shift | mean | invstd
             }
             sCoef[i] = v;
         }
@@ -237,7 +243,7 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwArgs a) {
         const long p = (long)unit * 16 + pl;
         const long pc = p < a.M ? p : a.M - 1;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) r.x[s] = ldg16(a.x + pc * a.ldx + 32 * s + 8 * q);
+        for (int s = 0; s < KS; ++s) r.x[s] = ldg16(a.x + pc * a.ldx + (32 * s + 8 * q < a.Kr ? 32 * s + 8 * q : 0));
         if constexpr (MODE >= PW_REDUCE) {
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
@@ -249,7 +255,8 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwArgs a) {
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const int g = group_of(u);
-                if constexpr (EX) r.ex[u] = ldg16(a.res[g] + pc * a.ldr[g] + (32 * u - (g ? N0 : 0)) + 8 * q);
+                if constexpr (EX)
+                    r.ex[u] = ldg16(a.res[g] + pc * a.ldr[g] + (32 * u + 8 * q < a.Nr ? (32 * u - (g ? N0 : 0)) + 8 * q : 0));
             }
         }
         if constexpr (MODE == PW_BWD) {
@@ -309,7 +316,8 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwArgs a) {
                         v[e] = a.relu ? fmaxf(v[e], 0.f) : v[e];
                         v[e] += rr[e];
                     }
-                    if (ok) *(uint4*)(a.y[g] + p * a.ldy[g] + (32 * u - (g ? N0 : 0)) + 8 * q) = VecIO<bf16_t>::pack(v);
+                    if (ok && 32 * u + 8 * q < a.Nr)
+                        *(uint4*)(a.y[g] + p * a.ldy[g] + (32 * u - (g ? N0 : 0)) + 8 * q) = VecIO<bf16_t>::pack(v);
                 } else {
                     float gy[8];
                     VecIO<bf16_t>::unpack(r.dy[u], gy);
@@ -524,6 +532,11 @@ int dispatch_pw(int N, int K, const PwArgs& a, hipStream_t st, const char* who) 
     VT_PW_CASE(160, 160)
     VT_PW_CASE(160, 320)
 #undef VT_PW_CASE
+    if constexpr (MODE == PW_APPLY) {
+        // the 80-channel shapes: one 32-channel unit more than fits, real widths in a.Nr / a.Kr
+        if (N == 80 && K == 80) return ex ? launch_pw<96, 96, MODE, true>(a, st, who) : launch_pw<96, 96, MODE, false>(a, st, who);
+        if (N == 80 && K == 160) return ex ? launch_pw<96, 160, MODE, true>(a, st, who) : launch_pw<96, 160, MODE, false>(a, st, who);
+    }
     vt_set_error("%s: no pointwise kernel for %d -> %d channels", who, K, N);
     return VT_ERR_UNSUPPORTED;
 }
@@ -533,14 +546,17 @@ bool shape_ok(int N, int K) {
            (N == 64 && K == 128) || (N == 160 && K == 160) || (N == 160 && K == 320);
 }
 
-int fill_common(PwArgs& a, const vt_pw_desc* d, const char* who) {
+bool ragged_apply_ok(int N, int K, int ngroups) { return ngroups == 1 && N == 80 && (K == 80 || K == 160); }
+
+int fill_common(PwArgs& a, const vt_pw_desc* d, const char* who, bool apply = false) {
     VT_REQUIRE(d, VT_ERR_INVALID, "%s: null descriptor", who);
     VT_REQUIRE(d->dtype == VT_BF16, VT_ERR_UNSUPPORTED, "%s: bf16 only", who);
     VT_REQUIRE(d->M > 0 && d->M < 0x7fffffffL * 16, VT_ERR_INVALID, "%s: bad M", who);
     VT_REQUIRE(d->ngroups == 1 || d->ngroups == 2, VT_ERR_INVALID, "%s: ngroups %d", who, d->ngroups);
     const int N = d->C[0] + (d->ngroups == 2 ? d->C[1] : 0);
-    VT_REQUIRE(shape_ok(N, d->K), VT_ERR_UNSUPPORTED, "%s: no pointwise kernel for %d -> %d channels", who, d->K, N);
-    VT_REQUIRE(d->C[0] > 0 && d->C[0] % 32 == 0 && (d->ngroups == 1 || (d->C[1] > 0 && d->C[1] % 32 == 0)),
+    const bool ragged = apply && ragged_apply_ok(N, d->K, d->ngroups);
+    VT_REQUIRE(ragged || shape_ok(N, d->K), VT_ERR_UNSUPPORTED, "%s: no pointwise kernel for %d -> %d channels", who, d->K, N);
+    VT_REQUIRE(ragged || (d->C[0] > 0 && d->C[0] % 32 == 0 && (d->ngroups == 1 || (d->C[1] > 0 && d->C[1] % 32 == 0))),
                VT_ERR_UNSUPPORTED, "%s: group widths must be multiples of 32", who);
     VT_REQUIRE(d->x && vt_aligned16(d->x) && d->ldx % 8 == 0 && d->ldx >= d->K, VT_ERR_INVALID, "%s: bad x", who);
     VT_REQUIRE(d->M * (int64_t)d->ldx < 0x7fffffff00LL, VT_ERR_UNSUPPORTED, "%s: tensor too large", who);
@@ -551,6 +567,7 @@ int fill_common(PwArgs& a, const vt_pw_desc* d, const char* who) {
     a.N0 = d->C[0];
     a.relu = d->relu;
     a.nunits = (int)((d->M + 15) / 16);
+    a.Nr = N, a.Kr = d->K;
     for (int g = 0; g < d->ngroups; ++g) {
         VT_REQUIRE(d->w[g] && vt_aligned16(d->w[g]) && d->ldw[g] % 8 == 0 && d->ldw[g] >= d->K, VT_ERR_INVALID,
                    "%s: bad weights of group %d", who, g);
@@ -578,6 +595,10 @@ int vt_pw_supported(int32_t dtype, int32_t K, int32_t C0, int32_t C1) {
     return N * K <= 4096 ? 2 : 1;
 }
 
+int vt_pw_apply_supported(int32_t dtype, int32_t K, int32_t C0) {
+    return dtype == VT_BF16 && (shape_ok(C0, K) || ragged_apply_ok(C0, K, 1));
+}
+
 int vt_pw_fwd_stats(const vt_pw_desc* d, float* const* stats, void* stream) {
     PwArgs a;
     int rc = fill_common(a, d, "vt_pw_fwd_stats");
@@ -592,7 +613,7 @@ int vt_pw_fwd_stats(const vt_pw_desc* d, float* const* stats, void* stream) {
 int vt_pw_fwd_apply(const vt_pw_desc* d, const float* coef, void* const* y, const int32_t* ldy, const void* const* res,
                     const int32_t* ldr, void* stream) {
     PwArgs a;
-    int rc = fill_common(a, d, "vt_pw_fwd_apply");
+    int rc = fill_common(a, d, "vt_pw_fwd_apply", true);
     if (rc != VT_OK) return rc;
     VT_REQUIRE(coef && y && ldy, VT_ERR_INVALID, "vt_pw_fwd_apply: null argument");
     a.coef = coef;

@@ -230,6 +230,7 @@ SYMBOLS = {
     "vt_stem_bn_bwd_s2": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "vt_bn_act_bwd_apply": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "vt_pw_supported": (_i32, [_i32, _i32, _i32, _i32]),
+    "vt_pw_apply_supported": (_i32, [_i32, _i32, _i32]),
     "vt_pw_fwd_stats": (_i32, [C.POINTER(PwDesc), C.POINTER(_vp), _vp]),
     "vt_pw_fwd_apply": (_i32, [C.POINTER(PwDesc), _vp, C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_vp), C.POINTER(_i32), _vp]),
     "vt_pw_bwd_reduce": (_i32, [C.POINTER(PwDesc), _vp, C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_vp), _vp]),

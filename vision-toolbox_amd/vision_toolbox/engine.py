@@ -779,7 +779,11 @@ class Builder:
         if x.M * x.C * 2 < self.pointwise_min_mb * 1e6:
             return 0
         cs = [sp[0].out_channels for sp in specs] + [0]
-        return int(N.lib().vt_pw_supported(self.dtype, x.C, cs[0], cs[1]))
+        mode = int(N.lib().vt_pw_supported(self.dtype, x.C, cs[0], cs[1]))
+        if mode == 0 and len(specs) == 1 and not unit_training and not self.need_grad:
+            # inference runs the apply pass alone: also on the 80-channel shapes of YOLOv5x's first stage
+            mode = 1 if N.lib().vt_pw_apply_supported(self.dtype, x.C, cs[0]) else 0
+        return mode
 
     def pw_units(self, x: TRef, specs) -> "list[TRef]":
         """one or two 1x1 ConvNormAct units reading the same tensor x (components.py:26-44; two: CSPDarknetStage's
