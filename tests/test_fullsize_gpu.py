@@ -524,8 +524,9 @@ def test_vovnet_stage_boundaries_train_mode_gradients_at_batch_256(dtype):
     """A two-stage VoVNet (reference backbones/vovnet.py:73-104) at batch 256 @112: stem (3 -> 32 stride 2, 32 -> 32,
     32 -> 64) -> MaxPool2d(3, 2, 1) -> OSABlock(64, 64, 3, 128) -> MaxPool2d(3, 2, 1) -> OSABlock(128, 80, 3, 256): the
     stride-2 conv -> OSA -> max-pool -> OSA chain, i.e. the max-pool writing into the first slice of a concat buffer, its
-    backward (vt_maxpool3x3s2_bwd) routing the slice's accumulated gradient to the arg-max taps, and the stride-2 stem
-    unit's data path.
+    backward routing the slice's accumulated gradient to the arg-max taps, and the stride-2 stem unit's data path.  Since
+    round 4 both pools run INSIDE the producing unit's passes (vt_bn_act_apply_pool; the unit's BatchNorm backward reads the
+    pooled gradient through the taps, vt_bn_act_bwd_reduce_pool / _apply_pool): this is their chain-level check.
 
     f32 kernels against pure float64: the output and the last unit's BatchNorm gradients to 1e-4, every other gradient
     within 8e-3 in L2 (measured 2.0e-3 .. 4.7e-3, flat over the depth of the chain: the conditioning of train-mode
