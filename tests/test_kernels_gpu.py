@@ -214,10 +214,12 @@ def test_conv_filter_gradient(dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=DNAME.get)
-@pytest.mark.parametrize("shape", [(2, 24, 5, 7), (3, 160, 4, 4), (2, 8, 16, 16)], ids=str)
+@pytest.mark.parametrize("shape", [(2, 24, 5, 7), (3, 160, 4, 4), (2, 8, 16, 16), (6, 256, 7, 7), (5, 512, 5, 3), (3, 320, 9, 9)],
+                         ids=str)
 def test_batchnorm_relu_forward_backward_chain(dtype, shape):
     """stats -> finalize -> apply -> bwd reduce -> bwd finalize -> bwd apply vs autograd of
-    F.batch_norm + relu (+ residual), incl. running statistics (components.py:36-44)."""
+    F.batch_norm + relu (+ residual), incl. running statistics (components.py:36-44).  (256 / 512 / 320 channels on small
+    maps: the backward reduction splits the channels over blockIdx.y there, round 4.)"""
     B, Cc, H, W = shape
     M = B * H * W
     z0 = rounded(filler.tensor(f"z{shape}", shape) * 1.5 + 0.3, dtype)

@@ -426,7 +426,7 @@ __global__ void __launch_bounds__(kThreads)
 bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z, int ldz,
                      const float* __restrict__ scale, const float* __restrict__ shift,
                      const float* __restrict__ mean, const float* __restrict__ invstd, long M, int C,
-                     RowMap rm, int relu_flags, float* __restrict__ sums) {
+                     RowMap rm, int relu_flags, float* __restrict__ sums, int Ctot) {
     const int relu = relu_flags & 1;  // bit 1: dev switch, LDS staging of every row lane (the pre-round-2 fold)
     constexpr int EPC = VecIO<T>::EPC;
     // [RT][2][CT*EPC] partial sums: each thread parks its 2*EPC partials, then the first
@@ -439,6 +439,12 @@ bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z
     const int W = rm.CT * EPC;  // channels covered per pass
     const long row0 = (long)(rm.rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * rm.RT * rm.iters + r;
     const int rep = blockIdx.x % kStatReplicas;
+    // blockIdx.y: channel group (C channels each of Ctot; round 4).  On the small maps a block's 2 * C fixed-point atomics
+    // were half of the launch (C = 512 @7x7: 242 blocks x 1024 atomics, 14.6 us of which ~7 in that tail; twice the blocks:
+    // 21.6 us); with C / 64 channel groups and as many fewer row splits a block adds 128.
+    const int cg0 = blockIdx.y * rm.CPR;  // first 16-byte chunk of this group
+    dy += (long)cg0 * EPC, z += (long)cg0 * EPC;
+    scale += cg0 * EPC, shift += cg0 * EPC, mean += cg0 * EPC, invstd += cg0 * EPC;
     for (int cbase = 0; cbase < rm.CPR; cbase += rm.CT) {
         const int col = cbase + tc;
         const bool active = (r < rm.RT) && (col < rm.CPR);
@@ -518,7 +524,7 @@ bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z
                 float acc = 0.f;
                 for (int rr = 0; rr < rows_l; ++rr) acc += sred[(long)(rr * 2 + which) * W + lc];
                 if (which) acc *= invstd[c];
-                vt_stat_add(sums, ((long)rep * 2 + which) * C + c, acc);
+                vt_stat_add(sums, ((long)rep * 2 + which) * Ctot + cg0 * EPC + c, acc);
             }
         }
         __syncthreads();
@@ -1409,16 +1415,19 @@ int vt_bn_act_bwd_reduce(const void* dy, int32_t lddy, const void* z, int32_t ld
     const int epc = vt_epc(dtype);
     // every block ends with 2*C 64-bit atomics into one of the statistics replicas: ~100 ns each when they queue on the same address,
     // so fewer, longer blocks win over grid-filling ones (measured per step: 1024 -> 23.53, 512 -> 23.36, 256 -> 23.27 ms)
-    const int target = (256);
-    RowMap rm = RowMap::make(C, epc, M, target);
+    // channel groups of 64 on the small maps with many channels (see the kernel): the row splits shrink by the same factor
+    const int cgroups = (M <= 65536 && C >= 256 && C % 64 == 0) ? C / 64 : 1;
+    const int Cg = C / cgroups;
+    const int target = (256) / cgroups > 0 ? (256) / cgroups : 1;
+    RowMap rm = RowMap::make(Cg, epc, M, target);
     rm.rev = (vt_bn_order() >> 1) & 1;
     const int inwave_env = (1);
     const bool inwave = inwave_env && rm.CT < 64 && (rm.CT & (rm.CT - 1)) == 0;  // (as in the kernel)
     const int smem = (inwave ? kThreads / 64 : rm.RT) * 2 * rm.CT * epc * (int)sizeof(float);
     VT_DISPATCH_T(dtype, "vt_bn_act_bwd_reduce",
-                  hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(rm.blocks(M)), dim3(kThreads), smem,
+                  hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(rm.blocks(M), cgroups), dim3(kThreads), smem,
                                      (hipStream_t)stream, (const T*)dy, lddy, (const T*)z, ldz, scale, shift,
-                                     mean, invstd, (long)M, C, rm, (relu ? 1 : 0) | (inwave_env ? 0 : 2), sums));
+                                     mean, invstd, (long)M, Cg, rm, (relu ? 1 : 0) | (inwave_env ? 0 : 2), sums, C));
     VT_CHECK_LAUNCH("vt_bn_act_bwd_reduce");
     return VT_OK;
 }
