@@ -716,6 +716,8 @@ def main():
             print(json.dumps({"steps_only": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": round(elapsed / args.steps * 1e3, 3), "final_loss": round(loss, 4)}), flush=True)
         if world > 1:
+            torch.cuda.synchronize()
+            N.lib().vt_comm_destroy()  # (no-op without the library communicator)
             dist.destroy_process_group()
         return
     if rank == 0:
@@ -827,6 +829,8 @@ def main():
         print(json.dumps(out), flush=True)
     barrier()
     if world > 1:
+        torch.cuda.synchronize()
+        N.lib().vt_comm_destroy()  # (no-op without the library communicator)
         dist.destroy_process_group()
 
 
