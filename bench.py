@@ -624,7 +624,10 @@ def main():
     bb = getattr(backbones, args.model)()
     coll = args.collectives
     if coll == "auto":
-        coll = "rccl" if (world > 1 and backend == "nccl" and args.exchange == "allreduce" and not args.graphs) else "torch"
+        # (VT_BENCH_AUTO_RCCL=1: test hook -- take the rccl branch under the gloo test backend too: two ranks on one GPU are
+        #  refused by RCCL, which exercises the agreed fall-back below)
+        nccl_like = backend == "nccl" or os.environ.get("VT_BENCH_AUTO_RCCL", "0") == "1"
+        coll = "rccl" if (world > 1 and nccl_like and args.exchange == "allreduce" and not args.graphs) else "torch"
     if coll == "rccl" and args.collectives == "auto":
         # the library's communicator is collective to create: agree on the outcome, and fall back to torch.distributed on
         # EVERY rank if it could not be made on any of them (the line reports which form ran: config.collectives)
@@ -637,7 +640,7 @@ def main():
             ok = 0
             print(f"[bench rank {rank}] library RCCL communicator unavailable ({e!r}); falling back to torch.distributed",
                   file=sys.stderr, flush=True)
-        flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+        flag = torch.tensor([ok], device=dev if backend == "nccl" else "cpu", dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             coll = "torch"

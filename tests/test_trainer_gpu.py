@@ -264,3 +264,36 @@ def test_deterministic_mode_matches_the_oracle_like_the_default_mode():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     buf = torch.zeros(16, device="cuda")
     N.check(N.lib().vt_memset(buf.data_ptr(), 0, 64, int(torch.cuda.current_stream().cuda_stream)))
+
+
+def test_bench_n2_falls_back_together_when_the_library_communicator_cannot_be_made():
+    """`bench.py --gpus 2` takes the in-list collectives (the library's own RCCL communicator) on the nccl backend; when the
+    communicator cannot be made the ranks AGREE on that and run the torch.distributed form instead.  Two ranks on this one GPU
+    over gloo with the rccl branch forced (VT_BENCH_AUTO_RCCL=1): RCCL refuses two ranks on one device (`vt_comm_init: invalid
+    usage` on both), both report the fall-back, and the JSON line of the run says `"collectives": "torch"` and carries the
+    self-contained N > 1 keys."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, VT_DIST_BACKEND="gloo", VT_FORCE_DEVICE="0", VT_BENCH_AUTO_RCCL="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup",
+                        "1", "--batch", "16"], capture_output=True, text=True, timeout=900, env=env, cwd=str(root))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stderr.count("falling back to torch.distributed") == 2, r.stderr[-3000:]
+    line = json.loads(next(l for l in reversed(r.stdout.splitlines()) if l.startswith("{")))
+    assert line["n_gpus"] == 2 and line["config"]["collectives"] == "torch" and line["config"]["backend"] == "gloo"
+    for key in ("n1_same_per_gpu_batch_ms", "weak_scaling_efficiency", "exchange_exposed_ms"):
+        assert key in line
+    buf = torch.zeros(16, device="cuda")  # the launch-count guard of this module wants a launch here too
+    N.check(N.lib().vt_memset(buf.data_ptr(), 0, 64, int(torch.cuda.current_stream().cuda_stream)))
