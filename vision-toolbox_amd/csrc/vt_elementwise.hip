@@ -244,25 +244,36 @@ bn_bwd_pool_kernel(const T* __restrict__ dp, int lddp, const uint8_t* __restrict
                 if (APPLY) ca[e] = c2[c], cb[e] = c2[C + c], cd[e] = c2[2 * C + c];
                 else ca[e] = 0.f, cb[e] = c2[c], cd[e] = 0.f;
             }
+            // (wo, ho, b) of the thread's first pooled row once (64-bit divisions), then advanced by additions: a step is
+            // rm.RT rows = qstep full rows of Wo + rstep columns (the per-iteration divisions and the twelve 64-bit
+            // multiply chains of the load addresses were a quarter of this loop's vector issue time: 47 v_mul_lo_u32 +
+            // 32 v_mad_u64_u32 per iteration)
+            int wo = (int)(row0 % Wo);
+            long t2_ = row0 / Wo;
+            int ho = (int)(t2_ % Ho);
+            long b = t2_ / Ho;
+            const int qstep = rm.RT / Wo, rstep = rm.RT - qstep * Wo;
             for (int it = 0; it < rm.iters; ++it) {
                 const long row = row0 + (long)it * rm.RT;
                 if (row >= Mo) break;
-                const int wo = (int)(row % Wo);
-                const long t2 = row / Wo;
-                const int ho = (int)(t2 % Ho);
-                const long b = t2 / Ho;
-                // the four windows (clamped coordinates: every load unconditional) and the four owned pixels
+                // the four windows (clamped coordinates: every load unconditional) and the four owned pixels: one base
+                // offset each, the neighbours by clamped deltas
                 uint4 gw[4], vz[4];
                 unsigned aw[4][EPC / 4];
+                const int dwo = wo + 1 < Wo ? 1 : 0, dho = ho + 1 < Ho ? Wo : 0;
+                const int dpw = 2 * wo + 1 < W ? 1 : 0, dph = 2 * ho + 1 < H ? W : 0;
+                const T* dp0 = dp + row * lddp + col * EPC;
+                const uint8_t* am0 = amax + row * C + col * EPC;
+                const T* z0 = z + ((b * H + 2 * ho) * W + 2 * wo) * ldz + col * EPC;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const long orow = (b * Ho + min(ho + (k >> 1), Ho - 1)) * Wo + min(wo + (k & 1), Wo - 1);
-                    gw[k] = ld16(dp + orow * lddp + col * EPC);
-                    const unsigned* ap = (const unsigned*)(amax + orow * C + col * EPC);
+                    const int od = ((k >> 1) ? dho : 0) + ((k & 1) ? dwo : 0);
+                    gw[k] = ld16(dp0 + (long)od * lddp);
+                    const unsigned* ap = (const unsigned*)(am0 + (long)od * C);
 #pragma unroll
                     for (int q = 0; q < EPC / 4; ++q) aw[k][q] = ap[q];
-                    const long pix = (b * H + min(2 * ho + (k >> 1), H - 1)) * W + min(2 * wo + (k & 1), W - 1);
-                    vz[k] = ld16(z + pix * ldz + col * EPC);
+                    const int pd = ((k >> 1) ? dph : 0) + ((k & 1) ? dpw : 0);
+                    vz[k] = ld16(z0 + (long)pd * ldz);
                 }
                 float gf[4][EPC];
 #pragma unroll
@@ -300,6 +311,9 @@ bn_bwd_pool_kernel(const T* __restrict__ dp, int lddp, const uint8_t* __restrict
                     }
                     if (APPLY) st16(dz + ((b * H + h) * W + w) * lddz + col * EPC, VecIO<T>::pack(g));
                 }
+                wo += rstep, ho += qstep;
+                if (wo >= Wo) wo -= Wo, ++ho;
+                while (ho >= Ho) ho -= Ho, ++b;
             }
         }
         if constexpr (!APPLY) {
@@ -358,20 +372,27 @@ bn_act_apply_pool_kernel(const T* __restrict__ z, int ldz, const float* __restri
         float sc[EPC], sf[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) sc[e] = scale[col * EPC + e], sf[e] = shift[col * EPC + e];
+        int wo = (int)(row0 % Wo);
+        long t2_ = row0 / Wo;
+        int ho = (int)(t2_ % Ho);
+        long b = t2_ / Ho;
+        const int qstep = rm.RT / Wo, rstep = rm.RT - qstep * Wo;
         for (int it = 0; it < rm.iters; ++it) {
             const long row = row0 + (long)it * rm.RT;
             if (row >= Mo) break;
-            const int wo = (int)(row % Wo);
-            const long t2 = row / Wo;
-            const int ho = (int)(t2 % Ho);
-            const long b = t2 / Ho;
             uint4 rz[9], rr[kRes ? 9 : 1];
+            // the window's nine pixels from ONE base offset (its centre, always inside the map) and clamped row / column
+            // deltas: additions instead of nine 64-bit multiply chains
+            const long pc = (b * H + 2 * ho) * W + 2 * wo;
+            const int dh_[3] = {ho > 0 ? -W : 0, 0, 2 * ho + 1 < H ? W : 0};
+            const int dw_[3] = {wo > 0 ? -1 : 0, 0, 2 * wo + 1 < W ? 1 : 0};
+            const T* zc = z + pc * ldz + col * EPC;
+            const T* rc = kRes ? res + pc * ldr + col * EPC : nullptr;
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                const int h = min(max(ho * 2 - 1 + k / 3, 0), H - 1), w = min(max(wo * 2 - 1 + k % 3, 0), W - 1);
-                const long pix = (b * H + h) * W + w;
-                rz[k] = ld16(z + pix * ldz + col * EPC);
-                if (kRes) rr[k] = ld16(res + pix * ldr + col * EPC);
+                const int dpx = dh_[k / 3] + dw_[k % 3];
+                rz[k] = ld16(zc + (long)dpx * ldz);
+                if (kRes) rr[k] = ld16(rc + (long)dpx * ldr);
             }
             float best[EPC];
             int bi[EPC];
@@ -414,6 +435,9 @@ bn_act_apply_pool_kernel(const T* __restrict__ z, int ldz, const float* __restri
 #pragma unroll
             for (int q = 0; q < EPC / 4; ++q)
                 ap[q] = (unsigned)bi[4 * q] | ((unsigned)bi[4 * q + 1] << 8) | ((unsigned)bi[4 * q + 2] << 16) | ((unsigned)bi[4 * q + 3] << 24);
+            wo += rstep, ho += qstep;
+            if (wo >= Wo) wo -= Wo, ++ho;
+            while (ho >= Ho) ho -= Ho, ++b;
         }
     }
 }
