@@ -55,13 +55,6 @@ template <typename T>
 __device__ __forceinline__ uint4 ld16(const T* p) { return *(const uint4*)p; }
 template <typename T>
 __device__ __forceinline__ void st16(T* p, const uint4& v) { *(uint4*)p = v; }
-// EXPERIMENT: streaming (non-temporal) 16-byte store
-typedef __attribute__((ext_vector_type(4))) unsigned int vt_u32x4;
-template <typename T>
-__device__ __forceinline__ void st16_nt(T* p, const uint4& v, int nt) {
-    if (nt) __builtin_nontemporal_store(vt_u32x4{v.x, v.y, v.z, v.w}, (vt_u32x4*)p);
-    else *(uint4*)p = v;
-}
 
 // ---------------------------------------------------------------------------------
 // BatchNorm finalize (training): stats -> mean / invstd / scale / shift + running stats
@@ -150,8 +143,6 @@ __global__ void __launch_bounds__(kThreads)
 bn_act_apply_kernel(const T* __restrict__ z, int ldz, const float* __restrict__ scale,
                     const float* __restrict__ shift, const T* __restrict__ res, int ldr, T* __restrict__ y,
                     int ldy, long M, RowMap rm, int relu) {
-    const int nt = relu >> 4;
-    relu &= 1;
     constexpr int EPC = VecIO<T>::EPC;
     const int t = threadIdx.x;
     const int r = t / rm.CT;
@@ -201,7 +192,7 @@ bn_act_apply_kernel(const T* __restrict__ z, int ldz, const float* __restrict__ 
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) v[e] += rr[e];
                 }
-                if (ok[u]) st16_nt(py + (it + u) * sy, VecIO<T>::pack(v), nt);
+                if (ok[u]) st16(py + (it + u) * sy, VecIO<T>::pack(v));
             }
         }
     }
@@ -596,8 +587,6 @@ bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z,
                     const float* __restrict__ scale, const float* __restrict__ shift,
                     const float* __restrict__ coef, T* __restrict__ dz, int lddz, long M, int C, RowMap rm,
                     int relu) {
-    const int nt = relu >> 4;
-    relu &= 1;
     constexpr int EPC = VecIO<T>::EPC;
     const int t = threadIdx.x;
     const int r = t / rm.CT;
@@ -639,7 +628,7 @@ bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z,
                     const float gg = (!relu || fmaf(zz[e], sc[e], sf[e]) > 0.f) ? g[e] : 0.f;
                     g[e] = fmaf(ca[e], gg, fmaf(-cb[e], zz[e], cd[e]));
                 }
-                st16_nt(dz + row * lddz + col * EPC, VecIO<T>::pack(g), nt);
+                st16(dz + row * lddz + col * EPC, VecIO<T>::pack(g));
             }
         }
     }
@@ -1425,18 +1414,16 @@ int vt_bn_act_apply(const void* z, int32_t ldz, const float* scale, const float*
     if (residual) VT_TRY(check_mat("vt_bn_act_apply(residual)", residual, ldr, C, dtype));
     RowMap rm = RowMap::make(C, vt_epc(dtype), M);
     rm.rev = (vt_bn_order() >> 0) & 1;
-    const int nt_mb = VT_KNOB("VT_BN_NT", 0);  // EXPERIMENT: streaming stores from this many MB of output up
-    const int nt_flag = nt_mb > 0 && (double)M * C * (dtype == VT_BF16 ? 2 : 4) >= nt_mb * 1e6;
     if (residual) {
         VT_DISPATCH_T(dtype, "vt_bn_act_apply",
                       VT_LAUNCH_STOP((bn_act_apply_kernel<T, true>), dim3(rm.blocks(M)), dim3(kThreads), 0,
                                      (hipStream_t)stream, (const T*)z, ldz, scale, shift, (const T*)residual,
-                                     ldr, (T*)y, ldy, (long)M, rm, (relu ? 1 : 0) | (nt_flag << 4)));
+                                     ldr, (T*)y, ldy, (long)M, rm, relu));
     } else {
         VT_DISPATCH_T(dtype, "vt_bn_act_apply",
                       VT_LAUNCH_STOP((bn_act_apply_kernel<T, false>), dim3(rm.blocks(M)), dim3(kThreads), 0,
                                      (hipStream_t)stream, (const T*)z, ldz, scale, shift, (const T*)residual,
-                                     ldr, (T*)y, ldy, (long)M, rm, (relu ? 1 : 0) | (nt_flag << 4)));
+                                     ldr, (T*)y, ldy, (long)M, rm, relu));
     }
     VT_CHECK_LAUNCH("vt_bn_act_apply");
     return VT_OK;
@@ -1489,12 +1476,10 @@ int vt_bn_act_bwd_apply(const void* dy, int32_t lddy, const void* z, int32_t ldz
     VT_TRY(check_mat("vt_bn_act_bwd_apply(dz)", dz, lddz, C, dtype));
     RowMap rm = RowMap::make(C, vt_epc(dtype), M);
     rm.rev = (vt_bn_order() >> 2) & 1;
-    const int nt_mb = VT_KNOB("VT_BN_NT", 0);  // EXPERIMENT
-    const int nt_flag = nt_mb > 0 && (double)M * C * (dtype == VT_BF16 ? 2 : 4) >= nt_mb * 1e6;
     VT_DISPATCH_T(dtype, "vt_bn_act_bwd_apply",
                   VT_LAUNCH_STOP(bn_bwd_apply_kernel<T>, dim3(rm.blocks(M)), dim3(kThreads), 0,
                                  (hipStream_t)stream, (const T*)dy, lddy, (const T*)z, ldz, scale, shift,
-                                 coef, (T*)dz, lddz, (long)M, C, rm, (relu ? 1 : 0) | (nt_flag << 4)));
+                                 coef, (T*)dz, lddz, (long)M, C, rm, relu));
     VT_CHECK_LAUNCH("vt_bn_act_bwd_apply");
     return VT_OK;
 }
