@@ -131,6 +131,15 @@ int vt_conv_wgrad(const vt_conv_desc* d, const void* x, const void* dz, float* d
 int vt_conv_wgrad_slabs(const vt_conv_desc* d, const void* x, const void* dz, float* dw, int32_t ldgw,
                         void* scratch, int64_t scratch_bytes, void* stream);
 
+/* n filter gradients of ONE descriptor -- same-shape layers, e.g. the 3x3 convs of a stage's DarknetBlocks
+ * (darknet.py:20-28) or of an OSA chain (vovnet.py:41-44) -- in as few launches as the kernels allow: the CU-owning
+ * stride-1 3x3 kernel takes up to 8 layers per launch and pays its prologue and its f32 atomic flush once per launch
+ * (a filter gradient has no consumer before the optimiser, so a caller may hold the layers of a stage back until the
+ * last one's dz exists).  Shapes that kernel does not cover run one by one, exactly as vt_conv_wgrad.  x / dz / dw are
+ * HOST arrays of n device pointers. */
+int vt_conv_wgrad_group(const vt_conv_desc* d, int32_t n, const void* const* x, const void* const* dz,
+                        float* const* dw, int32_t ldgw, void* stream);
+
 /* dst[i] (+)= hi[i]*2^12 + lo[i]/2^33 for a fixed-point buffer q = int64[n][2] (vt_colsum_fixed). */
 int vt_fixed_to_f32(const void* q, float* dst, int64_t n, int32_t accumulate, void* stream);
 

@@ -92,7 +92,16 @@ def main():
             d0, _ = desc_for(B, Cin, Cout, k, s, H, 0)
             ms = timeit(lambda st: N.check(lib.vt_conv_wgrad(ctypes.byref(d0), x.data_ptr(), dz.data_ptr(),
                                                              dw.data_ptr(), k * k * Cin, st)))
-            line += f" | wgrad {ms:7.4f} ms {flops / ms / 1e9:7.1f} TF/s"
+            line += f" | wgrad {ms:7.4f} ms {flops / ms / 1e9:7.1f} TF/s [{N.last_kernel_name()}]"
+            G = int(os.environ.get("VT_BENCH_GROUP", "0"))
+            if G > 1:  # G same-shape layers through vt_conv_wgrad_group (operands of their own: no cache help)
+                xs = [x] + [torch.randn_like(x) for _ in range(G - 1)]
+                dzs = [dz] + [torch.randn_like(dz) for _ in range(G - 1)]
+                dws = [dw] + [torch.zeros_like(dw) for _ in range(G - 1)]
+                arr = lambda ts: (ctypes.c_void_p * G)(*[t.data_ptr() for t in ts])
+                ax, az, aw = arr(xs), arr(dzs), arr(dws)
+                ms = timeit(lambda st: N.check(lib.vt_conv_wgrad_group(ctypes.byref(d0), G, ax, az, aw, k * k * Cin, st)))
+                line += f" | group of {G}: {ms / G:7.4f} ms per layer {flops * G / ms / 1e9:7.1f} TF/s [{N.last_kernel_name()}]"
         print(line, flush=True)
 
 

@@ -360,6 +360,12 @@ int vt_wgrad_span_dispatch(const vt_conv_desc* d, const void* x, const void* dz,
 int vt_wgrad_span_s2_dispatch(const vt_conv_desc* d, const void* x, const void* dz, float* dw, int32_t ldgw,
                               void* stream);
 
+// vt_wgrad6.hip: stride-1 3x3 bf16 layers wider than 32 channels as a CU-owning kernel (one or several same-shape layers
+// per launch); -1 when it does not apply
+int vt_wgrad6_dispatch(const vt_conv_desc* d, const void* x, const void* dz, float* dw, int32_t ldgw, void* stream);
+int vt_wgrad6_group(const vt_conv_desc* d, int G, const void* const* x, const void* const* dz, float* const* dw,
+                    int32_t ldgw, void* stream);
+
 // dw[n][k] += sum over the splits of slab[s][n][k], in split order: the ordered second stage of the filter gradient
 __global__ void __launch_bounds__(256) wgrad_reduce_slabs_kernel(const float* __restrict__ slab, long stride, int split,
                                                                  float* __restrict__ dw, int Cout, int Ktot, int ldgw) {
@@ -407,6 +413,39 @@ extern "C" int vt_conv_wgrad_slabs(const vt_conv_desc* d, const void* x, const v
     return wgrad_impl(d, x, dz, dw, ldgw, (float*)scratch, scratch_bytes, stream);
 }
 
+// n filter gradients of ONE descriptor (same-shape layers: the 3x3 convs of a stage's DarknetBlocks, an OSA chain) in as
+// few launches as the kernels allow: the CU-owning kernel takes up to 8 layers per launch and pays its prologue and its
+// f32 atomic flush once per launch; shapes it does not cover run layer by layer.
+extern "C" int vt_conv_wgrad_group(const vt_conv_desc* d, int32_t n, const void* const* x, const void* const* dz,
+                                   float* const* dw, int32_t ldgw, void* stream) {
+    VT_REQUIRE(d && x && dz && dw && n >= 1, VT_ERR_INVALID, "vt_conv_wgrad_group: bad argument");
+    for (int i = 0; i < n; ++i)
+        VT_REQUIRE(x[i] && dz[i] && dw[i], VT_ERR_INVALID, "vt_conv_wgrad_group: null operand %d", i);
+    const int maxg = VT_KNOB("VT_WGRAD6_GROUP", 8);
+    int i = 0;
+    while (i < n) {
+        int g = n - i < maxg ? n - i : maxg;
+        if (g < 1) g = 1;
+        int rc = -1;
+        if (g > 1) {
+            // (the argument checks of the single-layer entry, which the grouped kernel shares)
+            const long in_elems = (long)d->B * d->Hi * d->Wi * d->ldx;
+            const long M = (long)d->B * d->Ho * d->Wo;
+            if (d->dtype == VT_BF16 && ldgw >= d->ntaps * d->Cin && in_elems < 0x7fffffffL && M * d->ldy < 0x7fffffffL &&
+                d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->oHs == 1 && d->oWs == 1 &&
+                d->oh0 == 0 && d->ow0 == 0 && d->oH == d->Ho && d->oW == d->Wo)
+                rc = vt_wgrad6_group(d, g, x + i, dz + i, dw + i, ldgw, stream);
+        }
+        if (rc == -1) {  // one by one (argument checks, every kernel family)
+            g = 1;
+            rc = wgrad_impl(d, x[i], dz[i], dw[i], ldgw, nullptr, 0, stream);
+        }
+        if (rc != VT_OK) return rc;
+        i += g;
+    }
+    return VT_OK;
+}
+
 static int wgrad_impl(const vt_conv_desc* d, const void* x, const void* dz, float* dw, int32_t ldgw, float* scratch,
                       int64_t scratch_bytes, void* stream) {
     VT_REQUIRE(d && x && dz && dw, VT_ERR_INVALID, "vt_conv_wgrad: null argument");
@@ -428,6 +467,10 @@ static int wgrad_impl(const vt_conv_desc* d, const void* x, const void* dz, floa
     VT_REQUIRE(in_elems < 0x7fffffffL && M * d->ldy < 0x7fffffffL, VT_ERR_UNSUPPORTED,
                "vt_conv_wgrad: tensor exceeds 2^31 elements");
     const bool slabs = scratch && (d->ntaps * d->Cin) % 4 == 0 && ldgw % 4 == 0;
+    if (!scratch) {  // (atomic flush: not in the two-stage / deterministic mode)
+        const int rc = vt_wgrad6_dispatch(d, x, dz, dw, ldgw, stream);
+        if (rc >= 0) return rc;
+    }
     {
         const int rc = vt_wgrad_span_dispatch(d, x, dz, dw, ldgw, slabs ? scratch : nullptr, scratch_bytes, stream);
         if (rc >= 0) return rc;

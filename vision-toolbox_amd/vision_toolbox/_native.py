@@ -221,6 +221,7 @@ SYMBOLS = {
     "vt_bn_act_bwd_reduce": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "vt_bn_bwd_finalize": (_i32, [_vp, _i32, _f64, _f64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "vt_conv_wgrad_slabs": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i32, _vp, _i64, _vp]),
+    "vt_conv_wgrad_group": (_i32, [C.POINTER(ConvDesc), _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i32, _vp]),
     "vt_fixed_to_f32": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "vt_colsum_fixed": (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "vt_stem_bn_bwd_scratch_bytes": (_i64, [_i32]),
