@@ -47,19 +47,32 @@ def main():
     by_pix = defaultdict(lambda: [0.0, 0])
     reps = 5
     for phase, ops, n in (("fwd", p.fwd_ops, p.n_fwd), ("bwd", p.bwd_ops, p.n_bwd)):
+        group_ms = {}  # op index -> per-layer ms of the grouped filter-gradient run it belongs to
         for idx in range(n):
             op = ops[idx]
             kind = op.kind & 0xFFFF
             if kind in (N.OP_FORK, N.OP_JOIN, N.OP_FORK_MARK, N.OP_FORK_WAIT):
                 continue
-            one = (N.Op * 1).from_address(ctypes.addressof(ops) + idx * ctypes.sizeof(N.Op))
-            N.run_ops(one, 1, ts.bases, s)
-            e0, e1 = N.Event(), N.Event()
-            e0.record(s)
-            for _ in range(reps):
-                N.run_ops(one, 1, ts.bases, s)
-            e1.record(s)
-            ms = e0.elapsed_ms(e1) / reps
+            cnt = 1
+            if kind == N.OP_CONV_WGRAD and idx not in group_ms:
+                # a run of same-descriptor filter gradients is ONE grouped call in the step (vt_conv_wgrad_group)
+                dsz = ctypes.sizeof(N.ConvDesc)
+                while (idx + cnt < n and (ops[idx + cnt].kind & 0xFFFF) == kind
+                       and bytes(ops[idx + cnt].i)[:dsz + 4] == bytes(op.i)[:dsz + 4]):
+                    cnt += 1
+            if idx in group_ms:
+                ms = group_ms[idx]
+            else:
+                one = (N.Op * cnt).from_address(ctypes.addressof(ops) + idx * ctypes.sizeof(N.Op))
+                N.run_ops(one, cnt, ts.bases, s)
+                e0, e1 = N.Event(), N.Event()
+                e0.record(s)
+                for _ in range(reps):
+                    N.run_ops(one, cnt, ts.bases, s)
+                e1.record(s)
+                ms = e0.elapsed_ms(e1) / reps / cnt
+                for j in range(1, cnt):
+                    group_ms[idx + j] = ms
             name = N.OP_NAMES.get(kind, str(kind))
             desc, work = "", ""
             if kind in (N.OP_CONV_IGEMM, N.OP_CONV_WGRAD):

@@ -486,6 +486,35 @@ static int run_ops_impl(const vt_op* ops, int32_t n, void* const* bases, int32_t
             }
             if (two && on_side) side_dirty = true;
             i = j - 1;
+        } else if (op.kind == VT_OP_CONV_WGRAD && op.ptr[3].base < 0 && i + 1 < n &&
+                   (ops[i + 1].kind & ~VT_OP_SIDE_STREAM) == VT_OP_CONV_WGRAD) {
+            // consecutive filter gradients of ONE descriptor on one stream (the engine holds the same-shape layers of a
+            // stage back and releases them together): vt_conv_wgrad_group, which shares a launch among up to 8 of them
+            constexpr int DI = (int)(sizeof(vt_conv_desc) / 4);
+            std::vector<const void*> xs, dzs;
+            std::vector<float*> dws;
+            int j = i;
+            bool bad = false;
+            for (; j < n; ++j) {
+                const vt_op& o = ops[j];
+                if ((o.kind & ~VT_OP_SIDE_STREAM) != VT_OP_CONV_WGRAD || ((o.kind & VT_OP_SIDE_STREAM) != 0) != on_side ||
+                    o.ptr[3].base >= 0 || memcmp(o.i, op.i, (DI + 1) * sizeof(int32_t)) != 0)
+                    break;
+                xs.push_back(rp(o, 0, bases, nbases, &bad));
+                dzs.push_back(rp(o, 1, bases, nbases, &bad));
+                dws.push_back((float*)rp(o, 2, bases, nbases, &bad));
+            }
+            if (bad) {
+                vt_set_error("vt_run_ops: a filter-gradient op references an unbound base");
+                rc = VT_ERR_INVALID;
+            } else {
+                vt_conv_desc d;
+                memcpy(&d, op.i, sizeof(d));
+                rc = vt_conv_wgrad_group(&d, (int)xs.size(), xs.data(), dzs.data(), dws.data(), op.i[DI],
+                                         (two && on_side) ? side : stream);
+            }
+            if (two && on_side) side_dirty = true;
+            i = j - 1;
         } else {
             rc = run_one(op, bases, nbases, (two && on_side) ? side : stream);
             if (two && on_side) side_dirty = true;

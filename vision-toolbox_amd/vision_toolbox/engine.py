@@ -265,6 +265,19 @@ class Builder:
         # their toy tensors would otherwise never reach these kernels)
         self.pointwise_min_mb = float(os.environ.get("VT_PW_MIN_MB", "80"))
         self._hoisted: list[N.Op] = []
+        # Filter gradients of same-shape stride-1 3x3 layers (the DarknetBlock.conv2 units of a stage, darknet.py:23-24;
+        # an OSA chain, vovnet.py:41-44) are HELD BACK in backward and released together, as consecutive ops that the
+        # executor hands to vt_conv_wgrad_group in launches of <= wgrad_group layers: the CU-owning kernel
+        # (vt_wgrad6.hip) then pays its prologue and its f32 atomic flush once per launch (isolated, batch 256:
+        # 128 -> 128 @28x28 96 us per layer alone, 64 us in a group of 8; the kernel it replaces: 118 us).  Nothing reads a
+        # filter gradient before the optimiser (or the bucket all-reduce, which is cut behind the op that completes the
+        # bucket), and the arena keeps every x / dz.  VT_WGRAD_GROUP=1: one layer per launch.
+        self.wgrad_group = max(1, min(8, int(os.environ.get("VT_WGRAD_GROUP", "8"))))
+        # ... on the side stream (0) or in line on the main stream (1): the CU-owning kernel shares nothing with the
+        # kernels beside it (12 waves x 168 registers, 104 KiB of LDS), so the side stream buys it no overlap
+        self.wgrad_inline = os.environ.get("VT_WGRAD_INLINE", "0") != "0"
+        self._wg_expect: dict[tuple, int] = {}   # shape key -> units seen in forward and not yet released
+        self._wg_pending: dict[tuple, list] = {}  # shape key -> [(x addr, dz addr, dw addr, desc, ldw)]
         # SyncBatchNorm (configs/base.yaml:22): the trainer all-reduces every layer's statistics
         # between the kernel that accumulates them and the finalize kernel; the finalize kernels
         # are then told the GLOBAL sample count (and scale the affine gradients by 1/world)
@@ -642,6 +655,13 @@ class Builder:
         if pool_out is not None and not pool_fused:
             self.maxpool3x3s2(y, out=pool_out, name=name + ".max_pool")  # (no normalise pass to fuse it into)
 
+        wg_key = None
+        if (track and has_bn and not fused and not stem_fused and not padded and w.requires_grad and dt == N.VT_BF16 and
+                k == 3 and s == 1 and pad == 1 and x.C > 32 and Cout > 32 and self.wgrad_group > 1 and
+                not self.deterministic):
+            wg_key = (B, x.H, x.W, x.C, x.ld, Cout, ldw)
+            self._wg_expect[wg_key] = self._wg_expect.get(wg_key, 0) + 1
+
         if track:
             tag = self.tag
             training = unit_training
@@ -722,6 +742,9 @@ class Builder:
                     if not w.requires_grad:
                         return
                     dfwd = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, dz.ld, ldw, 0)
+                    if wg_key is not None:
+                        self._wgrad_hold(wg_key, x.addr(), dz.addr(), self.pgrad(w), dfwd, ldw)
+                        return
                     self.emit(N.OP_FORK)
                     slab, slab_mb = None, 0
                     if self.wgrad_slab_mb > 0:  # two-stage (stored slabs + ordered reducer) instead of f32 atomics
@@ -891,6 +914,26 @@ class Builder:
         if sa[1] is not None and sb[1] is not None and self._pw_ok(x, [sa, sb]):
             return self.pw_units(x, [sa, sb])
         return [a[0]._vt_emit(self, x, out=a[1], name=a[2]), b[0]._vt_emit(self, x, out=b[1], name=b[2])]
+
+    def _wgrad_hold(self, key, xa, dza, dwa, desc, ldw):
+        """hold a filter gradient back until its shape group is complete (or wgrad_group of them wait), then release the
+        group as consecutive side-stream ops behind ONE fork (the executor gathers them: vt_conv_wgrad_group)."""
+        pend = self._wg_pending.setdefault(key, [])
+        pend.append((xa, dza, dwa, desc, ldw))
+        self._wg_expect[key] -= 1
+        if len(pend) >= self.wgrad_group or self._wg_expect[key] <= 0:
+            self._wgrad_release(key)
+
+    def _wgrad_release(self, key=None):
+        for k_ in ([key] if key is not None else list(self._wg_pending)):
+            pend = self._wg_pending.pop(k_, [])
+            if not pend:
+                continue
+            side = not self.wgrad_inline
+            if side:
+                self.emit(N.OP_FORK)
+            for xa, dza, dwa, desc, ldw in pend:
+                self.emit(N.OP_CONV_WGRAD, [xa, dza, dwa, None], desc=desc, extra_ints=[ldw, 0], side=side)
 
     def _dgrad(self, x: TRef, dz: TRef, wptr, w_dtype, ldw, Cout, k, s, pad, Ho, Wo):
         dt = self.dtype
@@ -1159,6 +1202,7 @@ class Builder:
         self._cur = self.bwd
         for node in reversed(self.nodes):
             node()
+        self._wgrad_release()  # (groups whose units did not all reach backward: a branch without gradient)
         self.emit(N.OP_JOIN)  # all filter gradients done before anything reads the gradient buffers
         self._cur = self.fwd
         if self._hoisted:
