@@ -492,6 +492,11 @@ int vt_graph_destroy(void* graph);
 #define VT_COMM_ID_BYTES 128
 int vt_comm_unique_id(void* id128);
 int vt_comm_init(const void* id128, int32_t rank, int32_t world);
+/* Optional second communicator over the same ranks (a second id, drawn and carried like the first), used by
+ * vt_stat_sync only: RCCL serialises the operations of ONE communicator in issue order across streams, so the per-layer
+ * statistics exchanges (main stream) would otherwise queue behind the bucket all-reduces (filter-gradient stream). */
+int vt_comm_init_stat(const void* id128);
+int vt_comm_has_stat(void);
 int vt_comm_world(void); /* ranks of this process's communicator, 0 without one */
 int vt_comm_destroy(void);
 /* in-place sum all-reduce of `count` elements (VT_F32 / VT_BF16 gradients, VT_I64 fixed-point sums) on `stream` */

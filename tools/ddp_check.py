@@ -116,7 +116,7 @@ def main():
             for k in (rv[0], rv[-1]):
                 err = ((got[k].cpu() - sd[k]).norm() / sd[k].norm()).item()
                 assert err < 5e-3, (k, err)
-        print(f"DDP_CHECK_OK sync_bn={sync_bn} world={world} buckets={len(ts.bucketer.buckets)} segments={len(ts.bwd_cuts)} "
+        print(f"DDP_CHECK_OK sync_bn={sync_bn} world={world} buckets={len(ts.bucketer.buckets) if ts.bucketer is not None else len(ts.inline_buckets)} segments={len(ts.bwd_cuts)} "
               f"worst update rel err {worst:.3e}", flush=True)
     dist.barrier()
     dist.destroy_process_group()

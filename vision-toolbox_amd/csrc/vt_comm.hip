@@ -29,6 +29,7 @@ struct Rccl {
 std::mutex g_mu;
 Rccl g_rccl;
 ncclComm_t g_comm = nullptr;
+ncclComm_t g_comm_stat = nullptr;  // optional second communicator: the SyncBatchNorm exchanges (vt_comm_init_stat)
 int g_world = 0, g_rank = -1;
 
 int bind_rccl() {
@@ -97,6 +98,29 @@ int vt_comm_init(const void* id128, int32_t rank, int32_t world) {
     return VT_OK;
 }
 
+// A second communicator over the same ranks for vt_stat_sync.  RCCL orders the operations of ONE communicator in issue
+// order whatever streams they sit on: with the statistics exchanges (main stream, on the critical path of every layer)
+// and the multi-megabyte bucket all-reduces (filter-gradient stream) on one communicator, each exchange would wait for
+// the bucket issued before it -- and for the filter gradients queued ahead of that bucket.  Invisible with one rank.
+int vt_comm_init_stat(const void* id128) {
+    VT_REQUIRE(id128, VT_ERR_INVALID, "vt_comm_init_stat: null id");
+    std::lock_guard<std::mutex> lk(g_mu);
+    VT_REQUIRE(g_comm != nullptr, VT_ERR_INVALID, "vt_comm_init_stat: vt_comm_init first");
+    VT_REQUIRE(g_comm_stat == nullptr, VT_ERR_INVALID, "vt_comm_init_stat: already initialised");
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t c = nullptr;
+    const ncclResult_t r = g_rccl.CommInitRank(&c, g_world, id, g_rank);
+    if (r != ncclSuccess) return rccl_error("vt_comm_init_stat", r);
+    g_comm_stat = c;
+    return VT_OK;
+}
+
+int vt_comm_has_stat(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_comm_stat != nullptr;
+}
+
 int vt_comm_world(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     return g_comm ? g_world : 0;
@@ -105,12 +129,22 @@ int vt_comm_world(void) {
 int vt_comm_destroy(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_comm) return VT_OK;
+    ncclResult_t r2 = ncclSuccess;
+    if (g_comm_stat) r2 = g_rccl.CommDestroy(g_comm_stat);
+    g_comm_stat = nullptr;
     const ncclResult_t r = g_rccl.CommDestroy(g_comm);
     g_comm = nullptr, g_world = 0, g_rank = -1;
-    return r == ncclSuccess ? VT_OK : rccl_error("vt_comm_destroy", r);
+    if (r != ncclSuccess) return rccl_error("vt_comm_destroy", r);
+    return r2 == ncclSuccess ? VT_OK : rccl_error("vt_comm_destroy(stat)", r2);
 }
 
+static int allreduce_on(bool stat, void* buf, int64_t count, int32_t dtype, void* stream);
+
 int vt_allreduce_bucket(void* buf, int64_t count, int32_t dtype, void* stream) {
+    return allreduce_on(false, buf, count, dtype, stream);
+}
+
+static int allreduce_on(bool stat, void* buf, int64_t count, int32_t dtype, void* stream) {
     VT_REQUIRE(buf && count > 0, VT_ERR_INVALID, "vt_allreduce_bucket: bad argument");
     ncclDataType_t t;
     switch (dtype) {
@@ -122,7 +156,7 @@ int vt_allreduce_bucket(void* buf, int64_t count, int32_t dtype, void* stream) {
     ncclComm_t c;
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        c = g_comm;
+        c = (stat && g_comm_stat) ? g_comm_stat : g_comm;
     }
     VT_REQUIRE(c != nullptr, VT_ERR_INVALID, "vt_allreduce_bucket: no communicator (vt_comm_init first)");
     const ncclResult_t r = g_rccl.AllReduce(buf, buf, (size_t)count, t, ncclSum, c, (hipStream_t)stream);
@@ -135,7 +169,8 @@ int vt_stat_sync(float* stats, int32_t C, void* stream) {
     // algorithmic payload, exact and order-free, so every rank finalises identical statistics
     const int rc = vt_stat_fold(stats, C, stream);
     if (rc != VT_OK) return rc;
-    return vt_allreduce_bucket(stats, 4 * (int64_t)C, VT_I64, stream);
+    // (on the statistics communicator when there is one: vt_comm_init_stat)
+    return allreduce_on(true, stats, 4 * (int64_t)C, VT_I64, stream);
 }
 
 }  // extern "C"

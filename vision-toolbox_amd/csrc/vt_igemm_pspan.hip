@@ -751,6 +751,25 @@ int vt_pspan_dispatch(IgemmArgs& a0, int dtype, void* stream) {
     if ((long)a0.B * a0.Hi * a0.Wi * a0.ldx * 2 >= 0x7fff0000L) return -1;  // (per-lane byte offsets are ints)
     if ((long)a0.B * a0.oH * a0.oW > 0x7fffffffL) return -1;
     if ((long)a0.Cout * a0.ldw * 2 >= 0x7fff0000L) return -1;
+    if ((a0.flags & VT_CONV_RESIDUAL) && a0.res) {
+        // The residual rows are fetched with asm loads that nothing orders against the tile's later stores to y: sound
+        // only while a lane's residual element IS the element it stores later (res == y with the same pixel stride) or the
+        // two tensors do not overlap at all.  A shifted or re-strided alias would race silently: the ordered kernels take it.
+        const long opix = (long)a0.B * a0.oH * a0.oW;
+        const char* y0 = (const char*)a0.y;
+        const char* y1 = y0 + ((opix - 1) * a0.ldy + ((a0.flags & VT_CONV_D2S) ? 4L * a0.Cout : (long)a0.Cout)) * 2;
+        const char* r0 = (const char*)a0.res;
+        const char* r1 = r0 + ((opix - 1) * a0.ldr + ((a0.flags & VT_CONV_D2S) ? 4L * a0.Cout : (long)a0.Cout)) * 2;
+        const bool overlap = r0 < y1 && y0 < r1;
+        if (overlap && !(r0 == y0 && a0.ldr == a0.ldy)) {
+            // two channel slices of ONE wider buffer (same pixel stride, disjoint channel ranges) never share an element
+            const long cb = ((a0.flags & VT_CONV_D2S) ? 4L * a0.Cout : (long)a0.Cout) * 2, pitch = (long)a0.ldy * 2;
+            long off = (r0 - y0) % pitch;
+            if (off < 0) off += pitch;
+            const bool slices = a0.ldr == a0.ldy && off >= cb && off + cb <= pitch;
+            if (!slices) return -1;
+        }
+    }
     PsArgs a;
     memset(&a, 0, sizeof(a));
     a.p = a0;

@@ -214,6 +214,8 @@ SYMBOLS = {
     "vt_comm_unique_id": (_i32, [_vp]),
     "vt_comm_init": (_i32, [_vp, _i32, _i32]),
     "vt_comm_world": (_i32, []),
+    "vt_comm_init_stat": (_i32, [_vp]),
+    "vt_comm_has_stat": (_i32, []),
     "vt_comm_destroy": (_i32, []),
     "vt_allreduce_bucket": (_i32, [_vp, C.c_int64, _i32, _vp]),
     "vt_bn_eval_coeffs": (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),

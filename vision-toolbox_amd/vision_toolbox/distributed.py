@@ -57,11 +57,27 @@ def plan_buckets(total_elems: int, bucket_elems: int, align: int = 64, head_elem
     return bounds
 
 
-def ensure_library_comm(group=None, device: Optional[torch.device] = None) -> int:
+def _agree(ok: bool, group, device) -> bool:
+    """True iff EVERY rank of `group` passed ok=True (one MIN all-reduce; gloo: host tensor, nccl: device tensor)."""
+    backend = dist.get_backend(group)
+    dev = device if (backend == "nccl" and device is not None) else (
+        torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu"))
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item())
+
+
+def ensure_library_comm(group=None, device: Optional[torch.device] = None, stat_comm: bool = False) -> int:
     """The library's own RCCL communicator over the ranks of `group` (vt_comm_init, include/vt_amd.h): rank 0 draws the
     id, torch.distributed carries its 128 bytes to the other ranks (any backend: this is the out-of-band channel the
     header speaks of, used once), every rank joins with its device current.  Returns the world size.  With it a launch
-    list carries its collectives as ops (VT_OP_ALLREDUCE / VT_OP_STAT_SYNC): nothing of torch sits between two kernels."""
+    list carries its collectives as ops (VT_OP_ALLREDUCE / VT_OP_STAT_SYNC): nothing of torch sits between two kernels.
+
+    Failure is AGREED, never one-sided: every rank first runs the fallible local part (binding RCCL, drawing
+    an id -- a purely local call) and the ranks all-reduce an ok flag BEFORE the id broadcast; a rank that cannot bind
+    therefore raises on every rank instead of leaving the others blocked in the broadcast or in RCCL's bootstrap.  The
+    collective join is followed by a second agreed flag.  `stat_comm`: also create the second communicator that
+    vt_stat_sync uses (SyncBatchNorm exchanges must not queue behind bucket all-reduces of the same communicator)."""
     import ctypes
 
     from . import _native as N
@@ -69,24 +85,76 @@ def ensure_library_comm(group=None, device: Optional[torch.device] = None) -> in
     L = N.lib()
     world = dist.get_world_size(group)
     have = L.vt_comm_world()
-    if have:
-        if have != world:
-            raise RuntimeError(f"the library communicator spans {have} ranks, the process group {world}")
+    if have and have != world:
+        raise RuntimeError(f"the library communicator spans {have} ranks, the process group {world}")
+    need_main, need_stat = not have, bool(stat_comm) and not L.vt_comm_has_stat()
+    if not need_main and not need_stat:
         return world
     rank = dist.get_rank(group)
-    ident = ctypes.create_string_buffer(128)
-    if rank == 0:
-        N.check(L.vt_comm_unique_id(ident))
-    box = [bytes(ident.raw)]
-    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    ident = ctypes.create_string_buffer(box[0], 128)
-    ctx = torch.cuda.device(device) if device is not None and device.type == "cuda" else None
-    if ctx is not None:
-        with ctx:
-            N.check(L.vt_comm_init(ident, rank, world))
-    else:
-        N.check(L.vt_comm_init(ident, rank, world))
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+
+    def join(init):
+        # 1. the local, fallible part on EVERY rank; agree before anything collective depends on it
+        ident = ctypes.create_string_buffer(128)
+        err = ""
+        try:
+            N.check(L.vt_comm_unique_id(ident))
+        except Exception as e:  # noqa: BLE001 -- reported on every rank below
+            err = repr(e)
+        if not _agree(not err, group, device):
+            raise RuntimeError(f"library communicator: RCCL could not be bound on at least one rank (this rank: {err or 'ok'})")
+        # 2. rank 0's id to everyone
+        box = [bytes(ident.raw)]
+        dist.broadcast_object_list(box, src=src, group=group)
+        ident = ctypes.create_string_buffer(box[0], 128)
+        # 3. the collective join, then an agreed verdict
+        err = ""
+        try:
+            ctx = torch.cuda.device(device) if device is not None and device.type == "cuda" else None
+            if ctx is not None:
+                with ctx:
+                    N.check(init(ident))
+            else:
+                N.check(init(ident))
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)
+        if not _agree(not err, group, device):
+            raise RuntimeError(f"library communicator: the RCCL join failed on at least one rank (this rank: {err or 'ok'})")
+
+    if need_main:
+        join(lambda ident: L.vt_comm_init(ident, rank, world))
+    if need_stat:
+        join(lambda ident: L.vt_comm_init_stat(ident))
     return world
+
+
+def self_test_library_comm(device: torch.device, timeout_s: float = 30.0) -> bool:
+    """One small vt_allreduce_bucket on a stream of its own, polled from the host for at most `timeout_s`: True when it
+    completed with the right sum.  A communicator that came up but whose first collective never finishes (a rank missing,
+    a transport that does not connect) then costs one stuck 1 MiB kernel instead of the whole job -- the caller agrees on
+    the verdict over torch.distributed and falls back (bench.py); the library communicator is NOT used after a False."""
+    import time
+
+    from . import _native as N
+
+    L = N.lib()
+    world, rank = L.vt_comm_world(), dist.get_rank()
+    if not world:
+        return False
+    with torch.cuda.device(device):
+        st = torch.cuda.Stream(device=device)
+        buf = torch.full((262144,), float(rank + 1), dtype=torch.float32, device=device)
+        torch.cuda.current_stream(device).synchronize()
+        rc = L.vt_allreduce_bucket(buf.data_ptr(), buf.numel(), N.VT_F32, st.cuda_stream)
+        if rc != N.VT_OK:
+            return False
+        t0 = time.perf_counter()
+        while not st.query():
+            if time.perf_counter() - t0 > timeout_s:
+                return False
+            time.sleep(0.005)
+        want = world * (world + 1) / 2.0
+        return bool((buf == want).all().item())
 
 
 class GradBucketer:

@@ -161,9 +161,8 @@ class TrainStep:
         self.dp = data_parallel is not False and (
             self.world > 1 or (os.environ.get("VT_DP_WORLD1", "0") != "0" and torch.distributed.is_available()
                                and torch.distributed.is_initialized()))
-        # (measurement only) run the data-parallel schedule -- cut lists, stream ordering -- without issuing the
-        # collectives: step time with them minus step time without = what the exchange leaves exposed
-        self.skip_exchange = False
+        # (measurement only, set through the `exchange_skipped()` context manager, which restores the replicas' state)
+        self._skip_exchange = False
         head = nn.Linear(backbone.get_last_out_channels(), num_classes)
         self.model = nn.Sequential(backbone, nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten(), head)
         self.model.train()
@@ -195,7 +194,8 @@ class TrainStep:
             if not plan_only:
                 from .distributed import ensure_library_comm
 
-                ensure_library_comm(self.pg, self.device)
+                # (with SyncBatchNorm: a second communicator for the statistics exchanges, see vt_comm_init_stat)
+                ensure_library_comm(self.pg, self.device, stat_comm=bool(sync_bn) and self.dp)
         self._align = 64 * self.world if self.exchange == "sharded" else 64
         st.pad_multiple = self._align
         with self._dev_ctx():
@@ -463,7 +463,7 @@ class TrainStep:
                 N.run_ops(sub, hi - lo, self.bases, s, side=side, leave_side_open=keep_side_open and hi != n)
             if hi in marks:  # stream-ordered: NCCL makes the launch stream wait, no host sync
                 self._sync_stats(*marks[hi][1], s)
-            if hi in cut_buckets and cut_buckets[hi] and not self.skip_exchange:
+            if hi in cut_buckets and cut_buckets[hi] and not self._skip_exchange:
                 if side and self._side is not None:
                     N.stream_wait(side, s)
                     with torch.cuda.stream(self._side):
@@ -480,6 +480,29 @@ class TrainStep:
         return torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()
 
     # -- data-parallel plumbing ----------------------------------------------------------------
+    def exchange_skipped(self):
+        """MEASUREMENT ONLY: a context in which step() runs the data-parallel schedule -- cut lists, stream ordering --
+        WITHOUT issuing the collectives (step time with them minus step time without = what the exchange leaves exposed).
+        Steps taken inside update every replica from its own rank's gradients, which would desynchronise the replicas (and
+        under the sharded exchange leave non-owned slices stale): the context snapshots parameters, BatchNorm state, the
+        batch counters, momentum and the bf16 mirror on entry and restores them on exit."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            st = self.store
+            keep = [t.clone() for t in (st.pflat, st.sflat, st.nflat, self.mflat, st.mirror)]
+            self._skip_exchange = True
+            try:
+                yield self
+            finally:
+                self._skip_exchange = False
+                torch.cuda.synchronize(self.device)
+                for dst, src_ in zip((st.pflat, st.sflat, st.nflat, self.mflat, st.mirror), keep):
+                    dst.copy_(src_)
+
+        return ctx()
+
     def broadcast_parameters(self, src: int = 0) -> None:
         """initial weights + buffers from rank `src` (what DDP's constructor does)."""
         if self.dp:
@@ -549,7 +572,7 @@ class TrainStep:
                 self._graphs["head"].launch(s)
                 for g, bks in zip(self._graphs["bwd"], self.cut_buckets):
                     g.launch(s)
-                    for bi in ([] if self.skip_exchange else bks):
+                    for bi in ([] if self._skip_exchange else bks):
                         self.bucketer.reduce_bucket(bi)
             else:
                 if self._side is None:
@@ -558,17 +581,17 @@ class TrainStep:
                 N.run_ops(self.zero_ops, 1, self.bases, s)
                 self._run_list(p.fwd_ops, p.n_fwd, self._fwd_sync, [], {}, s, side, keep_side_open=False)
                 bwd_ops, n_bwd = p.bwd_ops, p.n_bwd
-                if self.skip_exchange and self.collectives == "rccl" and getattr(self, "_bwd_without_exchange", None):
+                if self._skip_exchange and self.collectives == "rccl" and getattr(self, "_bwd_without_exchange", None):
                     bwd_ops, n_bwd = self._bwd_without_exchange
                 self._run_list(bwd_ops, n_bwd, self._bwd_sync, [n_bwd] if self.collectives == "rccl" else self.bwd_cuts,
                                dict(zip(self.bwd_cuts, self.cut_buckets)), s, side)
-            if self.bucketer is not None and not self.skip_exchange:
+            if self.bucketer is not None and not self._skip_exchange:
                 self.bucketer.finish()
             if self.use_graphs and not self.sync_bn and self.collectives != "rccl":
                 self._graphs["opt"].launch(s)
             else:
                 N.run_ops(self.opt_ops, self.n_opt, self.bases, s)
-            if self.exchange == "sharded" and not self.skip_exchange:
+            if self.exchange == "sharded" and not self._skip_exchange:
                 self._gather_weights()
                 self._master_stale = True
         self.steps_done += 1
