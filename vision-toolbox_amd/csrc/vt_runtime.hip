@@ -282,6 +282,33 @@ struct Graph {
 extern "C" {
 
 int vt_version(void) { return 101; }
+// Measurement aid (tools/rccl_hog.py): `wgs` workgroups of 256 threads that hold `lds_bytes` of LDS each and do nothing
+// until `microseconds` of wall clock have passed -- the footprint of a collective library's channel kernels beside the
+// step's own kernels (persistent, CU-owning kernels with static partitions wait for their slowest CU).
+// Every wave leaves by the clock alone: no flag, no dependence on another workgroup.
+namespace {
+__global__ void __launch_bounds__(256) hog_kernel(unsigned long long ticks, int lds_bytes, unsigned* sink) {
+    extern __shared__ char hog_smem[];
+    if (threadIdx.x * 4 < (unsigned)lds_bytes) ((volatile unsigned*)hog_smem)[threadIdx.x] = threadIdx.x;  // (the allocation is real)
+    const unsigned long long t0 = wall_clock64();  // 100 MHz
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (sink && ticks == ~0ull) sink[0] = ((volatile unsigned*)hog_smem)[0];
+}
+}  // namespace
+
+extern "C" int vt_debug_hog(int32_t wgs, int32_t lds_bytes, double microseconds, void* stream) {
+    VT_REQUIRE(wgs >= 1 && wgs <= 256 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && microseconds >= 0 && microseconds <= 1e6,
+               VT_ERR_INVALID, "vt_debug_hog: bad argument");
+    if (lds_bytes > 64 * 1024) {
+        const int rc = vt_raise_dynamic_lds((const void*)hog_kernel, lds_bytes, "vt_debug_hog");
+        if (rc != VT_OK) return rc;
+    }
+    hipLaunchKernelGGL(hog_kernel, dim3(wgs), dim3(256), lds_bytes, (hipStream_t)stream,
+                       (unsigned long long)(microseconds * 100.0), lds_bytes, (unsigned*)nullptr);
+    VT_CHECK_LAUNCH("vt_debug_hog");
+    return VT_OK;
+}
+
 int vt_set_knob(const char* name, int32_t value) {
     VT_REQUIRE(name && strlen(name) < 48, VT_ERR_INVALID, "vt_set_knob: bad name");
     // (a knob set before its first use overrides the environment: the slot exists from here on)
