@@ -33,6 +33,12 @@
 #define VT_W6_ABL 0
 #endif
 #define VT_W6DBG(bit) ((VT_W6_ABL & (bit)) != 0)
+// -DVT_W6_DIAG: shader-clock accounting per wave role (work between barriers vs waiting in them); never in the shipped build
+#ifdef VT_W6_DIAG
+#define VT_W6_T(...) __VA_ARGS__
+#else
+#define VT_W6_T(...)
+#endif
 
 namespace {
 
@@ -57,6 +63,9 @@ struct W6Args {
 };
 
 __device__ __attribute__((aligned(16))) unsigned int vt_w6_zero16[4];
+#ifdef VT_W6_DIAG
+__device__ unsigned long long vt_w6_diag[256 * 16];  // per workgroup: [0..3] loader 0: barrier wait, loop, vmcnt wait, steps | [4..6] g0 wave 0: wait, read tick, mfma tick | [8..10] g1 wave 4
+#endif
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
@@ -81,6 +90,17 @@ __device__ __forceinline__ void w6_barrier() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
+
+#ifdef VT_W6_DIAG
+#define VT_W6_BAR(wacc)                              \
+    do {                                             \
+        const unsigned long long c0_ = clock64();    \
+        w6_barrier();                                \
+        (wacc) += clock64() - c0_;                   \
+    } while (0)
+#else
+#define VT_W6_BAR(wacc) w6_barrier()
+#endif
 
 struct W6Pos {  // a padded position, decomposed, and the element offset of its pixel
     int b, i, j, off;
@@ -202,17 +222,26 @@ __global__ void __launch_bounds__(768, 3) wgrad6_kernel(const W6Args p) {
         // Tick t starts with barrier t.  Group 0 reads step s in tick 2s (and the second K half of its x fragments in
         // tick 2s+1), group 1 one tick later: step s is in LDS before barrier 2s and its dz slot / oldest ring chunk are
         // free from barrier 2s+3 on.  In ticks 2s and 2s+1 this wave issues its four pieces of step s + PD.
+        // (Round 5 also built, parity green, and measured NO faster in same-box A/B runs: the position tracking on the scalar
+        //  unit; one tracker wave per operand with lane = row that hands the row addresses to the other loaders through an
+        //  LDS table; loaders specialised per operand with the pieces dealt 3 / 5; that table pipelined one iteration ahead.
+        //  Stamps (-DVT_W6_DIAG): every wave spends 30-45 % of a step waiting in the two tick barriers -- the ticks end with
+        //  whichever of the twelve waves is slowest that time -- and a loader's LDS-DMA issue costs it 100-180 cycles a piece
+        //  whatever surrounds it.  NOTEBOOK R5.3.)
         int zs = PD % NS;  // dz slot of the step being issued
+        VT_W6_T(unsigned long long lwait = 0, lvm = 0; const unsigned long long lt0 = clock64();)
         for (int s = 0; s < nsteps; ++s) {
+            VT_W6_T(const unsigned long long v0_ = clock64();)
             if (s + PD - 1 < nsteps) w6_vmw<4 * (PD - 1)>();  // the PD - 1 younger steps may stay in flight
             else w6_vmw<0>();
-            w6_barrier();
+            VT_W6_T(lvm += clock64() - v0_;)
+            VT_W6_BAR(lwait);
             const bool more = s + PD < nsteps && !VT_W6DBG(1);
             if (more) {
                 issue_z(0, zs);
                 issue_x(0, xc);
             }
-            w6_barrier();
+            VT_W6_BAR(lwait);
             if (more) {
                 issue_z(1, zs);
                 issue_x(1, xc);
@@ -223,6 +252,12 @@ __global__ void __launch_bounds__(768, 3) wgrad6_kernel(const W6Args p) {
         w6_barrier();  // tick 2 nsteps: group 1's last MFMA tick
         w6_vmw<0>();
         w6_set_m0(m0_keep);
+#ifdef VT_W6_DIAG
+        if (lj == 0 && lane == 0 && blockIdx.x < 256) {
+            vt_w6_diag[blockIdx.x * 16 + 0] = lwait, vt_w6_diag[blockIdx.x * 16 + 1] = clock64() - lt0;
+            vt_w6_diag[blockIdx.x * 16 + 2] = lvm, vt_w6_diag[blockIdx.x * 16 + 3] = (unsigned long long)nsteps;
+        }
+#endif
     } else {
         // =============================== compute waves ==================================================
         const int grp = wave >> 2, w4 = wave & 3;
@@ -257,9 +292,11 @@ __global__ void __launch_bounds__(768, 3) wgrad6_kernel(const W6Args p) {
             constexpr int NTL = decltype(ntl_c)::value;
             constexpr int NB = NTL > 0 ? NTL : 1;
             int zs = 0;
+            VT_W6_T(unsigned long long cwait = 0, cR = 0, cM = 0;)
             for (int s = 0; s < nsteps; ++s) {
                 // ---- read tick: the step's dz slot and ring rows are in LDS -------------------------------------
-                w6_barrier();
+                VT_W6_BAR(cwait);
+                VT_W6_T(const unsigned long long r0_ = clock64();)
                 const char* dzs = sDz + zs * kDzSlot;
                 s16x4 a0l[4], a0h[4], a1l[4], a1h[4], b0l[NB], b0h[NB];
                 if (!VT_W6DBG(4)) {
@@ -286,8 +323,10 @@ __global__ void __launch_bounds__(768, 3) wgrad6_kernel(const W6Args p) {
                 }
                 // (no wait here: the compiler's counted lgkmcnt waits sit in front of the MFMAs that use each fragment)
                 __builtin_amdgcn_sched_barrier(0);
+                VT_W6_T(cR += clock64() - r0_;)
                 // ---- MFMA tick (the other group reads meanwhile) ---------------------------------------------
-                w6_barrier();
+                VT_W6_BAR(cwait);
+                VT_W6_T(const unsigned long long m0_ = clock64();)
                 bf16x8 af[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -330,8 +369,15 @@ __global__ void __launch_bounds__(768, 3) wgrad6_kernel(const W6Args p) {
                         acc[tt][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[tt][i], 0, 0, 0);
                     }
                 }
+                VT_W6_T(asm volatile("s_nop 0" ::"v"(acc[NB - 1][3][0])); cM += clock64() - m0_;)
                 zs = (zs + 1 == NS) ? 0 : zs + 1;
             }
+#ifdef VT_W6_DIAG
+            if (w4 == 0 && lane == 0 && blockIdx.x < 256) {
+                const int o_ = blockIdx.x * 16 + 4 + 4 * grp;
+                vt_w6_diag[o_] = cwait, vt_w6_diag[o_ + 1] = cR, vt_w6_diag[o_ + 2] = cM;
+            }
+#endif
         };
         switch (ntl) {
             case 5: run(I_<5>{}); break;
@@ -416,6 +462,24 @@ int launch_w6(const W6Args& a, hipStream_t st) {
     const long items = (long)a.tiles_n * a.tiles_c * a.split * a.G;
     hipLaunchKernelGGL(kern, dim3(vt_xcd_grid(items)), dim3(768), smem, st, a);
     VT_CHECK_LAUNCH("vt_conv_wgrad(wgrad6)");
+#ifdef VT_W6_DIAG
+    {
+        static int calls = 0;
+        if (++calls % 8 == 0 && calls <= 64) {  // warm launches
+            (void)hipStreamSynchronize(st);
+            static unsigned long long h[256 * 16];
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(vt_w6_diag), sizeof(h));
+            double m_[12] = {0};
+            const int nb = items < 256 ? (int)items : 256;
+            for (int b = 0; b < nb; ++b)
+                for (int k = 0; k < 12; ++k) m_[k] += (double)h[b * 16 + k] / nb;
+            const double ns = m_[3] > 0 ? m_[3] : 1;
+            fprintf(stderr, "[w6 diag G%d split%d] per step (shader cycles, mean over %d WGs, %.0f steps): loader0 loop %.0f = barrier wait %.0f + vmcnt wait %.0f + issue %.0f | "
+                            "g0 wave: barrier wait %.0f, read tick %.0f, mfma tick %.0f | g1 wave: barrier wait %.0f, read tick %.0f, mfma tick %.0f\n",
+                    a.G, a.split, nb, ns, m_[1] / ns, m_[0] / ns, m_[2] / ns, (m_[1] - m_[0] - m_[2]) / ns, m_[4] / ns, m_[5] / ns, m_[6] / ns, m_[8] / ns, m_[9] / ns, m_[10] / ns);
+        }
+    }
+#endif
     return VT_OK;
 }
 
