@@ -367,6 +367,11 @@ int vt_softmax_xent_mix(const void* logits, int32_t ldl, const int64_t* labels,
                         float label_smoothing, float grad_scale, float* loss, void* dlogits,
                         int32_t lddl, int32_t B, int32_t N, int32_t dtype, const float* mix,
                         void* stream);
+/* Validation step (classifier.py:97-109): out3[0] += sum of the rows' cross entropy WITHOUT label smoothing, out3[1] +=
+ * rows whose arg-max (first maximum, as torch.argmax) equals the label, out3[2] += rows.  The caller zeroes out3 or keeps
+ * accumulating over an epoch's batches; data parallel it all-reduces the three sums (`sync_dist=True`, classifier.py:104). */
+int vt_softmax_xent_eval(const void* logits, int32_t ldl, const int64_t* labels, float* out3, int32_t B, int32_t N,
+                         int32_t dtype, void* stream);
 int vt_mix_nchw_to_nhwc(const float* x, void* y, int32_t B, int32_t C, int32_t H, int32_t W,
                         int32_t Cpad, int32_t dtype, const float* mix, void* stream);
 
@@ -440,6 +445,7 @@ enum vt_op_kind {
     VT_OP_STEM_BWD_S2,      /* vt_stem_bn_bwd_s2 */
     VT_OP_ALLREDUCE,        /* vt_allreduce_bucket (a gradient bucket, in place) */
     VT_OP_STAT_SYNC,        /* vt_stat_sync (one BatchNorm layer's sums over all ranks) */
+    VT_OP_XENT_EVAL,        /* vt_softmax_xent_eval (validation: loss sum, top-1 hits, rows) */
     VT_OP_KIND_END
 };
 

@@ -319,3 +319,42 @@ def test_inlist_collectives_layout_of_the_launch_lists(monkeypatch):
     assert covered[0][0] == 0 and covered[-1][1] == ts.gflat.numel() and len(covered) > 2
     assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
     assert any((ops[i].kind & 0xFFFF) == N.OP_JOIN for i in range(last_ar + 1, n))
+
+
+def _val_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    sys.path[:0] = [str(root / "vision-toolbox_amd"), str(root)]
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vision_toolbox.trainer import reduce_validation_sums
+
+        mine = torch.tensor([1.5 * (rank + 1), float(3 + rank), 8.0])
+        q.put((rank, reduce_validation_sums(mine).tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_validation_sums_are_all_reduced_over_the_ranks():
+    """the scalar-sized exchange of the validation step (`sync_dist=True`, classifier.py:104; SURVEY collective C4)"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_val_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0] == res[1] == [4.5, 7.0, 16.0]
+
+
+def test_validation_sums_without_a_process_group_are_unchanged():
+    from vision_toolbox.trainer import reduce_validation_sums
+
+    t = torch.tensor([2.0, 1.0, 4.0])
+    assert torch.equal(reduce_validation_sums(t), t)

@@ -336,6 +336,36 @@ def test_softmax_cross_entropy_label_smoothing(dtype):
     assert rel_err(dl.float().cpu(), logits.grad) < tol(dtype, 1e-5)
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=DNAME.get)
+def test_validation_cross_entropy_and_top1(dtype):
+    """vt_softmax_xent_eval: loss sum without label smoothing, top-1 hits (first maximum, as torch.argmax) and rows,
+    accumulated over two calls (classifier.py:97-109)."""
+    B, Ncls = 37, 1000
+    g = torch.Generator().manual_seed(5)
+    logits = (torch.randn(B, Ncls, generator=g) * 3).to(TD[dtype])
+    logits[3, 10] = logits[3, 700] = 40.0  # a tie: the first maximum wins
+    labels = torch.randint(0, Ncls, (B,), generator=g)
+    labels[3] = 10
+    labels[4] = int(logits[4].float().argmax())
+    ld = Ncls + 8
+    dev = torch.zeros(B, ld, dtype=TD[dtype], device="cuda")
+    dev[:, :Ncls] = logits.cuda()
+    out = torch.zeros(3, device="cuda")
+    lab = labels.cuda()
+    for _ in range(2):
+        N.check(N.lib().vt_softmax_xent_eval(vp(dev), ld, vp(lab), vp(out), B, Ncls, dtype, stream()))
+    torch.cuda.synchronize()
+    ref = F.cross_entropy(logits.double(), labels, reduction="sum").item()
+    hits = int((logits.float().argmax(-1) == labels).sum())
+    assert hits >= 2
+    assert abs(out[0].item() - 2 * ref) < 1e-4 * abs(2 * ref)
+    assert out[1].item() == 2 * hits and out[2].item() == 2 * B
+    bad = lab.clone()
+    bad[0] = Ncls  # out of range: torch raises, the kernel poisons the sum
+    N.check(N.lib().vt_softmax_xent_eval(vp(dev), ld, vp(bad), vp(out), B, Ncls, dtype, stream()))
+    assert torch.isnan(out[0]).item()
+
+
 def test_softmax_cross_entropy_out_of_range_label_poisons_the_loss():
     """torch raises on a label outside [0, N); the kernel cannot, so it must neither read out of bounds
     nor train silently: the loss becomes NaN, the gradients of the valid samples stay finite."""

@@ -297,3 +297,42 @@ def test_bench_n2_falls_back_together_when_the_library_communicator_cannot_be_ma
         assert key in line
     buf = torch.zeros(16, device="cuda")  # the launch-count guard of this module wants a launch here too
     N.check(N.lib().vt_memset(buf.data_ptr(), 0, 64, int(torch.cuda.current_stream().cuda_stream)))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("name", ["darknet19", "vovnet19_slim_ese"])
+def test_validation_step_matches_the_oracle(name, dtype):
+    """TrainStep.validate(): eval-mode forward (running statistics), cross entropy WITHOUT label smoothing, top-1 accuracy --
+    `validation_step` of the reference's classifier.py:97-109 -- against the oracle on the same weights and batch, after one
+    train step so that the running statistics are not the initial ones.  Nothing is updated by validate()."""
+    ncls, B, S = 24, 12, 96
+    x, y = filler.images(B, S), filler.labels(B, ncls)
+    ts = TrainStep(getattr(backbones, name)(), ncls, B, S, dtype, lr=1e-3, momentum=0.9, weight_decay=1e-4,
+                   label_smoothing=0.1, device="cuda")
+    filler.fill_module(ts.model, "va.")
+    ts.weights_changed()
+    ts.step(x.cuda(), y.cuda())
+    torch.cuda.synchronize()
+    sd = {k: v.detach().clone().cpu() for k, v in ts.model.state_dict().items()}
+    before = {k: v.clone() for k, v in sd.items()}
+    got = ts.validate(x.cuda(), y.cuda())
+    with torch.no_grad():
+        logits = R.classifier_logits(name, sd, x, False)
+        ref_loss = torch.nn.functional.cross_entropy(logits, y).item()
+        ref_hits = int((logits.argmax(-1) == y).sum())
+    assert got["count"] == B
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    assert abs(got["loss"] - ref_loss) <= tol * max(1.0, abs(ref_loss)), (got, ref_loss)
+    dev_logits = ts.eval_logits().float().cpu()
+    assert rel_err(dev_logits, logits) < (2e-4 if dtype == torch.float32 else 3e-2)
+    # top-1: exact against the arg-max of the DEVICE logits (a bf16 near-tie may legitimately differ from the oracle's)
+    assert got["correct"] == int((dev_logits.argmax(-1) == y).sum())
+    if dtype == torch.float32:
+        assert got["correct"] == ref_hits
+    assert abs(got["acc"] - got["correct"] / B) < 1e-6
+    after = ts.model.state_dict()
+    for k, v in before.items():
+        assert torch.equal(after[k].cpu(), v), f"validate() changed {k}"
+    # a second call repeats (same sums, nothing accumulates across calls)
+    again = ts.validate()
+    assert again["count"] == B and again["correct"] == got["correct"] and abs(again["loss"] - got["loss"]) < 1e-5

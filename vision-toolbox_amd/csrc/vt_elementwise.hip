@@ -1029,6 +1029,60 @@ colsum_kernel(const T* __restrict__ a, int lda, long M, int C, RowMap rm, float*
 template <typename T>
 __device__ __forceinline__ float ldf(const T* p) { return (float)(*p); }
 
+// Validation (classifier.py:97-109): cross entropy WITHOUT label smoothing and top-1 hits of one batch.
+// out[0] += sum over rows of the row loss, out[1] += rows whose arg-max (first maximum, as torch.argmax) is the label,
+// out[2] += rows.  f32 adds of at most a few hundred terms per call; the caller zeroes `out` (or keeps accumulating over the
+// batches of an epoch) and, data parallel, all-reduces the three sums (the `sync_dist=True` of classifier.py:104).
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+xent_eval_kernel(const T* __restrict__ logits, int ldl, const int64_t* __restrict__ labels, float* __restrict__ out, int B,
+                 int N) {
+    __shared__ float sv[kThreads / 64];
+    __shared__ int si[kThreads / 64];
+    __shared__ float sbc;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const T* lp = logits + (long)b * ldl;
+    float mx = -INFINITY;
+    int am = 0x7fffffff;
+    for (int i = t; i < N; i += kThreads) {
+        const float v = ldf(lp + i);
+        if (v > mx || (v == mx && i < am)) mx = v, am = i;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(mx, o, 64);
+        const int oi = __shfl_xor(am, o, 64);
+        if (ov > mx || (ov == mx && oi < am)) mx = ov, am = oi;
+    }
+    if ((t & 63) == 0) sv[t >> 6] = mx, si[t >> 6] = am;
+    __syncthreads();
+    if (t == 0) {
+        for (int i = 1; i < kThreads / 64; ++i)
+            if (sv[i] > mx || (sv[i] == mx && si[i] < am)) mx = sv[i], am = si[i];
+        sbc = mx;
+        si[0] = am;
+    }
+    __syncthreads();
+    mx = sbc;
+    am = si[0];
+    float se = 0.f;
+    for (int i = t; i < N; i += kThreads) se += expf(ldf(lp + i) - mx);
+    se = wave_sum(se);
+    __syncthreads();
+    if ((t & 63) == 0) sv[t >> 6] = se;
+    __syncthreads();
+    if (t == 0) {
+        float tse = 0.f;
+        for (int i = 0; i < kThreads / 64; ++i) tse += sv[i];
+        const int64_t yb = labels[b];
+        const bool bad = yb < 0 || yb >= (int64_t)N;  // (torch raises; here the loss sum becomes NaN)
+        const float l = bad ? __builtin_nanf("") : mx + logf(tse) - ldf(lp + yb);
+        atomicAdd(out + 0, l);
+        if (!bad && (int64_t)am == yb) atomicAdd(out + 1, 1.0f);
+        atomicAdd(out + 2, 1.0f);
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
 xent_kernel(const T* __restrict__ logits, int ldl, const int64_t* __restrict__ labels, float eps,
@@ -1735,6 +1789,16 @@ int vt_softmax_xent(const void* logits, int32_t ldl, const int64_t* labels, floa
                                      (const T*)logits, ldl, labels, label_smoothing, grad_scale, loss,
                                      (T*)dlogits, lddl, B, N, (const float*)nullptr));
     VT_CHECK_LAUNCH("vt_softmax_xent");
+    return VT_OK;
+}
+
+int vt_softmax_xent_eval(const void* logits, int32_t ldl, const int64_t* labels, float* out3, int32_t B, int32_t N,
+                         int32_t dtype, void* stream) {
+    VT_REQUIRE(logits && labels && out3 && B > 0 && N > 0 && ldl >= N, VT_ERR_INVALID, "vt_softmax_xent_eval: bad argument");
+    VT_DISPATCH_T(dtype, "vt_softmax_xent_eval",
+                  hipLaunchKernelGGL(xent_eval_kernel<T>, dim3(B), dim3(kThreads), 0, (hipStream_t)stream,
+                                     (const T*)logits, ldl, labels, out3, B, N));
+    VT_CHECK_LAUNCH("vt_softmax_xent_eval");
     return VT_OK;
 }
 

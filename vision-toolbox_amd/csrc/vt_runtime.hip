@@ -213,6 +213,8 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
                         : vt_colsum(P[0], I[0], (int64_t)F[0], I[1], I[2], (float*)P[1], st);
         case VT_OP_FIXED_TO_F32:  // ptr: q dst | i: accumulate | f: n
             return vt_fixed_to_f32(P[0], (float*)P[1], (int64_t)F[0], I[0], st);
+        case VT_OP_XENT_EVAL:  // ptr: logits labels out3 | i: ldl B N dtype
+            return vt_softmax_xent_eval(P[0], I[0], (const int64_t*)P[1], (float*)P[2], I[1], I[2], I[3], st);
         case VT_OP_XENT:  // ptr: logits labels loss dlogits [mix] | i: ldl lddl B N dtype | f: eps grad_scale
             if (P[4])
                 return vt_softmax_xent_mix(P[0], I[0], (const int64_t*)P[1], (float)F[0], (float)F[1], (float*)P[2],

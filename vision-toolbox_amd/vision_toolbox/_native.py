@@ -91,7 +91,8 @@ VT_OP_MAX_PTR, VT_OP_MAX_INT, VT_OP_MAX_FLT, VT_MAX_BASES = 16, 110, 8, 16
     OP_STEM_BWD_S2,
     OP_ALLREDUCE,
     OP_STAT_SYNC,
-) = range(1, 39)
+    OP_XENT_EVAL,
+) = range(1, 40)
 OP_SIDE_STREAM = 0x10000  # OR-ed into Op.kind: enqueue on the side stream
 
 OP_NAMES = {
@@ -113,6 +114,7 @@ OP_NAMES = {
     OP_ESE_BWD: "ese_bwd",
     OP_COLSUM: "colsum",
     OP_XENT: "xent",
+    OP_XENT_EVAL: "xent_eval",
     OP_SGD: "sgd",
     OP_COPY2D: "copy2d",
     OP_NCHW_TO_NHWC: "nchw_to_nhwc",
@@ -257,6 +259,7 @@ SYMBOLS = {
     "vt_colsum": (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "vt_softmax_xent": (_i32, [_vp, _i32, _vp, _f32, _f32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "vt_softmax_xent_mix": (_i32, [_vp, _i32, _vp, _f32, _f32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "vt_softmax_xent_eval": (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vt_mix_nchw_to_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "vt_sgd_momentum": (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _f32, _f32, _f32, _f32, _vp, _vp]),
     "vt_copy2d": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _i64, _i32, _i32, _vp]),

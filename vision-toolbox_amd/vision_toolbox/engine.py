@@ -1197,6 +1197,13 @@ class Builder:
                   [logits.ld, g.ld if g else 0, Bn, Ncls, self.dtype], [label_smoothing, grad_scale])
         return loss
 
+    def xent_eval(self, logits: TRef) -> Buf:
+        """validation (classifier.py:97-109): [loss sum without label smoothing, top-1 hits, rows] of the batch, f32[3]."""
+        self.tag += 1
+        out = self.zeroed_f32(64, "val_sums")
+        self.emit(N.OP_XENT_EVAL, [logits.addr(), (LABELS, 0), self.bp(out)], [logits.ld, logits.B, logits.C, self.dtype])
+        return out
+
     # -- finish ---------------------------------------------------------------------------
     def build_backward(self):
         self._cur = self.bwd

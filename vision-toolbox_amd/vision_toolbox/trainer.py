@@ -110,6 +110,20 @@ def sample_mix(cutmix_alpha: float, mixup_alpha: float, width: int, height: int)
     return "cutmix", lam, (x1, y1, x2, y2)
 
 
+def reduce_validation_sums(sums: torch.Tensor, group=None) -> torch.Tensor:
+    """[loss sum, top-1 hits, rows] of this rank's batch -> the same three sums over all ranks of `group` (one scalar-sized
+    all-reduce: the `sync_dist=True` of classifier.py:104; SURVEY collective C4).  Without a process group: unchanged."""
+    if group is None and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return sums
+    if torch.distributed.get_world_size(group) == 1:
+        return sums
+    t = sums.double()  # (hits and rows are integers: exact in any order)
+    if torch.distributed.get_backend(group) != "nccl":
+        t = t.cpu()
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=group)
+    return t.to(sums.device, torch.float32)
+
+
 def _grad_write_offsets(op: N.Op) -> list[int]:
     """element offsets in the flat gradient buffer this backward op writes."""
     return [op.ptr[k].offset // 4 for k in range(N.VT_OP_MAX_PTR) if op.ptr[k].base == E.GRADS]
@@ -595,6 +609,63 @@ class TrainStep:
                 self._gather_weights()
                 self._master_stale = True
         self.steps_done += 1
+
+    # ---- validation step (reference classifier.py:97-109) ----------------------------------------------------------
+    def _build_eval(self):
+        """The SAME modules and flat parameter store compiled once more in eval mode: every BatchNorm uses its running
+        statistics (folded into the conv epilogues: one launch per unit), no gradient bookkeeping, and the loss op is the
+        validation one (no label smoothing, top-1 hits).  Its arena is its own (forward only)."""
+        was = [(m, m.training) for m in self.model.modules()]
+        self.model.eval()
+        try:
+            b = E.Builder(self.store, self.dtype, training=False, need_grad=False)
+            x = b.input_images(self.B, 3, self.S, self.S)
+            fmap = self.model[0]._vt_emit_maps(b, x)[-1]
+            pooled = b.global_avgpool(fmap, "head.pool")
+            logits = b.conv_unit(pooled, _LinearAsConv(self.model[3]), None, False, name="head.linear")
+            sums = b.xent_eval(logits)
+            b.build_backward()
+            prog = Program(b, [logits], [])
+        finally:
+            for m, t in was:
+                m.training = t
+        with self._dev_ctx():
+            arena = torch.empty(prog.arena_bytes, dtype=torch.uint8, device=self.device)
+        bases = prog.bases(arena.data_ptr(), PARAMS=self.store.pflat.data_ptr(), STATE=self.store.sflat.data_ptr(),
+                           MIRROR=self.store.mirror.data_ptr(), INPUT=self.images.data_ptr(),
+                           COUNTERS=self.store.nflat.data_ptr(), LABELS=self.labels.data_ptr())
+        self._eval = (prog, arena, bases, prog.zf_off + sums.offset, logits)
+
+    def validate(self, images: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None) -> dict:
+        """One validation step on the resident (or given) batch: eval-mode forward, cross entropy WITHOUT label smoothing,
+        top-1 accuracy -- `validation_step` of classifier.py:97-109.  Data parallel, the three sums (loss, hits, rows) are
+        all-reduced over the ranks (its `sync_dist=True`; collective C4 of SURVEY section 2), so every rank returns the
+        GLOBAL mean loss and accuracy.  Parameters, BatchNorm statistics and optimiser state are not touched."""
+        if self.plan_only:
+            raise RuntimeError("plan_only TrainStep cannot execute: there is no CPU path")
+        if getattr(self, "_master_stale", False):
+            self.gather_master()
+        with self._dev_ctx():
+            if images is not None:
+                self.images.copy_(images, non_blocking=True)
+            if labels is not None:
+                self.labels.copy_(labels, non_blocking=True)
+            if getattr(self, "_eval", None) is None:
+                self._build_eval()
+            prog, arena, bases, off, _ = self._eval
+            s = current_stream_handle()
+            if self._side is None:
+                self._side = torch.cuda.Stream(self.device)
+            N.run_ops(prog.fwd_ops, prog.n_fwd, bases, s, side=int(self._side.cuda_stream))
+            sums = arena[off : off + 12].view(torch.float32).clone()
+        sums = reduce_validation_sums(sums, self.pg if self.dp else None)
+        loss_sum, hits, rows = (float(v) for v in sums.tolist())
+        return {"loss": loss_sum / rows, "acc": hits / rows, "correct": int(round(hits)), "count": int(round(rows))}
+
+    def eval_logits(self) -> torch.Tensor:
+        """logits of the last validate() call"""
+        _, arena, _, _, logits = self._eval
+        return E.tref_to_tensor(arena, logits).reshape(self.B, -1)
 
     def loss(self) -> float:
         """mean loss of the last step (synchronises)."""
