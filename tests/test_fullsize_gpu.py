@@ -11,6 +11,8 @@ gradient -- checked where the oracle can still follow:
 Tolerances: bf16 storage of the output (rel 2^-8 per element, 6e-3 in L2), f32 accumulation."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -312,6 +314,68 @@ def test_full_batch_train_step_equals_small_batch_step_and_oracle(name, dtype, f
             (float(np.median(a)), float(a.max()), max(fs, key=fs.get))
         assert np.median(b) < (8e-2 if bf else 1e-3) and b.max() < (0.5 if bf else 5e-2), \
             (float(np.median(b)), float(b.max()), max(fr, key=fr.get))
+
+
+@pytest.mark.parametrize("name", ["cspdarknet53", "vovnet39"])
+def test_full_model_bf16_gradient_scale_against_the_f32_program_per_tensor(name):
+    """the only full-depth bf16 train-mode check used to allow a head-gradient error of 0.25 and a median
+    norm ratio in (0.5, 2): a scale slip confined to one mid-network stage would have passed.  Here the bf16 program's
+    gradient of EVERY parameter tensor (>= 4096 elements) is set against the f32-kernel program's -- same GPU, same weights,
+    same batch of 256, train-mode BatchNorm -- by regression slope <g_bf16, g_f32> / |g_f32|^2, relative error and norm ratio.
+
+    What was measured (round 5, `VT_SLOPE_DUMP=1`): at random initialisation the DIRECTION of a train-mode gradient does
+    not survive bf16 storage through 40-67 BatchNorm backward passes -- each subtracts the batch mean and the projection on
+    x-hat, i.e. most of dy, and what is left sits at the rounding level of what was subtracted: slope 0.99 on the head, 0.55
+    on the last conv, 0.08-0.25 from stage 3 down (rel 0.95-1.36; VoVNet-39: 0.22-0.75).  The per-tensor slope bound the
+    verdict asked for therefore says nothing below the last stage.  What DOES survive, tightly, is the SCALE: random
+    decorrelation leaves |g_bf16| = |g_f32| (equivalently slope = 1 - rel^2 / 2): the norm ratio of every one of the 103
+    tensors of the two models lies in [0.982, 1.018].  A scale or routing slip in any stage (a doubled or missing
+    contribution, a wrong BatchNorm coefficient) moves the norm of every gradient upstream of it by its own size.
+    Asserted per tensor: norm ratio within 4 %, |slope - (1 - rel^2 / 2)| <= 0.03; and the head, which sees one backward
+    op: slope within 2 % of 1."""
+    from oracle import filler
+    from vision_toolbox import backbones
+    from vision_toolbox.trainer import TrainStep
+
+    ncls, n = 1000, 16
+    kw = dict(lr=0.0, momentum=0.0, weight_decay=0.0, label_smoothing=0.1, device="cuda", use_graphs=False)
+    x, y = filler.images(n, 224, seed=21), filler.labels(n, ncls, seed=22)
+    torch.manual_seed(0)
+    ref = TrainStep(getattr(backbones, name)(), ncls, B, 224, torch.float32, **kw)
+    sd0 = {k: v.detach().cpu().clone() for k, v in ref.model.state_dict().items()}
+    loss_f, g_f = _train_step_grads(ref, x, y)
+    del ref
+    torch.cuda.empty_cache()
+    low = TrainStep(getattr(backbones, name)(), ncls, B, 224, torch.bfloat16, **kw)
+    low.model.load_state_dict(sd0)
+    low.weights_changed()
+    loss_b, g_b = _train_step_grads(low, x, y)
+    del low
+    torch.cuda.empty_cache()
+    assert loss_b == pytest.approx(loss_f, rel=2e-2)
+    rows, bad = [], []
+    for k, gf in g_f.items():
+        if gf.numel() < 4096:
+            continue
+        gb = g_b[k]
+        nf = gf.norm().item()
+        assert nf > 0, k
+        slope = float((gb * gf).sum() / (gf * gf).sum())
+        rel = float((gb - gf).norm() / nf)
+        ratio = gb.norm().item() / nf
+        rows.append((k, gf.numel(), rel, slope, ratio))
+        if abs(ratio - 1.0) > 0.04 or abs(slope - (1.0 - 0.5 * rel * rel)) > 0.03:
+            bad.append((k, gf.numel(), round(rel, 4), round(slope, 4), round(ratio, 4)))
+    ratios = np.array([r[4] for r in rows])
+    print(f"\n[{name}] {len(rows)} tensors: norm ratio {ratios.min():.4f} .. {ratios.max():.4f} (median {np.median(ratios):.4f}); "
+          f"slope {min(r[3] for r in rows):.3f} .. {max(r[3] for r in rows):.3f}")
+    if os.environ.get("VT_SLOPE_DUMP"):
+        for r in rows:
+            print(f"   {r[0]:55s} n {r[1]:8d} rel {r[2]:.4f} slope {r[3]:.4f} norm ratio {r[4]:.4f}")
+    assert len(rows) >= 39
+    assert not bad, bad[:8]
+    head = [r for r in rows if r[0] == "3.weight"]
+    assert head and abs(head[0][3] - 1.0) < 0.02, head
 
 
 # ---- BASELINE configs[4]: Darknet-YOLOv5x get_feature_maps(), batch 64 @640 ----------------------------
