@@ -164,3 +164,48 @@ except Exception as ex:
 json.dump(res, open(f"{out}/{tag}_pspan_pmc.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 EOF3
+
+# 6. (round 5) the CU-owning filter-gradient kernel on the dominant shape: 25 launches of one layer, then 25 launches of a
+#    group of eight layers (tools/bench_conv.py wgrad with VT_BENCH_GROUP=8); each counter group in its own pass
+for grp in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" GRBM_GUI_ACTIVE; do
+    name=$(echo $grp | cut -d' ' -f1)
+    VT_BENCH_GROUP=8 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/${TAG}_w6_pmc_$name" -- \
+        python3 "$ROOT/tools/bench_conv.py" wgrad 128,128,3,1,28 > "$OUT/${TAG}_w6_pmc_$name.log" 2>&1
+    echo "wgrad6 pmc $name exit $?"
+done
+python3 - "$OUT" "$TAG" <<'EOF6'
+import csv, glob, json, sys
+out, tag = sys.argv[1], sys.argv[2]
+res = {"layer": "filter gradient of conv3x3 s1 128->128 @28x28 B=256 (59.19 GFLOP, 103 MB of operands per layer)",
+       "note": "dispatch order: 25 launches of ONE layer (split 64), then 25 launches of a GROUP OF EIGHT layers (split 8 each); FETCH_SIZE x2 on gfx950"}
+def rows(d, counter):
+    f = glob.glob(f"{out}/{tag}_w6_pmc_{d}/*/*counter_collection.csv")[0]
+    r = [x for x in csv.DictReader(open(f)) if "wgrad6_kernel" in x["Kernel_Name"] and x["Counter_Name"] == counter]
+    r.sort(key=lambda x: int(x["Dispatch_Id"]))
+    return [float(x["Counter_Value"]) for x in r]
+def durs(d):
+    f = glob.glob(f"{out}/{tag}_w6_pmc_{d}/*/*kernel_trace.csv")[0]
+    r = [x for x in csv.DictReader(open(f)) if "wgrad6_kernel" in x["Kernel_Name"]]
+    r.sort(key=lambda x: int(x["Start_Timestamp"]))
+    return [(int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3 for x in r]
+avg = lambda v: sum(v) / max(len(v), 1)
+try:
+    for label, lo, hi, layers in (("one_layer", 5, 25, 1), ("group_of_8", 30, 50, 8)):
+        fe, wr = rows("FETCH_SIZE", "FETCH_SIZE")[lo:hi], rows("WRITE_SIZE", "WRITE_SIZE")[lo:hi]
+        mf = rows("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES")[lo:hi]
+        gui = rows("GRBM_GUI_ACTIVE", "GRBM_GUI_ACTIVE")[lo:hi]
+        du = durs("GRBM_GUI_ACTIVE")[lo:hi]
+        flop = 59190018048.0 * layers
+        n_mfma = flop * (29 * 29) / (28 * 28) / (2 * 16 * 16 * 32)  # (padded positions: 29 x 29 per image)
+        e = {"launches": len(du), "layers_per_launch": layers, "avg_duration_us": avg(du), "us_per_layer": avg(du) / layers,
+             "tflops": flop / avg(du) / 1e6, "frac_of_2.5PF": flop / avg(du) / 1e6 / 2500.0,
+             "hbm_traffic_bytes_per_layer": (avg(fe) * 2048 + avg(wr) * 1024) / layers,
+             "FETCH_SIZE_KB_raw": avg(fe), "WRITE_SIZE_KB": avg(wr), "SQ_VALU_MFMA_BUSY_CYCLES": avg(mf),
+             "kernel_cycles": avg(gui) / 8, "effective_clock_GHz": avg(gui) / 8 / (avg(du) * 1e3),
+             "mfma_pipe_utilisation": (n_mfma * 16 / 1024) / (avg(gui) / 8)}
+        res[label] = e
+except Exception as ex:
+    res["error"] = repr(ex)
+json.dump(res, open(f"{out}/{tag}_wgrad6_pmc.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
+EOF6

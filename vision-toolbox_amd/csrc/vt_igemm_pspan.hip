@@ -757,13 +757,15 @@ int vt_pspan_dispatch(IgemmArgs& a0, int dtype, void* stream) {
         // two tensors do not overlap at all.  A shifted or re-strided alias would race silently: the ordered kernels take it.
         const long opix = (long)a0.B * a0.oH * a0.oW;
         const char* y0 = (const char*)a0.y;
-        const char* y1 = y0 + ((opix - 1) * a0.ldy + ((a0.flags & VT_CONV_D2S) ? 4L * a0.Cout : (long)a0.Cout)) * 2;
+        // (channels of one OUTPUT pixel: a depth-to-space launch computes 4 pixels' worth of columns per grid position)
+        const long pixc = (a0.flags & VT_CONV_D2S) ? a0.Cout / 4 : a0.Cout;
+        const char* y1 = y0 + ((opix - 1) * a0.ldy + pixc) * 2;
         const char* r0 = (const char*)a0.res;
-        const char* r1 = r0 + ((opix - 1) * a0.ldr + ((a0.flags & VT_CONV_D2S) ? 4L * a0.Cout : (long)a0.Cout)) * 2;
+        const char* r1 = r0 + ((opix - 1) * a0.ldr + pixc) * 2;
         const bool overlap = r0 < y1 && y0 < r1;
         if (overlap && !(r0 == y0 && a0.ldr == a0.ldy)) {
             // two channel slices of ONE wider buffer (same pixel stride, disjoint channel ranges) never share an element
-            const long cb = ((a0.flags & VT_CONV_D2S) ? 4L * a0.Cout : (long)a0.Cout) * 2, pitch = (long)a0.ldy * 2;
+            const long cb = pixc * 2, pitch = (long)a0.ldy * 2;
             long off = (r0 - y0) % pitch;
             if (off < 0) off += pitch;
             const bool slices = a0.ldr == a0.ldy && off >= cb && off + cb <= pitch;
