@@ -283,7 +283,7 @@ struct Graph {
 
 extern "C" {
 
-int vt_version(void) { return 101; }
+int vt_version(void) { return 102; }  // 102: round 5 (vt_conv_wgrad_group, vt_softmax_xent_eval, vt_comm_init_stat, vt_debug_hog)
 // Measurement aid (tools/rccl_hog.py): `wgs` workgroups of 256 threads that hold `lds_bytes` of LDS each and do nothing
 // until `microseconds` of wall clock have passed -- the footprint of a collective library's channel kernels beside the
 // step's own kernels (persistent, CU-owning kernels with static partitions wait for their slowest CU).
