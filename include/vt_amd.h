@@ -187,7 +187,9 @@ typedef struct vt_bn_eval_item {
     float eps;
 } vt_bn_eval_item;
 int vt_bn_eval_coeffs_batch(const vt_bn_eval_item* items, int32_t n, void* stream);
-/* y = [relu](z*scale + shift) [+ residual] */
+/* y = act(z*scale + shift) [+ residual].  `relu` here and in vt_bn_act_bwd_reduce / _bwd_apply is an ACTIVATION CODE
+ * (ConvNormAct's `act`, components.py:37-44): 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 SiLU ("swish"), 4 GELU (exact).  Codes 0 / 1
+ * are the Darknet / VoVNet path; 2-4 run generic instantiations of the same kernels (round 5). */
 int vt_bn_act_apply(const void* z, int32_t ldz, const float* scale, const float* shift,
                     const void* residual, int32_t ldr, void* y, int32_t ldy, int64_t M,
                     int32_t C, int32_t relu, int32_t dtype, void* stream);

@@ -200,12 +200,26 @@ def test_vovnet_ese_program_compiles_with_gradients():
 
 
 def test_unsupported_variants_raise_not_fallback():
+    # (round 5: ConvNormAct's own activation choices all have kernels -- their codes, components.py:37-44 ...)
+    assert [ConvNormAct(8, 8, act=a)._vt_relu() for a in ("none", "relu", "leaky_relu", "swish", "silu", "gelu")] == \
+        [0, 1, 2, 3, 3, 4]
+    # ... an activation that is NOT one of them raises, it does not fall back
     u = ConvNormAct(8, 8, act="gelu")
+    u.act = torch.nn.GELU(approximate="tanh")
     b = E.Builder(E.ParamStore(u), N.VT_F32, False, False)
     b.store.ensure(torch.device("cpu"))
     x = b.act(1, 4, 4, 8)
     with pytest.raises(NotImplementedError, match="activation"):
         u._vt_emit(b, x)
+    # the generic activations emit the unfused passes (conv, coefficients, normalise + activation) also in eval mode
+    u = ConvNormAct(8, 8, act="silu").eval()
+    b = E.Builder(E.ParamStore(u), N.VT_F32, False, False)
+    b.store.ensure(torch.device("cpu"))
+    u._vt_emit(b, b.act(1, 4, 4, 8))
+    kinds = [op.kind & 0xFFFF for op in b.fwd]
+    assert N.OP_BN_ACT_APPLY in kinds and N.OP_BN_EVAL_COEFFS in kinds
+    act_op = [op for op in b.fwd if (op.kind & 0xFFFF) == N.OP_BN_ACT_APPLY][0]
+    assert act_op.i[4] == 3  # the activation code travels in the op
     g = ConvNormAct(8, 8, groups=2)
     b = E.Builder(E.ParamStore(g), N.VT_F32, False, False)
     b.store.ensure(torch.device("cpu"))

@@ -11,6 +11,7 @@ incoming gradient, which amplifies that rounding, so gradients get 0.25 -- the f
 which shares every line of code except the MFMA opcode and the rounding, carries the
 strict check.
 """
+import copy
 import json
 
 import numpy as np
@@ -459,3 +460,50 @@ def test_odd_input_shapes_match_the_oracle(name, shape, training):
     for got, want in zip(maps, ref):
         # (a train-mode map of four values per channel -- 33 x 47 at stride 32 -- amplifies f32 rounding: 2e-3 there)
         assert rel_err(got.cpu(), want) < (2e-3 if min(want.shape[2:]) <= 2 and training else 2e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("act", ["leaky_relu", "swish", "silu", "gelu", "none"])
+@pytest.mark.parametrize("k,s", [(3, 1), (1, 1), (3, 2)])
+def test_conv_norm_act_other_activations_forward_backward(act, k, s, dtype):
+    """ConvNormAct's non-default activations (reference components.py:37-44: leaky_relu(0.2), swish / silu, gelu, none) on the
+    GPU path, train and eval mode, against the module's own torch children on the CPU in float64 (the CPU path of the SAME
+    class is the reference's arithmetic: nn.Conv2d -> nn.BatchNorm2d -> the activation)."""
+    from vision_toolbox.components import ConvNormAct
+
+    def rel_err(a, b):
+        return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+    torch.manual_seed(7)
+    m = ConvNormAct(16, 24, k, s, act=act)
+    with torch.no_grad():
+        m.norm.weight.uniform_(0.5, 1.5)
+        m.norm.bias.uniform_(-0.3, 0.3)
+        m.norm.running_mean.uniform_(-0.2, 0.2)
+        m.norm.running_var.uniform_(0.5, 1.5)
+    ref = copy.deepcopy(m).double()
+    x = torch.randn(4, 16, 13, 11)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    for training in (True, False):
+        m.train(training), ref.train(training)
+        xr = x.double().requires_grad_(True)
+        yr = ref.act(ref.norm(ref.conv(xr)))
+        gy = torch.randn(yr.shape, generator=torch.Generator().manual_seed(3)).double()
+        ref.zero_grad()
+        yr.backward(gy)
+        dev = m.cuda()
+        dev.compute_dtype = dtype
+        xd = x.cuda().requires_grad_(True)
+        before = N.launch_count()
+        yd = dev(xd)
+        dev.zero_grad()
+        yd.backward(gy.float().cuda())
+        torch.cuda.synchronize()
+        assert N.launch_count() > before
+        tol = 2e-5 if dtype == torch.float32 else 2e-2
+        assert rel_err(yd.float().cpu(), yr.detach()) < tol, (act, training, "y")
+        assert rel_err(xd.grad.float().cpu(), xr.grad) < (1e-4 if dtype == torch.float32 else 4e-2), (act, training, "dx")
+        assert rel_err(dev.conv.weight.grad.float().cpu(), ref.conv.weight.grad) < (1e-4 if dtype == torch.float32 else 4e-2)
+        assert rel_err(dev.norm.weight.grad.float().cpu(), ref.norm.weight.grad) < (1e-4 if dtype == torch.float32 else 4e-2)
+        m = dev.cpu()

@@ -136,9 +136,35 @@ __global__ void __launch_bounds__(256) bn_eval_coeffs_batch_kernel(const BnEvalB
 }
 
 // ---------------------------------------------------------------------------------
+// Activation codes of the `relu` argument of vt_bn_act_apply / _bwd_reduce / _bwd_apply (components.py:37-44): 0 none, 1 ReLU,
+// 2 LeakyReLU(0.2), 3 SiLU ("swish"), 4 GELU (exact, erf).  Codes 0 / 1 run the kernels' original instantiations (the hot
+// path); codes >= 2 a GEN instantiation of the same kernels, so that the Darknet / VoVNet launches keep their code.
+__device__ __forceinline__ float act_fwd(int code, float u) {
+    switch (code) {
+        case 1: return fmaxf(u, 0.f);
+        case 2: return u > 0.f ? u : 0.2f * u;
+        case 3: return u / (1.f + expf(-u));
+        case 4: return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
+        default: return u;
+    }
+}
+// d act / d u at pre-activation u
+__device__ __forceinline__ float act_grad(int code, float u) {
+    switch (code) {
+        case 1: return u > 0.f ? 1.f : 0.f;
+        case 2: return u > 0.f ? 1.f : 0.2f;
+        case 3: {
+            const float s = 1.f / (1.f + expf(-u));
+            return s * (1.f + u * (1.f - s));
+        }
+        case 4: return 0.5f * (1.f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * expf(-0.5f * u * u);
+        default: return 1.f;
+    }
+}
+
 // y = [relu](z*scale + shift) [+ residual]
 // ---------------------------------------------------------------------------------
-template <typename T, bool kRes>
+template <typename T, bool kRes, bool GEN = false>
 __global__ void __launch_bounds__(kThreads)
 bn_act_apply_kernel(const T* __restrict__ z, int ldz, const float* __restrict__ scale,
                     const float* __restrict__ shift, const T* __restrict__ res, int ldr, T* __restrict__ y,
@@ -184,7 +210,8 @@ bn_act_apply_kernel(const T* __restrict__ z, int ldz, const float* __restrict__ 
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     v[e] = fmaf(v[e], sc[e], sf[e]);
-                    v[e] = relu ? fmaxf(v[e], 0.f) : v[e];
+                    if constexpr (GEN) v[e] = act_fwd(relu, v[e]);
+                    else v[e] = relu ? fmaxf(v[e], 0.f) : v[e];
                 }
                 if (kRes) {
                     float rr[EPC];
@@ -445,13 +472,14 @@ bn_act_apply_pool_kernel(const T* __restrict__ z, int ldz, const float* __restri
 // ---------------------------------------------------------------------------------
 // BN backward, pass 1: per-channel sum(g) and sum(g*xhat), g = dy * [z*scale+shift > 0]
 // ---------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool GEN = false>
 __global__ void __launch_bounds__(kThreads)
 bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z, int ldz,
                      const float* __restrict__ scale, const float* __restrict__ shift,
                      const float* __restrict__ mean, const float* __restrict__ invstd, long M, int C,
                      RowMap rm, int relu_flags, float* __restrict__ sums, int Ctot) {
     const int relu = relu_flags & 1;  // bit 1: dev switch, LDS staging of every row lane (the pre-round-2 fold)
+    const int act = relu_flags >> 4;  // (GEN: the activation code)
     constexpr int EPC = VecIO<T>::EPC;
     // [RT][2][CT*EPC] partial sums: each thread parks its 2*EPC partials, then the first
     // 2*CT*EPC threads fold the RT row lanes (no LDS atomics: with RT rows per column they
@@ -504,7 +532,9 @@ bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z
                     VecIO<T>::unpack(vz[u], zz);
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) {
-                        const float gg = (!relu || fmaf(zz[e], sc[e], sf[e]) > 0.f) ? g[e] : 0.f;
+                        float gg;
+                        if constexpr (GEN) gg = g[e] * act_grad(act, fmaf(zz[e], sc[e], sf[e]));
+                        else gg = (!relu || fmaf(zz[e], sc[e], sf[e]) > 0.f) ? g[e] : 0.f;
                         s1[e] += gg;
                         s2[e] = fmaf(gg, zz[e] - mu[e], s2[e]);  // invstd applied once, below
                     }
@@ -581,7 +611,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, do
 }
 
 // dz = a*g - b*z + d
-template <typename T>
+template <typename T, bool GEN = false>
 __global__ void __launch_bounds__(kThreads)
 bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z, int ldz,
                     const float* __restrict__ scale, const float* __restrict__ shift,
@@ -625,7 +655,9 @@ bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z,
                 VecIO<T>::unpack(vz[u], zz);
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
-                    const float gg = (!relu || fmaf(zz[e], sc[e], sf[e]) > 0.f) ? g[e] : 0.f;
+                    float gg;
+                    if constexpr (GEN) gg = g[e] * act_grad(relu, fmaf(zz[e], sc[e], sf[e]));
+                    else gg = (!relu || fmaf(zz[e], sc[e], sf[e]) > 0.f) ? g[e] : 0.f;
                     g[e] = fmaf(ca[e], gg, fmaf(-cb[e], zz[e], cd[e]));
                 }
                 st16(dz + row * lddz + col * EPC, VecIO<T>::pack(g));
@@ -1468,6 +1500,22 @@ int vt_bn_act_apply(const void* z, int32_t ldz, const float* scale, const float*
     if (residual) VT_TRY(check_mat("vt_bn_act_apply(residual)", residual, ldr, C, dtype));
     RowMap rm = RowMap::make(C, vt_epc(dtype), M);
     rm.rev = (vt_bn_order() >> 0) & 1;
+    VT_REQUIRE(relu >= 0 && relu <= 4, VT_ERR_INVALID, "vt_bn_act_apply: activation code %d", relu);
+    if (relu >= 2) {  // LeakyReLU(0.2) / SiLU / GELU: the generic instantiation (off the Darknet / VoVNet path)
+        if (residual) {
+            VT_DISPATCH_T(dtype, "vt_bn_act_apply",
+                          hipLaunchKernelGGL((bn_act_apply_kernel<T, true, true>), dim3(rm.blocks(M)), dim3(kThreads), 0,
+                                             (hipStream_t)stream, (const T*)z, ldz, scale, shift, (const T*)residual, ldr,
+                                             (T*)y, ldy, (long)M, rm, relu));
+        } else {
+            VT_DISPATCH_T(dtype, "vt_bn_act_apply",
+                          hipLaunchKernelGGL((bn_act_apply_kernel<T, false, true>), dim3(rm.blocks(M)), dim3(kThreads), 0,
+                                             (hipStream_t)stream, (const T*)z, ldz, scale, shift, (const T*)residual, ldr,
+                                             (T*)y, ldy, (long)M, rm, relu));
+        }
+        VT_CHECK_LAUNCH("vt_bn_act_apply");
+        return VT_OK;
+    }
     if (residual) {
         VT_DISPATCH_T(dtype, "vt_bn_act_apply",
                       VT_LAUNCH_STOP((bn_act_apply_kernel<T, true>), dim3(rm.blocks(M)), dim3(kThreads), 0,
@@ -1502,6 +1550,15 @@ int vt_bn_act_bwd_reduce(const void* dy, int32_t lddy, const void* z, int32_t ld
     const int inwave_env = (1);
     const bool inwave = inwave_env && rm.CT < 64 && (rm.CT & (rm.CT - 1)) == 0;  // (as in the kernel)
     const int smem = (inwave ? kThreads / 64 : rm.RT) * 2 * rm.CT * epc * (int)sizeof(float);
+    VT_REQUIRE(relu >= 0 && relu <= 4, VT_ERR_INVALID, "vt_bn_act_bwd_reduce: activation code %d", relu);
+    if (relu >= 2) {
+        VT_DISPATCH_T(dtype, "vt_bn_act_bwd_reduce",
+                      hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(rm.blocks(M), cgroups), dim3(kThreads), smem,
+                                         (hipStream_t)stream, (const T*)dy, lddy, (const T*)z, ldz, scale, shift, mean,
+                                         invstd, (long)M, Cg, rm, (relu << 4) | (inwave_env ? 0 : 2), sums, C));
+        VT_CHECK_LAUNCH("vt_bn_act_bwd_reduce");
+        return VT_OK;
+    }
     VT_DISPATCH_T(dtype, "vt_bn_act_bwd_reduce",
                   hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(rm.blocks(M), cgroups), dim3(kThreads), smem,
                                      (hipStream_t)stream, (const T*)dy, lddy, (const T*)z, ldz, scale, shift,
@@ -1530,6 +1587,15 @@ int vt_bn_act_bwd_apply(const void* dy, int32_t lddy, const void* z, int32_t ldz
     VT_TRY(check_mat("vt_bn_act_bwd_apply(dz)", dz, lddz, C, dtype));
     RowMap rm = RowMap::make(C, vt_epc(dtype), M);
     rm.rev = (vt_bn_order() >> 2) & 1;
+    VT_REQUIRE(relu >= 0 && relu <= 4, VT_ERR_INVALID, "vt_bn_act_bwd_apply: activation code %d", relu);
+    if (relu >= 2) {
+        VT_DISPATCH_T(dtype, "vt_bn_act_bwd_apply",
+                      hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(rm.blocks(M)), dim3(kThreads), 0,
+                                         (hipStream_t)stream, (const T*)dy, lddy, (const T*)z, ldz, scale, shift, coef,
+                                         (T*)dz, lddz, (long)M, C, rm, relu));
+        VT_CHECK_LAUNCH("vt_bn_act_bwd_apply");
+        return VT_OK;
+    }
     VT_DISPATCH_T(dtype, "vt_bn_act_bwd_apply",
                   VT_LAUNCH_STOP(bn_bwd_apply_kernel<T>, dim3(rm.blocks(M)), dim3(kThreads), 0,
                                  (hipStream_t)stream, (const T*)dy, lddy, (const T*)z, ldz, scale, shift,

@@ -105,14 +105,22 @@ class ConvNormAct(nn.Sequential, HipModule):
             nn.init.kaiming_normal_(self.conv.weight, a=0.2, mode="fan_out", nonlinearity=act)
 
     # -- launch-list emission ----------------------------------------------------------
-    def _vt_relu(self) -> bool:
-        if isinstance(self.act, nn.ReLU):
-            return True
-        if isinstance(self.act, nn.Identity):
-            return False
+    def _vt_relu(self) -> int:
+        """activation code of the kernels (include/vt_amd.h): 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 SiLU, 4 GELU (exact)"""
+        a = self.act
+        if isinstance(a, nn.Identity):
+            return 0
+        if isinstance(a, nn.ReLU):
+            return 1
+        if isinstance(a, nn.LeakyReLU) and abs(a.negative_slope - 0.2) < 1e-12:
+            return 2
+        if isinstance(a, nn.SiLU):
+            return 3
+        if isinstance(a, nn.GELU) and getattr(a, "approximate", "none") == "none":
+            return 4
         raise NotImplementedError(
-            f"activation {type(self.act).__name__}: the MI355X hot path implements the reference's "
-            "default ReLU (and 'none'); other activations are outside the Darknet/VoVNet path"
+            f"activation {a!r}: the MI355X path implements ConvNormAct's own choices (components.py:37-44: none, relu, "
+            "leaky_relu(0.2), swish / silu, gelu)"
         )
 
     def _vt_emit(self, b, x, out=None, residual=None, name: str = "cna", pool_out=None):

@@ -543,8 +543,10 @@ class Builder:
             raise NotImplementedError(f"norm {type(norm).__name__} is outside the hot path")
         if has_bn and (norm.momentum is None or not norm.affine or not norm.track_running_stats):
             raise NotImplementedError("BatchNorm2d variants other than the default are outside the hot path")
+        relu = int(relu)  # activation code: 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 SiLU, 4 GELU (include/vt_amd.h)
+        generic_act = relu >= 2  # only the unfused BatchNorm passes implement these (off the Darknet / VoVNet path)
         if not has_bn and relu:
-            raise NotImplementedError("conv+relu without BatchNorm is outside the hot path")
+            raise NotImplementedError("conv + activation without BatchNorm is outside the hot path")
         Ho = (x.H + 2 * pad - k) // s + 1
         Wo = (x.W + 2 * pad - k) // s + 1
         ntaps = k * k
@@ -589,11 +591,11 @@ class Builder:
         # the unit follows ITS BatchNorm's flag (a frozen bn.eval() inside a training model uses the
         # running statistics and leaves them untouched, like nn.BatchNorm2d)
         unit_training = bool(norm.training) if has_bn else self.training
-        fused = has_bn and not unit_training and not track
+        fused = has_bn and not unit_training and not track and not generic_act
         y = out if out is not None else self.act(B, Ho, Wo, Cout, name + ".y")
         z = None
         coef = None
-        stem_fused = (track and padded and has_bn and not fused and residual is None and
+        stem_fused = (track and padded and has_bn and not fused and residual is None and not generic_act and
                       not x.needs_grad and w.requires_grad and dt == N.VT_BF16 and Cout == 32 and k == 3 and s == 1 and
                       pad == 1 and x.C == 8 and x.ld == 8 and x.W <= 888 and B * (x.H + 1) * (x.W + 1) < 0x7fff0000)  # (ring in LDS: halo <= 896 rows)
         stem_y = stem_fused and unit_training and x.W <= 824  # (one more step of halo)
@@ -632,7 +634,7 @@ class Builder:
                 self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, z.addr(), None, None, None, None], desc=d)
                 self.emit(N.OP_BN_EVAL_COEFFS, [g, b_, rm, rv, *cp], [Cout], [norm.eps])
             pool_am = None
-            if pool_out is not None:
+            if pool_out is not None and not generic_act:
                 assert (pool_out.B, pool_out.H, pool_out.W, pool_out.C) == (B, (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1, Cout)
                 pool_am = self.alloc(B * pool_out.H * pool_out.W * Cout, "argmax")
                 self.emit(N.OP_BN_ACT_APPLY,
@@ -651,7 +653,7 @@ class Builder:
                       [x.addr(), wptr, y.addr(), None, self.pref(conv.bias) if conv.bias is not None else None,
                        residual.addr() if residual else None, None], desc=d)
 
-        pool_fused = pool_out is not None and has_bn and not fused and not stem_y
+        pool_fused = pool_out is not None and has_bn and not fused and not stem_y and not generic_act
         if pool_out is not None and not pool_fused:
             self.maxpool3x3s2(y, out=pool_out, name=name + ".max_pool")  # (no normalise pass to fuse it into)
 
@@ -790,6 +792,8 @@ class Builder:
                 return 0
             if conv.in_channels != x.C or getattr(x, "logical_C", x.C) != x.C:
                 return 0
+            if int(relu) >= 2:
+                return 0  # (LeakyReLU / SiLU / GELU: the unfused BatchNorm passes only)
             flags.add((bool(norm.training), bool(relu)))
         if len(flags) != 1 or len({sp[3] is None for sp in specs}) != 1:  # (a residual for every group or for none)
             return 0
