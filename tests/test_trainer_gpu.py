@@ -369,7 +369,8 @@ def test_grouped_filter_gradients_equal_the_ungrouped_ones(monkeypatch):
     g1, run1, l1 = grads({"VT_WGRAD_GROUP": "1"})
     gi, runi, li = grads({"VT_WGRAD_INLINE": "1"})
     assert run8 >= 8 and runi >= 8 and run1 <= 2, (run8, runi, run1)
-    assert l8 == l1 == li  # forward and loss are bit-reproducible and do not depend on the filter-gradient schedule
+    # (the forward does not depend on the filter-gradient schedule; the reported scalar is a float atomic sum over the rows)
+    assert abs(l8 - l1) < 1e-6 * abs(l1) and abs(li - l1) < 1e-6 * abs(l1), (l8, l1, li)
     for k in g8:
         assert rel_err(g8[k], g1[k]) < 1e-5, k
         assert rel_err(gi[k], g1[k]) < 1e-5, k
