@@ -574,8 +574,11 @@ def main():
     ap.add_argument("--steps", type=int, default=100)  # >= 20 warm-up, >= 100 timed
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=None,
-                    help="per-GPU batch; default 256 on one GPU (BASELINE configs[1]), 128 per GPU on N > 1 "
-                         "(configs[2]: global 128*N = 1024 on 8 GPUs)")
+                    help="per-GPU batch; default 256 for every N (BASELINE configs[1] at N = 1; N > 1 is its WEAK scaling: the "
+                         "per-GPU work of the N = 1 line, global batch 256*N)")
+    ap.add_argument("--config3-batch", type=int, default=None,
+                    help="N > 1: per-GPU batch of the additional BASELINE configs[2] measurement carried by the same line "
+                         "(`config3`; default 128 = global batch 1024 on 8 GPUs when --batch is left at its default, else off; 0: off)")
     ap.add_argument("--no-secondary", action="store_true", help="skip configs[3] / configs[4] and the batch-128 step")
     ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "sharded"],
                     help="gradient exchange: f32 all-reduce per bucket (default) or reduce-scatter -> sharded SGD -> "
@@ -611,8 +614,15 @@ def main():
                     help="(tests) build the launch lists and the bucket plan on the CPU, run the first collectives "
                          "over the given backend and exit: exercises the N>1 launch path without a GPU")
     args = ap.parse_args()
+    if args.config3_batch is None:
+        args.config3_batch = 128 if args.batch is None else 0
     if args.batch is None:
-        args.batch = 256 if args.gpus == 1 else 128
+        # Round 5: 256 per GPU for EVERY N.  The driver derives the scaling efficiency from the per-N `value`s of this command;
+        # until round 4 the N > 1 lines ran BASELINE configs[2] (128 per GPU) against an N = 1 line at 256, so that quotient
+        # mixed the scaling with the batch-size effect on one GPU (12.1 ms at 128 = 0.83 of the rate at 256).  Now the series
+        # is weak scaling in the sense of the contract (per-GPU work fixed), and configs[2] is measured IN THE SAME RUN as
+        # `config3`, with its own single-GPU denominator.
+        args.batch = 256
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))  # before anything touches the GPU
@@ -775,6 +785,48 @@ def main():
             n1_ms, _ = time_train_step(args.model, args.batch, args.image_size, args.steps, args.warmup, dev)
         barrier()
 
+    # ---- N > 1: BASELINE configs[2] itself (128 images per GPU: global batch 1024 on 8 GPUs) in the same run ---------------
+    config3 = None
+    if world > 1 and not args.steps_only and args.config3_batch > 0 and args.config3_batch != args.batch:
+        b3 = args.config3_batch
+        k3, w3 = min(args.steps, 50), min(args.warmup, 10)
+        torch.manual_seed(0)
+        ts3 = TrainStep(getattr(backbones, args.model)(), 1000, b3, args.image_size, torch.bfloat16, lr=0.05, momentum=0.9,
+                        weight_decay=2e-5, label_smoothing=0.1, device=dev, bucket_mb=args.bucket_mb, use_graphs=args.graphs,
+                        sync_bn=args.sync_bn, deterministic=True if args.deterministic else None, exchange=args.exchange,
+                        collectives=coll)
+        ts3.broadcast_parameters(0)
+        ts3.images.copy_(torch.rand(ts3.images.shape, device=dev, generator=g))
+        ts3.labels.copy_(torch.randint(0, 1000, ts3.labels.shape, device=dev, generator=g))
+        for _ in range(w3):
+            ts3.step()
+        torch.cuda.synchronize()
+        barrier()
+        t3 = time.perf_counter()
+        for _ in range(k3):
+            ts3.step()
+        torch.cuda.synchronize()
+        el3 = time.perf_counter() - t3
+        t = torch.tensor([el3], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el3 = float(t.item())
+        loss3 = ts3.loss()
+        del ts3
+        torch.cuda.empty_cache()
+        n1_3 = None
+        if rank == 0:
+            n1_3, _ = time_train_step(args.model, b3, args.image_size, k3, w3, dev)
+        barrier()
+        if rank == 0:
+            v3 = b3 * world * k3 / el3
+            config3 = {"config": f"BASELINE configs[2]: {args.model} data-parallel train step, {b3} images per GPU, global batch "
+                                 f"{b3 * world}, same run, same ranks and communicator",
+                       "per_gpu_batch": b3, "global_batch": b3 * world, "steps": k3, "warmup": w3,
+                       "ms_per_step": round(el3 / k3 * 1e3, 3), "images_per_sec": round(v3, 1), "final_loss": round(loss3, 4),
+                       "n1_same_per_gpu_batch_ms": round(n1_3, 3),
+                       "n1_same_per_gpu_batch_images_per_sec": round(b3 / n1_3 * 1e3, 1),
+                       "weak_scaling_efficiency": round(v3 / (world * b3 / n1_3 * 1e3), 4)}
+
     if args.steps_only:
         if rank == 0:
             print(json.dumps({"steps_only": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -826,7 +878,9 @@ def main():
         # HBM-bound layers of stages 0-1 as the step runs them, in situ (HBM fraction on the early-stage convs)
         hbm_layers = hbm_layers_insitu(ts, args.batch) if args.model == "cspdarknet53" and args.image_size == 224 else []
         cfg = ("BASELINE configs[1]" if (world == 1 and args.batch == 256) else
-               f"BASELINE configs[2] (data parallel over RCCL, {args.batch} images per GPU, global batch {args.batch * world})"
+               (f"weak scaling of BASELINE configs[1]: data parallel over RCCL, {args.batch} images per GPU, global batch "
+                f"{args.batch * world}; BASELINE configs[2] ({args.config3_batch} per GPU) in `config3`" if config3 else
+                f"data parallel over RCCL, {args.batch} images per GPU, global batch {args.batch * world}")
                if world > 1 else f"single GPU, batch {args.batch}")
         out = {
             "metric": f"images/sec (node) {LABELS.get(args.model, args.model)} bf16 train step @{args.image_size}px",
@@ -878,6 +932,8 @@ def main():
             out["exchange_exposed_ms"] = round(exposed_ms, 3)
             out["exchange_exposed_note"] = ("ms_per_step minus the same data-parallel schedule timed with the collectives "
                                             "not issued (max over ranks); the N = 1 figures are rank 0 alone, same per-GPU batch")
+            if config3:
+                out["config3"] = config3
         if world == 1 and not args.no_secondary:
             del ts
             torch.cuda.empty_cache()

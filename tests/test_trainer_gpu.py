@@ -288,13 +288,18 @@ def test_bench_n2_falls_back_together_when_the_library_communicator_cannot_be_ma
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup",
-                        "1", "--batch", "16"], capture_output=True, text=True, timeout=900, env=env, cwd=str(root))
+                        "1", "--batch", "16", "--config3-batch", "8"], capture_output=True, text=True, timeout=900, env=env,
+                       cwd=str(root))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stderr.count("falling back to torch.distributed") == 2, r.stderr[-3000:]
     line = json.loads(next(l for l in reversed(r.stdout.splitlines()) if l.startswith("{")))
     assert line["n_gpus"] == 2 and line["config"]["collectives"] == "torch" and line["config"]["backend"] == "gloo"
     for key in ("n1_same_per_gpu_batch_ms", "weak_scaling_efficiency", "exchange_exposed_ms"):
         assert key in line
+    # BASELINE configs[2] (here: 8 per GPU) measured by the same run, with its own single-GPU denominator
+    c3 = line["config3"]
+    assert c3["per_gpu_batch"] == 8 and c3["global_batch"] == 16 and c3["ms_per_step"] > 0 and c3["n1_same_per_gpu_batch_ms"] > 0
+    assert line["config"]["per_gpu_batch"] == 16 and line["config"]["global_batch"] == 32
     buf = torch.zeros(16, device="cuda")  # the launch-count guard of this module wants a launch here too
     N.check(N.lib().vt_memset(buf.data_ptr(), 0, 64, int(torch.cuda.current_stream().cuda_stream)))
 
