@@ -912,7 +912,10 @@ def main():
                          "frac_fwd_dgrad_wgrad": round(tot_fl / tot_ms / 1e9 / PEAK_BF16_TFLOPS, 4) if tot_ms else None,
                          "traffic": traffic["bytes"] if traffic else None,
                          "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH x2 on gfx950) "
-                                            "run by this bench on tools/bench_conv.py" if traffic else None),
+                                            "run by this bench on tools/bench_conv.py: STANDALONE launches of this layer "
+                                            "back to back (x and the filter re-read from the memory-side cache where the step's "
+                                            "own launch finds what the previous kernels left), while launch_ms / frac are in situ"
+                                            if traffic else None),
                          "algorithmic_bytes": 2.0 * (args.batch * 28 * 28 * 256 + 128 * 1152),
                          "kernel": dom["kernel"], "launch_ms": round(dom["ms"], 4), "launches_timed": dom["n"],
                          "measured": "in situ (events around the layer's launches inside the step's forward list)"
