@@ -206,7 +206,9 @@ int vt_bn_act_bwd_reduce(const void* dy, int32_t lddy, const void* z, int32_t ld
 int vt_bn_bwd_finalize(const float* sums, int32_t C, double count, double pscale,
                        const float* scale, const float* mean, const float* invstd, int32_t train,
                        float* dgamma, float* dbeta, float* coef, void* stream);
-/* dz = coef0[c]*g - coef1[c]*z + coef2[c] */
+/* dz = coef0[c]*g - coef1[c]*z + coef2[c], g = dy * act'(z*scale + shift).
+ * scale, shift and coef ALL NULL: dz = dy * act'(z) -- the activation of a ConvNormAct built with norm="none"
+ * (reference components.py:36: nn.Identity between the biased conv and the activation). */
 int vt_bn_act_bwd_apply(const void* dy, int32_t lddy, const void* z, int32_t ldz,
                         const float* scale, const float* shift, const float* coef,
                         void* dz, int32_t lddz, int64_t M, int32_t C, int32_t relu,

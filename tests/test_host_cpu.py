@@ -220,11 +220,39 @@ def test_unsupported_variants_raise_not_fallback():
     assert N.OP_BN_ACT_APPLY in kinds and N.OP_BN_EVAL_COEFFS in kinds
     act_op = [op for op in b.fwd if (op.kind & 0xFFFF) == N.OP_BN_ACT_APPLY][0]
     assert act_op.i[4] == 3  # the activation code travels in the op
-    g = ConvNormAct(8, 8, groups=2)
+    # groups: one unit per group over channel slices (two conv launches, each 4 -> 4 channels of pixel stride 8) ...
+    g = ConvNormAct(8, 8, groups=2).eval()
     b = E.Builder(E.ParamStore(g), N.VT_F32, False, False)
     b.store.ensure(torch.device("cpu"))
-    with pytest.raises(NotImplementedError):
+    g._vt_emit(b, b.act(1, 4, 4, 8))
+    convs = [op for op in b.fwd if (op.kind & 0xFFFF) == N.OP_CONV_IGEMM]
+    assert len(convs) == 2
+    descs = [N.ConvDesc.from_buffer_copy(bytes(op.i)[: ctypes.sizeof(N.ConvDesc)]) for op in convs]
+    assert [(d.Cin, d.ldx, d.Cout, d.ldy, d.ldw) for d in descs] == [(4, 8, 4, 8, 36)] * 2
+    assert convs[1].ptr[1].offset - convs[0].ptr[1].offset == 4 * 36 * 4  # the second group's filter rows
+    # ... but not below one 16-byte chunk per group (depthwise): raises, no fallback
+    g = ConvNormAct(8, 8, groups=8)
+    b = E.Builder(E.ParamStore(g), N.VT_F32, False, False)
+    b.store.ensure(torch.device("cpu"))
+    with pytest.raises(NotImplementedError, match="depthwise"):
         g._vt_emit(b, b.act(1, 4, 4, 8))
+    # dilation: the taps move apart, the padding stays ceil((k - s) / 2) (components.py:31), so the map shrinks
+    dl = ConvNormAct(8, 8, dilation=2).eval()
+    b = E.Builder(E.ParamStore(dl), N.VT_F32, False, False)
+    b.store.ensure(torch.device("cpu"))
+    y = dl._vt_emit(b, b.act(1, 9, 7, 8))
+    assert (y.H, y.W) == (7, 5)
+    d = N.ConvDesc.from_buffer_copy(bytes([op for op in b.fwd if (op.kind & 0xFFFF) == N.OP_CONV_IGEMM][0].i)[: ctypes.sizeof(N.ConvDesc)])
+    assert [(d.dh[i], d.dw[i]) for i in range(9)] == [(2 * r, 2 * t) for r in range(3) for t in range(3)]
+    # norm="none": biased conv, then the activation through the unit-scale normalise pass
+    nn_ = ConvNormAct(8, 8, norm="none", act="leaky_relu").eval()
+    b = E.Builder(E.ParamStore(nn_), N.VT_F32, False, False)
+    b.store.ensure(torch.device("cpu"))
+    nn_._vt_emit(b, b.act(1, 4, 4, 8))
+    kinds = [op.kind & 0xFFFF for op in b.fwd]
+    assert kinds.count(N.OP_CONV_IGEMM) == 1 and N.OP_BN_ACT_APPLY in kinds and N.OP_BN_FINALIZE not in kinds
+    act_op = [op for op in b.fwd if (op.kind & 0xFFFF) == N.OP_BN_ACT_APPLY][0]
+    assert act_op.i[4] == 2 and act_op.ptr[1].base == -1 and act_op.ptr[2].base == -1  # no scale / shift
 
 
 def test_param_store_keeps_identity_names_and_values():

@@ -507,3 +507,118 @@ def test_conv_norm_act_other_activations_forward_backward(act, k, s, dtype):
         assert rel_err(dev.conv.weight.grad.float().cpu(), ref.conv.weight.grad) < (1e-4 if dtype == torch.float32 else 4e-2)
         assert rel_err(dev.norm.weight.grad.float().cpu(), ref.norm.weight.grad) < (1e-4 if dtype == torch.float32 else 4e-2)
         m = dev.cpu()
+
+
+def _variant_check(m, ref, x, dtype, fwd_ref, params):
+    """one train and one eval pass of HipModule `m` on the GPU against the float64 `ref` (same parameters) on the CPU"""
+    f32 = dtype == torch.float32
+    for training in (True, False):
+        # (bf16: the caller gives `ref` the bf16-ROUNDED filter the kernels read -- an unrounded one flips the sign of a
+        #  few pre-activations near zero, and one flipped mask element moves a gradient that is a sum of ~500 random-sign
+        #  terms by percents; with the same operands what remains is the rounding of the stored activations: 2e-3 to 1.7e-2, 3e-2 allowed.
+        #  In train mode BatchNorm backward subtracts the gradient's per-channel projections (most of it, at ~500 samples per
+        #  channel) and so amplifies that rounding (module docstring): 1.7-3.9e-2 measured, 8e-2 allowed; f32 is the strict run.
+        gtol = 1e-4 if f32 else (8e-2 if training else 3e-2)
+        m.train(training), ref.train(training)
+        xr = x.double().requires_grad_(True)
+        yr = fwd_ref(ref, xr)
+        gy = torch.randn(yr.shape, generator=torch.Generator().manual_seed(3)).double()
+        ref.zero_grad()
+        yr.backward(gy)
+        dev = m.cuda()
+        dev.compute_dtype = dtype
+        xd = x.cuda().requires_grad_(True)
+        before = N.launch_count()
+        yd = dev(xd)
+        dev.zero_grad()
+        yd.backward(gy.float().cuda())
+        torch.cuda.synchronize()
+        assert N.launch_count() > before
+        assert tuple(yd.shape) == tuple(yr.shape)
+        assert rel_err(yd.float().cpu(), yr.detach()) < (2e-5 if f32 else 1e-2), (training, "y")
+        assert rel_err(xd.grad.float().cpu(), xr.grad) < gtol, (training, "dx")
+        got = dict(dev.named_parameters())
+        for name, p in ref.named_parameters():
+            if name in params:
+                assert got[name].grad is not None, name
+                assert rel_err(got[name].grad.float().cpu(), p.grad) < gtol, (training, name)
+        if training and hasattr(ref, "norm") and isinstance(ref.norm, nn.BatchNorm2d):
+            assert rel_err(dev.norm.running_var.cpu(), ref.norm.running_var) < 1e-3
+            assert int(dev.norm.num_batches_tracked) == int(ref.norm.num_batches_tracked)
+        m = dev.cpu()
+
+
+VARIANTS = [  # Cin, Cout, k, s, kwargs
+    (16, 32, 3, 1, dict(groups=2)),
+    (32, 32, 3, 2, dict(groups=4)),
+    (32, 16, 1, 1, dict(groups=2)),
+    (16, 24, 3, 1, dict(dilation=2)),
+    (16, 24, 3, 2, dict(dilation=2)),
+    (8, 16, 3, 1, dict(dilation=3)),
+    (16, 24, 3, 1, dict(norm="none", act="relu")),
+    (16, 24, 1, 1, dict(norm="none", act="leaky_relu")),
+    (16, 24, 3, 2, dict(norm="none", act="gelu")),
+    (16, 24, 3, 1, dict(norm="none", act="none")),
+    (32, 32, 3, 1, dict(groups=2, dilation=2, norm="none", act="silu")),
+    (32, 32, 3, 2, dict(groups=2, dilation=2, act="leaky_relu")),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", VARIANTS, ids=lambda c: f"{c[0]}-{c[1]}k{c[2]}s{c[3]}" + "".join(f"_{k}{v}" for k, v in c[4].items()))
+def test_conv_norm_act_groups_dilation_and_no_norm(case, dtype):
+    """The remaining constructor arguments of ConvNormAct (reference components.py:13-36): `groups` (one unit per group
+    over channel slices), `dilation` (taps apart, padding unchanged: the map shrinks) and norm="none" (biased conv, then
+    the activation) -- forward, input gradient and every parameter gradient, train and eval, against the module's own
+    torch children in float64 on the CPU."""
+    Cin, Cout, k, s, kw = case
+    torch.manual_seed(11)
+    m = ConvNormAct(Cin, Cout, k, s, **kw)
+    with torch.no_grad():
+        if isinstance(m.norm, nn.BatchNorm2d):
+            m.norm.weight.uniform_(0.5, 1.5)
+            m.norm.bias.uniform_(-0.3, 0.3)
+            m.norm.running_mean.uniform_(-0.2, 0.2)
+            m.norm.running_var.uniform_(0.5, 1.5)
+        else:
+            m.conv.bias.uniform_(-0.5, 0.5)
+    ref = copy.deepcopy(m).double()
+    x = torch.randn(4, Cin, 13, 11)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+        with torch.no_grad():
+            ref.conv.weight.copy_(m.conv.weight.bfloat16().double())
+    names = {"conv.weight", "conv.bias", "norm.weight", "norm.bias"}
+    _variant_check(m, ref, x, dtype, lambda r, xr: r.act(r.norm(r.conv(xr))), names)
+
+
+def test_grouped_unit_inside_a_chain_with_a_shortcut():
+    """A grouped unit between ordinary ones, with a shortcut around it: its input's gradient is written slice by slice by
+    the groups and ALSO receives a full-width identity contribution, and its output's gradient arrives full width (from the
+    next unit's data gradient) and is read slice by slice -- the cases the gradient bookkeeping has to split."""
+    from vision_toolbox.components import HipModule
+
+    class Chain(HipModule):
+        def __init__(self):
+            super().__init__()
+            self.a = ConvNormAct(8, 32, 3, 1)
+            self.g = ConvNormAct(32, 32, 3, 1, groups=4)
+            self.c = ConvNormAct(32, 16, 1, 1)
+            self.out_channels_list = (16,)
+            self.stride = 1
+
+        def _vt_emit_maps(self, b, x):
+            y = self.a._vt_emit(b, x)
+            y2 = self.g._vt_emit(b, y, residual=y)
+            return [self.c._vt_emit(b, y2)]
+
+        def _eager_maps(self, x):
+            y = self.a(x)
+            return [self.c(self.g(y) + y)]
+
+    torch.manual_seed(5)
+    m = Chain()
+    ref = copy.deepcopy(m).double()
+    x = torch.randn(3, 8, 10, 9)
+    _variant_check(m, ref, x, torch.float32, lambda r, xr: r._eager_maps(xr)[-1],
+                   {n for n, _ in m.named_parameters()})

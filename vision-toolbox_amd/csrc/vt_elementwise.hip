@@ -627,11 +627,19 @@ bn_bwd_apply_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z,
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             const int c = col * EPC + e;
-            sc[e] = scale[c];
-            sf[e] = shift[c];
-            ca[e] = coef[c];
-            cb[e] = coef[C + c];
-            cd[e] = coef[2 * C + c];
+            if constexpr (GEN) {  // (no coefficients: dz = dy * act'(z), the unit without a BatchNorm)
+                sc[e] = scale ? scale[c] : 1.f;
+                sf[e] = shift ? shift[c] : 0.f;
+                ca[e] = coef ? coef[c] : 1.f;
+                cb[e] = coef ? coef[C + c] : 0.f;
+                cd[e] = coef ? coef[2 * C + c] : 0.f;
+            } else {
+                sc[e] = scale[c];
+                sf[e] = shift[c];
+                ca[e] = coef[c];
+                cb[e] = coef[C + c];
+                cd[e] = coef[2 * C + c];
+            }
         }
         for (int it = 0; it < rm.iters; it += kUnroll) {
             uint4 vg[kUnroll], vz[kUnroll];
@@ -1581,14 +1589,16 @@ int vt_bn_bwd_finalize(const float* sums, int32_t C, double count, double pscale
 int vt_bn_act_bwd_apply(const void* dy, int32_t lddy, const void* z, int32_t ldz, const float* scale,
                         const float* shift, const float* coef, void* dz, int32_t lddz, int64_t M, int32_t C,
                         int32_t relu, int32_t dtype, void* stream) {
-    VT_REQUIRE(M > 0 && scale && shift && coef, VT_ERR_INVALID, "vt_bn_act_bwd_apply: bad argument");
+    // (scale, shift, coef all NULL: dz = dy * act'(z) -- a ConvNormAct with norm="none", components.py:36)
+    const bool act_only = !scale && !shift && !coef;
+    VT_REQUIRE(M > 0 && (act_only || (scale && shift && coef)), VT_ERR_INVALID, "vt_bn_act_bwd_apply: bad argument");
     VT_TRY(check_mat("vt_bn_act_bwd_apply(dy)", dy, lddy, C, dtype));
     VT_TRY(check_mat("vt_bn_act_bwd_apply(z)", z, ldz, C, dtype));
     VT_TRY(check_mat("vt_bn_act_bwd_apply(dz)", dz, lddz, C, dtype));
     RowMap rm = RowMap::make(C, vt_epc(dtype), M);
     rm.rev = (vt_bn_order() >> 2) & 1;
     VT_REQUIRE(relu >= 0 && relu <= 4, VT_ERR_INVALID, "vt_bn_act_bwd_apply: activation code %d", relu);
-    if (relu >= 2) {
+    if (relu >= 2 || act_only) {
         VT_DISPATCH_T(dtype, "vt_bn_act_bwd_apply",
                       hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(rm.blocks(M)), dim3(kThreads), 0,
                                          (hipStream_t)stream, (const T*)dy, lddy, (const T*)z, ldz, scale, shift, coef,

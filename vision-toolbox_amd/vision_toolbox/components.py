@@ -8,6 +8,10 @@ is execution: on the GPU the unit is not three ATen calls but a few launches of
 libvt_amd (implicit-GEMM conv on MFMA with the BN statistics in its epilogue, one
 normalise+ReLU(+residual) pass), emitted into a static launch list by `_vt_emit`.
 CPU tensors run the children with plain torch ops (`_eager_maps`), as in the reference.
+
+Every constructor argument of the reference unit runs on the GPU: the Darknet / VoVNet configuration (bn + relu, groups
+= dilation = 1) on the fused kernels; other activations, `groups` (>= one 16-byte channel chunk per group), `dilation`
+and norm="none" on the general kernels (engine.Builder.conv_unit / _grouped_unit).  Depthwise groups raise.
 """
 from __future__ import annotations
 

@@ -83,6 +83,18 @@ class TRef:
         return (self.B, self.H, self.W, self.C) == (o.B, o.H, o.W, o.C)
 
 
+class _PSlice:
+    """Elements [start, start + n) of a parameter or buffer of the flat store: one group's rows of a grouped convolution's
+    filter, its share of the bias and of the BatchNorm vectors (conv_unit, `groups > 1`)."""
+
+    def __init__(self, base, start: int, n: int):
+        self.base, self.start, self.n = base, int(start), int(n)
+        self.requires_grad = bool(getattr(base, "requires_grad", False))
+
+    def numel(self) -> int:
+        return self.n
+
+
 class ParamStore:
     """Flat f32 storage behind every parameter / buffer of a module tree.
 
@@ -183,6 +195,9 @@ class ParamStore:
         self.version += 1
 
     def where(self, t) -> tuple[int, int, int]:
+        if isinstance(t, _PSlice):
+            base, off, _ = self.index[id(t.base)]
+            return base, off + t.start, t.n
         return self.index[id(t)]
 
     def param_signature(self):
@@ -368,6 +383,9 @@ class Builder:
         """address of the f32 gradient accumulator of parameter p (None if it needs none)."""
         if not p.requires_grad:
             return None
+        if isinstance(p, _PSlice):
+            a = self.pgrad(p.base)
+            return (a[0], a[1] + 4 * p.start)
         if self.grad_base == GRADS:
             _, off, _ = self.store.where(p)
             return (GRADS, off * 4)
@@ -400,7 +418,14 @@ class Builder:
         for a, b, add in gs.pending:
             if a < c1 and c0 < b:
                 if not (c0 <= a and b <= c1):
-                    raise NotImplementedError("pending gradient straddles the requested slice")
+                    # a contribution wider than the requested slice (a grouped convolution reads channel slices of a
+                    # tensor whose gradient arrives full width): the part inside is added now, the rest stays pending
+                    lo, hi = max(a, c0), min(b, c1)
+                    if a < lo:
+                        keep.append((a, lo, add.sl(0, lo - a)))
+                    if hi < b:
+                        keep.append((hi, b, add.sl(hi - a, b - hi)))
+                    add, a, b = add.sl(lo - a, hi - lo), lo, hi
                 sub = t.sl(a - c0, b - a)
                 g = self._gref(sub)
                 acc = gs.covered(a, b)
@@ -458,8 +483,8 @@ class Builder:
         if not gs.touches(c0, c1):
             if not over:
                 return None
-            if len(over) == 1 and over[0][0] == c0 and over[0][1] == c1:
-                return over[0][2]  # read-only alias of the single contribution
+            if len(over) == 1 and over[0][0] <= c0 and c1 <= over[0][1]:
+                return over[0][2].sl(c0 - over[0][0], c1 - c0)  # read-only alias of the single contribution
         self._flush_pending(t)
         if not gs.covered(c0, c1):
             # zero-fill the gaps (only dense full-width buffers can be memset)
@@ -498,10 +523,10 @@ class Builder:
         return x
 
     # -- the ConvNormAct unit (reference components.py:13-46) --------------------------
-    def _taps(self, k: int):
-        return [(r, t) for r in range(k) for t in range(k)]
+    def _taps(self, k: int, dil: int = 1):
+        return [(r * dil, t * dil) for r in range(k) for t in range(k)]
 
-    def _conv_desc(self, x: TRef, Cout, Ho, Wo, s, pad, k, ldy, ldw, flags, ldr=0) -> N.ConvDesc:
+    def _conv_desc(self, x: TRef, Cout, Ho, Wo, s, pad, k, ldy, ldw, flags, ldr=0, dil=1) -> N.ConvDesc:
         d = N.ConvDesc()
         d.dtype = self.dtype
         d.B, d.Hi, d.Wi, d.Cin, d.ldx = x.B, x.H, x.W, x.C, x.ld
@@ -510,7 +535,7 @@ class Builder:
         d.oHs = d.oWs = 1
         d.oh0 = d.ow0 = 0
         d.ldw, d.ldr, d.flags = ldw, ldr, flags
-        taps = self._taps(k)
+        taps = self._taps(k, dil)
         d.ntaps = len(taps)
         for i, (r, t) in enumerate(taps):
             d.dh[i], d.dw[i] = r, t
@@ -527,9 +552,16 @@ class Builder:
         dt, epc = self.dtype, _EPC[self.dtype]
         k, s = conv.kernel_size[0], conv.stride[0]
         pad = conv.padding[0]
+        dil = conv.dilation[0]
         if conv.kernel_size[0] != conv.kernel_size[1] or conv.stride[0] != conv.stride[1] or \
-                conv.dilation != (1, 1) or conv.groups != 1 or conv.padding[0] != conv.padding[1]:
-            raise NotImplementedError("hot path covers square, undilated, ungrouped convolutions")
+                conv.dilation[0] != conv.dilation[1] or conv.padding[0] != conv.padding[1]:
+            raise NotImplementedError("hot path covers square convolutions (kernel, stride, dilation, padding)")
+        if dil * (k - 1) > 127:
+            raise NotImplementedError(f"dilation {dil}: tap offsets are 8-bit")
+        if conv.groups != 1:
+            self.tag -= 1
+            self.n_units -= 1
+            return self._grouped_unit(x, conv, norm, relu, residual, out, name, pool_out)
         if k * k > N.VT_MAX_TAPS:
             raise NotImplementedError(f"kernel {k}x{k} exceeds {N.VT_MAX_TAPS} taps")
         Cout, Cin_w = conv.out_channels, conv.in_channels
@@ -538,17 +570,17 @@ class Builder:
             raise ValueError(f"conv expects {Cin_w} input channels, got {logical_cin}")
         if Cout % epc:
             raise NotImplementedError(f"out_channels={Cout} must be a multiple of {epc} for dtype {dt}")
-        has_bn = isinstance(norm, nn.BatchNorm2d)
+        has_bn = isinstance(norm, nn.BatchNorm2d) or getattr(norm, "_vt_bn", False)
         if norm is not None and not has_bn and not isinstance(norm, nn.Identity):
             raise NotImplementedError(f"norm {type(norm).__name__} is outside the hot path")
         if has_bn and (norm.momentum is None or not norm.affine or not norm.track_running_stats):
             raise NotImplementedError("BatchNorm2d variants other than the default are outside the hot path")
         relu = int(relu)  # activation code: 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 SiLU, 4 GELU (include/vt_amd.h)
         generic_act = relu >= 2  # only the unfused BatchNorm passes implement these (off the Darknet / VoVNet path)
-        if not has_bn and relu:
-            raise NotImplementedError("conv + activation without BatchNorm is outside the hot path")
-        Ho = (x.H + 2 * pad - k) // s + 1
-        Wo = (x.W + 2 * pad - k) // s + 1
+        Ho = (x.H + 2 * pad - dil * (k - 1) - 1) // s + 1
+        Wo = (x.W + 2 * pad - dil * (k - 1) - 1) // s + 1
+        if Ho <= 0 or Wo <= 0:
+            raise ValueError(f"{name}: a {x.H}x{x.W} map is smaller than the dilated {k}x{k} kernel")
         ntaps = k * k
         B = x.B
         M = B * Ho * Wo
@@ -597,40 +629,41 @@ class Builder:
         coef = None
         stem_fused = (track and padded and has_bn and not fused and residual is None and not generic_act and
                       not x.needs_grad and w.requires_grad and dt == N.VT_BF16 and Cout == 32 and k == 3 and s == 1 and
-                      pad == 1 and x.C == 8 and x.ld == 8 and x.W <= 888 and B * (x.H + 1) * (x.W + 1) < 0x7fff0000)  # (ring in LDS: halo <= 896 rows)
+                      dil == 1 and pad == 1 and x.C == 8 and x.ld == 8 and x.W <= 888 and B * (x.H + 1) * (x.W + 1) < 0x7fff0000)  # (ring in LDS: halo <= 896 rows)
         stem_y = stem_fused and unit_training and x.W <= 824  # (one more step of halo)
         if has_bn:
             coef = self.f32(4 * Cout, "bncoef")  # scale, shift, mean, invstd
             cp = [self.bp(coef, i * Cout * 4) for i in range(4)]
             g, b_, rm, rv = (self.pref(norm.weight), self.pref(norm.bias), self.pref(norm.running_mean),
                              self.pref(norm.running_var))
+            nbt = self.pref(norm.num_batches_tracked) if norm.num_batches_tracked is not None else None
         if fused:
             self.emit(N.OP_BN_EVAL_COEFFS, [g, b_, rm, rv, cp[0], cp[1], None, None], [Cout], [norm.eps])
             flags = N.VT_CONV_AFFINE | (N.VT_CONV_RELU if relu else 0) | (N.VT_CONV_RESIDUAL if residual else 0)
-            d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, y.ld, ldw, flags, residual.ld if residual else 0)
+            d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, y.ld, ldw, flags, residual.ld if residual else 0, dil=dil)
             self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, y.addr(), cp[0], cp[1],
                                         residual.addr() if residual else None, None], desc=d)
         elif stem_y:
             y.stem_out = True  # (the unit that reads it releases its filter gradient late: wgrad_late_stem)
             stats = self.zeroed_f32(N.stat_floats(Cout), "stats")
-            d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, y.ld, ldw, N.VT_CONV_STATS | N.VT_CONV_NOSTORE)
+            d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, y.ld, ldw, N.VT_CONV_STATS | N.VT_CONV_NOSTORE, dil=dil)
             self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, None, None, None, None, self.bp(stats)], desc=d)
             self.emit(N.OP_BN_FINALIZE,
-                      [self.bp(stats), g, b_, rm, rv, self.pref(norm.num_batches_tracked), *cp],
+                      [self.bp(stats), g, b_, rm, rv, nbt, *cp],
                       [Cout], [M * self.bn_world, norm.eps, norm.momentum])
-            d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, y.ld, ldw, N.VT_CONV_AFFINE | (N.VT_CONV_RELU if relu else 0))
+            d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, y.ld, ldw, N.VT_CONV_AFFINE | (N.VT_CONV_RELU if relu else 0), dil=dil)
             self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, y.addr(), cp[0], cp[1], None, None], desc=d)
         elif has_bn:
             z = self.act(B, Ho, Wo, Cout, name + ".z")
             if unit_training:
                 stats = self.zeroed_f32(N.stat_floats(Cout), "stats")
-                d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, z.ld, ldw, N.VT_CONV_STATS)
+                d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, z.ld, ldw, N.VT_CONV_STATS, dil=dil)
                 self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, z.addr(), None, None, None, self.bp(stats)], desc=d)
                 self.emit(N.OP_BN_FINALIZE,
-                          [self.bp(stats), g, b_, rm, rv, self.pref(norm.num_batches_tracked), *cp],
+                          [self.bp(stats), g, b_, rm, rv, nbt, *cp],
                           [Cout], [M * self.bn_world, norm.eps, norm.momentum])
             else:
-                d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, z.ld, ldw, 0)
+                d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, z.ld, ldw, 0, dil=dil)
                 self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, z.addr(), None, None, None, None], desc=d)
                 self.emit(N.OP_BN_EVAL_COEFFS, [g, b_, rm, rv, *cp], [Cout], [norm.eps])
             pool_am = None
@@ -645,10 +678,22 @@ class Builder:
                 self.emit(N.OP_BN_ACT_APPLY,
                           [z.addr(), cp[0], cp[1], residual.addr() if residual else None, y.addr()],
                           [z.ld, residual.ld if residual else 0, y.ld, Cout, int(relu), dt], [M])
+        elif relu:
+            # conv (+bias) -> activation, no BatchNorm: ConvNormAct(norm="none") (components.py:33-36).  The
+            # pre-activation is kept (backward needs act'(z)); the activation is the unit-scale form of the normalise pass.
+            z = self.act(B, Ho, Wo, Cout, name + ".z")
+            d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, z.ld, ldw, N.VT_CONV_AFFINE if conv.bias is not None else 0,
+                                dil=dil)
+            self.emit(N.OP_CONV_IGEMM,
+                      [x.addr(), wptr, z.addr(), None, self.pref(conv.bias) if conv.bias is not None else None,
+                       None, None], desc=d)
+            self.emit(N.OP_BN_ACT_APPLY,
+                      [z.addr(), None, None, residual.addr() if residual else None, y.addr()],
+                      [z.ld, residual.ld if residual else 0, y.ld, Cout, int(relu), dt], [M])
         else:
             # plain conv (+bias): ESE gate conv (vovnet.py:24), classifier head (classifier.py:63)
             flags = (N.VT_CONV_AFFINE if conv.bias is not None else 0) | (N.VT_CONV_RESIDUAL if residual else 0)
-            d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, y.ld, ldw, flags, residual.ld if residual else 0)
+            d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, y.ld, ldw, flags, residual.ld if residual else 0, dil=dil)
             self.emit(N.OP_CONV_IGEMM,
                       [x.addr(), wptr, y.addr(), None, self.pref(conv.bias) if conv.bias is not None else None,
                        residual.addr() if residual else None, None], desc=d)
@@ -659,7 +704,7 @@ class Builder:
 
         wg_key = None
         if (track and has_bn and not fused and not stem_fused and not padded and w.requires_grad and dt == N.VT_BF16 and
-                k == 3 and s == 1 and pad == 1 and x.C > 32 and Cout > 32 and self.wgrad_group > 1 and
+                k == 3 and s == 1 and dil == 1 and pad == 1 and x.C > 32 and Cout > 32 and self.wgrad_group > 1 and
                 not self.deterministic):
             wg_key = (B, x.H, x.W, x.C, x.ld, Cout, ldw)
             self._wg_expect[wg_key] = self._wg_expect.get(wg_key, 0) + 1
@@ -731,6 +776,10 @@ class Builder:
                               [g_.ld, z.ld, dz.ld, Cout, int(relu), dt] + geo, [M])
                 else:
                     dz = dy
+                    if relu:  # dz = dy * act'(z)
+                        dz = self.act(B, Ho, Wo, Cout, name + ".dz")
+                        self.emit(N.OP_BN_BWD_APPLY, [dy.addr(), z.addr(), None, None, None, dz.addr()],
+                                  [dy.ld, z.ld, dz.ld, Cout, int(relu), dt], [M])
                     if conv.bias is not None and conv.bias.requires_grad:
                         if self.deterministic:
                             qb = self.zeroed_f32(4 * Cout, "dbq", bwd=True)
@@ -743,7 +792,7 @@ class Builder:
                 def emit_wgrad():
                     if not w.requires_grad:
                         return
-                    dfwd = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, dz.ld, ldw, 0)
+                    dfwd = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, dz.ld, ldw, 0, dil=dil)
                     if wg_key is not None:
                         self._wgrad_hold(wg_key, x.addr(), dz.addr(), self.pgrad(w), dfwd, ldw)
                         return
@@ -771,11 +820,57 @@ class Builder:
                 # data gradient
                 if x.needs_grad:
                     self._dgrad(x, dz, wptr if not padded else self.bp(wpack), dt if (padded or dt != N.VT_F32) else N.VT_F32,
-                                ldw, Cout, k, s, pad, Ho, Wo)
+                                ldw, Cout, k, s, pad, Ho, Wo, dil)
                 if late:
                     emit_wgrad()
 
             self.nodes.append(bwd)
+        return y
+
+    def _grouped_unit(self, x: TRef, conv, norm, relu, residual, out, name, pool_out) -> TRef:
+        """nn.Conv2d(groups=G) inside a ConvNormAct (reference components.py:32): G independent units over channel slices
+        of x and y -- the kernels take a pixel stride and a channel offset, the filter rows of a group are contiguous in
+        the [Cout][kh][kw][Cin / G] image, and BatchNorm is per channel, so a group's statistics, coefficients and
+        parameter gradients are slices too.  Slices are addressed in 16-byte chunks: Cin / G and Cout / G must be
+        multiples of 8 (bf16) / 4 (f32); depthwise convolutions are outside the Darknet / VoVNet path."""
+        import types
+
+        G = conv.groups
+        Cin, Cout = conv.in_channels, conv.out_channels
+        ci, co = Cin // G, Cout // G
+        epc = _EPC[self.dtype]
+        if getattr(x, "logical_C", x.C) != Cin or x.C != Cin:
+            raise ValueError(f"conv expects {Cin} (unpadded) input channels, got {getattr(x, 'logical_C', x.C)}")
+        if ci % epc or co % epc:
+            raise NotImplementedError(
+                f"groups={G} with {ci} -> {co} channels per group: channel slices are addressed in 16-byte chunks "
+                f"({epc} elements); depthwise / narrow groups are outside the hot path")
+        k, s, pad, dil = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0]
+        Ho = (x.H + 2 * pad - dil * (k - 1) - 1) // s + 1
+        Wo = (x.W + 2 * pad - dil * (k - 1) - 1) // s + 1
+        y = out if out is not None else self.act(x.B, Ho, Wo, Cout, name + ".y")
+        assert (y.B, y.H, y.W, y.C) == (x.B, Ho, Wo, Cout), "out geometry mismatch"
+        has_bn = isinstance(norm, nn.BatchNorm2d)
+        wn = co * k * k * ci
+        for g in range(G):
+            cg = types.SimpleNamespace(
+                kernel_size=conv.kernel_size, stride=conv.stride, padding=conv.padding, dilation=conv.dilation, groups=1,
+                in_channels=ci, out_channels=co, weight=_PSlice(conv.weight, g * wn, wn),
+                bias=_PSlice(conv.bias, g * co, co) if conv.bias is not None else None, _vt_slice=True)
+            ng = norm
+            if has_bn:
+                ng = types.SimpleNamespace(
+                    weight=_PSlice(norm.weight, g * co, co), bias=_PSlice(norm.bias, g * co, co),
+                    running_mean=_PSlice(norm.running_mean, g * co, co), running_var=_PSlice(norm.running_var, g * co, co),
+                    # (the batch counter belongs to the module, not to a group: the first group's finalize advances it)
+                    num_batches_tracked=norm.num_batches_tracked if g == 0 else None,
+                    eps=norm.eps, momentum=norm.momentum, affine=norm.affine, track_running_stats=norm.track_running_stats,
+                    training=norm.training, _vt_bn=True)
+            self.conv_unit(x.sl(g * ci, ci), cg, ng, relu,
+                           residual=residual.sl(g * co, co) if residual is not None else None,
+                           out=y.sl(g * co, co), name=f"{name}.g{g}")
+        if pool_out is not None:
+            self.maxpool3x3s2(y, out=pool_out, name=name + ".max_pool")
         return y
 
     # -- pointwise (1x1) units without stored pre-activations (vt_pointwise.hip) ------------------------------------
@@ -786,6 +881,8 @@ class Builder:
             return 0
         flags = set()
         for conv, norm, relu, residual, out, _ in specs:
+            if getattr(conv, "_vt_slice", False):  # (one group of a grouped convolution: parameter slices)
+                return 0
             if (conv.kernel_size != (1, 1) or conv.stride != (1, 1) or conv.padding != (0, 0) or conv.dilation != (1, 1)
                     or conv.groups != 1 or conv.bias is not None or not isinstance(norm, nn.BatchNorm2d)
                     or norm.momentum is None or not norm.affine or not norm.track_running_stats):
@@ -939,12 +1036,12 @@ class Builder:
             for xa, dza, dwa, desc, ldw in pend:
                 self.emit(N.OP_CONV_WGRAD, [xa, dza, dwa, None], desc=desc, extra_ints=[ldw, 0], side=side)
 
-    def _dgrad(self, x: TRef, dz: TRef, wptr, w_dtype, ldw, Cout, k, s, pad, Ho, Wo):
+    def _dgrad(self, x: TRef, dz: TRef, wptr, w_dtype, ldw, Cout, k, s, pad, Ho, Wo, dil=1):
         dt = self.dtype
         # the s*s parity classes tile d(x) disjointly, so they share one destination and
         # one folded addend: every pixel is produced exactly once
         gx, res = self.grad_target(x)
-        if (s == 2 and k == 3 and pad == 1 and x.H % 2 == 0 and x.W % 2 == 0 and Cout <= self.dgrad_d2s_maxc and
+        if (s == 2 and k == 3 and dil == 1 and pad == 1 and x.H % 2 == 0 and x.W % 2 == 0 and Cout <= self.dgrad_d2s_maxc and
                 (4 * x.C) % (4 * _EPC[dt]) == 0 and dt == N.VT_BF16):
             # Every parity class (ph, pw) of d(x) reads dz at offsets {0, 1}^2 of its own grid position, so the four
             # are the column blocks of ONE 2x2-tap convolution over dz with 4*C output columns (zero taps where a
@@ -984,20 +1081,31 @@ class Builder:
                                         res.addr() if res is not None else None, None], desc=d)
             self.grad_written(x)
             return
+        # A dilated strided convolution may never read some parity classes of its input (s = 2, dilation 2: the rows
+        # 2i - 1 + 2r are all odd): those classes of d(x) are zero, i.e. the folded addend alone.  The whole of d(x) is
+        # initialised first then (addend or zeros) and the classes that exist accumulate into it.
+        if any(all((ph + pad - r * dil) % s for r in range(k)) for ph in range(s)):
+            if res is None:
+                zeros = self.act(x.B, x.H, x.W, x.C, "d0")
+                self.emit(N.OP_MEMSET, [zeros.addr()], [0], [zeros.M * zeros.C * zeros.esize])
+                self._add_into(gx, zeros, False)
+            elif not (res.buf is gx.buf and res.coff == gx.coff):
+                self._add_into(gx, res, False)
+            res = gx
         for ph in range(s):
             for pw in range(s):
-                r0, t0 = (ph + pad) % s, (pw + pad) % s
-                rows = list(range(r0, k, s))
-                cols = list(range(t0, k, s))
+                # d(x)[ph + s*c] = sum over the filter rows r with (ph + pad - r*dil) divisible by s of
+                # dz[c + (ph + pad - r*dil) / s] * w[r]  (columns alike): a stride-1 convolution over dz per parity class
+                rows = [r for r in range(k) if (ph + pad - r * dil) % s == 0]
+                cols = [t for t in range(k) if (pw + pad - t * dil) % s == 0]
                 Hc = (x.H - ph + s - 1) // s
                 Wc = (x.W - pw + s - 1) // s
                 if Hc <= 0 or Wc <= 0:
                     continue
                 if not rows or not cols:
-                    raise NotImplementedError("stride larger than kernel: empty data-gradient class")
-                eh, ew = (ph + pad - r0) // s, (pw + pad - t0) // s
+                    continue  # (initialised above)
                 sel = [r * k + t for r in rows for t in cols]
-                offs = [(eh - u, ew - v) for u in range(len(rows)) for v in range(len(cols))]
+                offs = [((ph + pad - r * dil) // s, (pw + pad - t * dil) // s) for r in rows for t in cols]
                 nsel = len(sel)
                 wd = self.alloc(x.C * nsel * Cout * _ESIZE[dt], "wd")
                 ints = [w_dtype, ldw, dt, nsel, Cout, k * k, x.C, 0] + sel
