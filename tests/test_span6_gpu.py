@@ -169,3 +169,53 @@ def test_160_columns_tail_on_the_persistent_span_kernel(mode):
     a, b = torch.nan_to_num(outs[0].float()), torch.nan_to_num(outs[1].float())
     torch.testing.assert_close(a, b, rtol=2.0 ** -6, atol=2e-2)
     assert torch.equal(a[..., 32:32 + 128], b[..., 32:32 + 128])  # the head columns: the same kernel, the same bits
+
+
+@pytest.mark.parametrize("mode", MODES, ids=[m[0] for m in MODES])
+@pytest.mark.parametrize("shape", [s for s in SHAPES if s[1] >= 64], ids=lambda s: "x".join(map(str, s)))
+def test_masked_rows_are_bit_identical_to_padded_positions(shape, mode):
+    """Round 5: the MASKED form of span6 (rows = pixels, a tap outside the image reads a zero block) against the padded
+    form (rows = positions of the (H+1) x (W+1) image) on identical operands: the masked taps contribute exact zeros, the
+    summation order is the same -- bit for bit, statistics included."""
+    B, Cin, Cout, H, W = shape
+    flags = mode[1]
+    torch.manual_seed(hash(shape) % 1000 + 1)
+    slices = shape[0] % 2 == 1
+    ldx, ldy = (Cin + 32, Cout + 64) if slices else (Cin, Cout)
+    xb = torch.randn(B, H, W, ldx, device="cuda").to(torch.bfloat16)
+    x = xb[..., 16:16 + Cin] if slices else xb
+    w = (torch.randn(Cout, 9, Cin, device="cuda") * (2.0 / (9 * Cin)) ** 0.5).to(torch.bfloat16)
+    res = torch.randn(B, H, W, Cout, device="cuda").to(torch.bfloat16) if flags & N.VT_CONV_RESIDUAL else None
+    scale = torch.rand(Cout, device="cuda") + 0.5 if flags & N.VT_CONV_AFFINE else None
+    shift = torch.randn(Cout, device="cuda") if flags & N.VT_CONV_AFFINE else None
+    d = _desc(B, Cin, Cout, H, W, ldx, ldy, Cout if res is not None else 0, flags, flip=mode[0] == "residual")
+    outs = []
+    try:
+        for mask in (0, 2):
+            N.set_knob("VT_SPAN6_MASK", mask)
+            yb = torch.full((B, H, W, ldy), float("nan"), device="cuda", dtype=torch.bfloat16)
+            y = yb[..., 32:32 + Cout] if slices else yb
+            st = N.stats_buffer(Cout) if flags & N.VT_CONV_STATS else None
+            name = _run("2", d, x, w, y, scale, shift, res, st)
+            outs.append((yb, N.stats_decode(st) if st is not None else None, name))
+    finally:
+        N.set_knob("VT_SPAN6_MASK", 1)
+    (y0, s0, n0), (y1, s1, n1) = outs
+    assert "span6" in n0 and "masked" not in n0 and "masked" in n1, (n0, n1)
+    assert torch.equal(torch.isnan(y0.float()), torch.isnan(y1.float()))
+    assert torch.equal(torch.nan_to_num(y0.float()), torch.nan_to_num(y1.float()))
+    if s0 is not None:
+        torch.testing.assert_close(s1, s0, rtol=1e-6, atol=1e-3)  # the same stored values, summed in fixed point
+
+
+def test_the_dispatcher_takes_pixel_rows_only_where_they_save_a_tile_round():
+    """256 -> 256 @14x14 at batch 256: 225 padded positions per image make 15 units for one workgroup in 16 (two tiles of
+    72 steps), 196 pixels make 12-13 (one tile): masked.  128 -> 128 @28x28: two tiles either way: padded (no masks)."""
+    for shape, want in (((256, 256, 256, 14, 14), True), ((256, 128, 128, 28, 28), False)):
+        B, Cin, Cout, H, W = shape
+        x = torch.randn(B, H, W, Cin, device="cuda").to(torch.bfloat16)
+        w = torch.randn(Cout, 9, Cin, device="cuda").to(torch.bfloat16)
+        y = torch.empty(B, H, W, Cout, device="cuda", dtype=torch.bfloat16)
+        d = _desc(B, Cin, Cout, H, W, Cin, Cout, 0, 0, flip=False)
+        name = _run("1", d, x, w, y, None, None, None, None)
+        assert ("masked" in name) == want, name

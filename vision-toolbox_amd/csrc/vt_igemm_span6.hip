@@ -74,9 +74,11 @@ struct S6Args {
     int fmx;         // tallest tile of this launch in 32-row units (<= kFMX): lowered on wide maps, whose halo would
                      // otherwise push the span past the 28 pieces a chunk slot holds
     int ppt;         // pieces issued per tap at taps 0..5: ceil(npc / 6)
-    int Hp, Wp, Mp;  // padded image (H+1) x (W+1) and the number of padded positions B*Hp*Wp
+    int Hp, Wp, Mp;  // the image H x W and the number of positions B*H*W (round 5: rows are the pixels themselves; the
+                     // names date from the padded (H+1) x (W+1) enumeration, see the kernel's compute-wave comment)
     unsigned hp_magic, wp_magic;  // ceil(2^32 / Hp), ceil(2^32 / Wp): quotients by multiply-high (+ one correction)
     int dtap[9];     // span row of every tap
+    int tsel[9];     // tap t reads row i + er - 1, column j + ec - 1: er | ec << 2  (er, ec in 0..2)
     int debug;       // dev ablations (VT_SPAN6_ABL): 1 no DMA in the loop, 2 no MFMA / reads, 4 no vmcnt wait, 16 stamps
 };
 
@@ -136,11 +138,12 @@ __device__ __forceinline__ void vm_wait_dyn(int n) {
 #undef VT_W4
 }
 
-// LDS map (bytes): [row output pixel 2 groups x 2 x kBMX x 4][filter ring kNSB x 8 KiB]
-//                  [group 0: span slot 0, slot 1][group 1: span slot 0, slot 1]
+// LDS map (bytes): [row output pixel 2 groups x 2 x kBMX x 4][16 zero bytes: the fragment of a tap outside the image]
+//                  [filter ring kNSB x 8 KiB][group 0: span slot 0, slot 1][group 1: span slot 0, slot 1]
 struct L6 {
     static constexpr int kPo = 0;
-    static constexpr int kB = kPo + 4 * kBMX * 4;
+    static constexpr int kZ = kPo + 4 * kBMX * 4;
+    static constexpr int kB = (kZ + 16 + 1023) / 1024 * 1024;
     static constexpr int kA = kB + kNSB * kBSlot;
     __host__ __device__ static constexpr int bytes(int npc) { return kA + 4 * npc * 1024; }
 };
@@ -187,7 +190,8 @@ __device__ __forceinline__ void wg_barrier() {
     } while (0)
 
 // 12 waves: 0-3 compute group 0, 4-7 compute group 1, 8-11 loaders; three per SIMD = at most 168 registers
-template <int MODE>  // epilogue: 0 plain (+ residual), 1 BatchNorm statistics, 2 affine (+ ReLU, + residual)
+// MASKED: rows are the pixels themselves and a tap that leaves the image reads a zero block (else: padded positions)
+template <int MODE, bool MASKED>  // epilogue: 0 plain (+ residual), 1 BatchNorm statistics, 2 affine (+ ReLU, + residual)
 __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
     const IgemmArgs& p = a.p;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -357,6 +361,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
         }
         row_tables(0, 0, m0c[0]);
         row_tables(1, 0, m0c[1]);
+        if (lj == 0 && lane < 4) ((unsigned*)(smem + L6::kZ))[lane] = 0u;  // the fragment of a tap outside the image
 #ifdef VT_SPAN6_PROTO_NORM
         {  // the first chunk of the first tiles: everything of the prologue must have landed (the loop's first wait is a full one anyway)
             vmw<0>();
@@ -571,6 +576,41 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
             int wrow = wm * 16 * FM + c16;  // this lane's row inside the tile, fragment 0
             asm volatile("" : "+v"(wrow));    // (opaque: nothing derived from it is hoisted out of the tile loop)
             unsigned a_off = 0;               // byte offset (inside this group's span slots) of this lane's fragment-0 row of the coming step
+            // MASKED (round 5): the rows of a tile are the PIXELS (flat index (b*H + i)*W + j), not the positions of a padded
+            // (H+1) x (W+1) image.  A tap is still a constant row offset inside the span; where it leaves the image (or wraps
+            // into the next row) the lane reads a zero block instead: one validity bit per (row fragment, tap), built once
+            // per tile -- tmask[i / 3] bit 9 * (i % 3) + t -- and three vector instructions per fragment read.  Those cost
+            // more than the padding positions do (+13 % per step at 28 x 28 against 7 % of padding rows), so the dispatcher
+            // takes this form only where the shorter row count saves a whole tile round (14 x 14 at batch 256: 15 units of
+            // padded positions for one of every 16 workgroups, two tiles, against 12-13 units of pixels, one tile).
+            unsigned tmask[(FM + 2) / 3];
+            if constexpr (MASKED) {
+                ArgsPtr Q = fresh_args();
+                const int W_ = Q->Wp, H_ = Q->Hp;
+                const unsigned wmag = Q->wp_magic, hmag = Q->hp_magic;
+#pragma unroll
+                for (int i3 = 0; i3 < (FM + 2) / 3; ++i3) tmask[i3] = 0;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int mp = (int)m0_cur + wrow + 16 * i;
+                    int q = (int)__umulhi((unsigned)mp, wmag);
+                    int j = mp - q * W_;
+                    if (j < 0) j += W_, --q;
+                    int b = (int)__umulhi((unsigned)q, hmag);
+                    int ii = q - b * H_;
+                    if (ii < 0) ii += H_;
+                    // bits 0..2: row i-1 / i / i+1 inside the image; bits 3..5: column j-1 / j / j+1
+                    const unsigned rc = (ii > 0 ? 1u : 0u) | 2u | (ii < H_ - 1 ? 4u : 0u) | (j > 0 ? 8u : 0u) | 16u | (j < W_ - 1 ? 32u : 0u);
+                    unsigned m9 = 0;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int sel = Q->tsel[t];
+                        m9 |= ((rc >> (sel & 3)) & (rc >> (3 + (sel >> 2))) & 1u) << t;
+                    }
+                    tmask[i / 3] |= m9 << (9 * (i % 3));
+                }
+            }
+            const char* const zfrag = smem + L6::kZ;
             f32x4 acc[FM][4];
 #pragma unroll
             for (int i = 0; i < FM; ++i)
@@ -606,7 +646,16 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                     bf2 = *(const uint4*)(Bt + 2048);
 #pragma unroll
                     for (int i = 0; i < FM; ++i) {
-                        af[i] = *(const uint4*)(A + i * 1024);  // padded coordinates: no masks, one address register
+                        if constexpr (MASKED) {
+                            // (opaque: the 63 lane masks of a tile are not to be hoisted into SGPR pairs -- they do not fit
+                            //  and came back as ~13 v_readlane per step -- but tested here)
+                            unsigned mk = tmask[i / 3];
+                            asm volatile("" : "+v"(mk));
+                            const bool inside = (mk >> (9 * (i % 3) + T)) & 1u;
+                            af[i] = *(const uint4*)(inside ? A + i * 1024 : zfrag);
+                        } else {
+                            af[i] = *(const uint4*)(A + i * 1024);  // padded coordinates: no masks, one address register
+                        }
                     }
                     // the next step's span row offset: a scalar load that returns during the MFMA tick
                     const int dnext = fresh_args()->dtap[(T + 1) % 9];
@@ -808,43 +857,73 @@ static int span6_run(IgemmArgs& a0, int dtype, void* stream, bool dry) {
     a.p = a0;
     IgemmArgs& p = a.p;
     a.debug = kDiag ? VT_KNOB("VT_SPAN6_ABL", 0) : 0;  // (diagnostic builds only)
-    // padded coordinates: every tap within one pixel of the centre (3x3, padding 1: forward and stride-1 data gradient)
-    a.Hp = a0.Hi + 1, a.Wp = a0.Wi + 1;
-    if ((long)a0.B * a.Hp * a.Wp > 0x3fffffffL) return -1;
-    a.Mp = a0.B * a.Hp * a.Wp;
+    // every tap within one pixel of the centre (3x3, padding 1: forward and stride-1 data gradient)
     for (int t = 0; t < 9; ++t) {
         const int eh = a0.h0 + a0.dh[t], ew = a0.w0 + a0.dw[t];
         if (eh < -1 || eh > 1 || ew < -1 || ew > 1) return -1;
-        a.dtap[t] = (eh + 1) * a.Wp + (ew + 1);
+        a.tsel[t] = (eh + 1) | ((ew + 1) << 2);
     }
-    a.dmin = -a.Wp - 1;
-    a.halo = 2 * a.Wp + 2;
     p.tiles_n = (p.Cout + 127) / 128;
     if (p.tiles_n > 8) return -1;
     const int g8 = 32 - 32 % p.tiles_n;  // working workgroups per XCD (one per CU; 32 % tiles_n CUs per XCD sit out)
     // MFMA-bound layers only: enough rows to give every compute group at least 4 units
     if ((long)p.M * p.tiles_n < 512L * 32 * 4) return -1;
     a.rslots = g8 / p.tiles_n;
-    a.units = (a.Mp + 31) / 32;
-    a.upx = (a.units + 7) / 8;
-    // tile height: the tallest one whose span (rows + halo) fits the 28 pieces of a chunk slot -- 7 units up to 80-pixel
-    // maps, 6 up to 112 (VoVNet-39's 64 -> 128 @112x112), 4 up to ~140
-    a.fmx = kFMX;
-    for (;;) {
-        a.npc = ((32 * a.fmx + a.halo + 15) / 16 + 3) / 4 * 4;  // a multiple of 4: every loader issues one piece per tap 0..npc/4-1
-        if (a.npc <= 28 || a.fmx == 4) break;
-        --a.fmx;
+    // Rows: the positions of the padded (H+1) x (W+1) image (pad = 1: no masks anywhere), or the pixels themselves with a
+    // per-tap validity bit per row (pad = 0: the MASKED kernel).  Returns the tile rounds of the slowest workgroup, 0 when
+    // the geometry does not fit.
+    auto geometry = [&](int pad) -> int {
+        a.Hp = a0.Hi + pad, a.Wp = a0.Wi + pad;
+        if ((long)a0.B * a.Hp * a.Wp > 0x3fffffffL) return 0;
+        a.Mp = a0.B * a.Hp * a.Wp;
+        for (int t = 0; t < 9; ++t) a.dtap[t] = (a.tsel[t] & 3) * a.Wp + (a.tsel[t] >> 2);
+        a.dmin = -a.Wp - 1;
+        a.halo = 2 * a.Wp + 2;
+        a.units = (a.Mp + 31) / 32;
+        a.upx = (a.units + 7) / 8;
+        // tile height: the tallest one whose span (rows + halo) fits the 28 pieces of a chunk slot -- 7 units up to 80-pixel
+        // maps, 6 up to 112 (VoVNet-39's 64 -> 128 @112x112), 4 up to ~140
+        a.fmx = kFMX;
+        for (;;) {
+            a.npc = ((32 * a.fmx + a.halo + 15) / 16 + 3) / 4 * 4;  // a multiple of 4: every loader issues one piece per tap 0..npc/4-1
+            if (a.npc <= 28 || a.fmx == 4) break;
+            --a.fmx;
+        }
+        a.ppt = (a.npc + 5) / 6;
+        if (a.npc < 16 || a.npc > 28) return 0;  // 4..7 taps carry one piece per loader and group
+        if (L6::bytes(a.npc) > 160 * 1024) return 0;
+        int rounds = 1;
+        for (int xcd = 0; xcd < 8; ++xcd) {  // (the kernel's own split)
+            const int ux0 = xcd * a.upx, ux1 = std::min(a.units, ux0 + a.upx);
+            const int nx = std::max(0, ux1 - ux0);
+            for (int rs = 0; rs < a.rslots; ++rs) {
+                const int nun = (int)((unsigned)(rs + 1) * (unsigned)nx / (unsigned)a.rslots) - (int)((unsigned)rs * (unsigned)nx / (unsigned)a.rslots);
+                rounds = std::max(rounds, ((nun + 1) / 2 + a.fmx - 1) / a.fmx);
+            }
+        }
+        return rounds;
+    };
+    // VT_SPAN6_MASK: 0 never, 1 (default) where the pixel rows save a tile round, 2 wherever they fit (tests)
+    const int maskk = VT_KNOB("VT_SPAN6_MASK", 1);
+    const int r_masked = maskk ? geometry(0) : 0;
+    const int r_padded = geometry(1);
+    bool masked = false;
+    // (a masked step costs ~13 % more than a padded one -- 128 -> 128 @28x28, same tile count: 72.6 against 65.0 us -- so seven
+    //  rounds of pixels against eight of padded positions, 128 -> 128 @56x56, still lose: 285 against 270 us)
+    if (r_masked > 0 && (r_padded == 0 || maskk >= 2 || 23 * r_masked < 20 * r_padded)) {
+        masked = true;
+        geometry(0);
+    } else if (r_padded == 0) {
+        return -1;
     }
-    a.ppt = (a.npc + 5) / 6;
-    if (a.npc < 16 || a.npc > 28) return -1;  // 4..7 taps carry one piece per loader and group
     const int smem = L6::bytes(a.npc);
-    if (smem > 160 * 1024) return -1;
     a.hp_magic = (unsigned)((0x100000000ull + a.Hp - 1) / a.Hp);
     a.wp_magic = (unsigned)((0x100000000ull + a.Wp - 1) / a.Wp);
     const int mode = (p.flags & VT_CONV_STATS) ? 1 : ((p.flags & VT_CONV_AFFINE) ? 2 : 0);
     if (mode == 1 && (p.flags & (VT_CONV_AFFINE | VT_CONV_RELU | VT_CONV_RESIDUAL))) return -1;
     if (mode == 0 && (p.flags & VT_CONV_RELU)) return -1;
-    auto kern = mode == 1 ? span6_kernel<1> : (mode == 2 ? span6_kernel<2> : span6_kernel<0>);
+    auto kern = masked ? (mode == 1 ? span6_kernel<1, true> : (mode == 2 ? span6_kernel<2, true> : span6_kernel<0, true>))
+                       : (mode == 1 ? span6_kernel<1, false> : (mode == 2 ? span6_kernel<2, false> : span6_kernel<0, false>));
     {
         // (in the dry run too: the only fallible step of a launch, so a caller that splits the columns over two kernels
         //  knows this half cannot fail once the other one has been issued)
@@ -852,7 +931,7 @@ static int span6_run(IgemmArgs& a0, int dtype, void* stream, bool dry) {
         if (rc != VT_OK) return rc;
     }
     if (dry) return VT_OK;
-    vt_note_kernel("span6_kernel<bf16,2x4+4 waves,FM%d>", kFMX);
+    vt_note_kernel(masked ? "span6_kernel<bf16,2x4+4 waves,FM%d,masked>" : "span6_kernel<bf16,2x4+4 waves,FM%d>", kFMX);
     hipLaunchKernelGGL(kern, dim3(8 * 32), dim3(768), smem, (hipStream_t)stream, a);
     VT_CHECK_LAUNCH("vt_conv_igemm(span6)");
     if (kDiag && (a.debug & 16)) {
