@@ -909,8 +909,10 @@ static int span6_run(IgemmArgs& a0, int dtype, void* stream, bool dry) {
     const int r_padded = geometry(1);
     bool masked = false;
     // (a masked step costs ~13 % more than a padded one -- 128 -> 128 @28x28, same tile count: 72.6 against 65.0 us -- so seven
-    //  rounds of pixels against eight of padded positions, 128 -> 128 @56x56, still lose: 285 against 270 us)
-    if (r_masked > 0 && (r_padded == 0 || maskk >= 2 || 23 * r_masked < 20 * r_padded)) {
+    //  rounds of pixels against eight of padded positions, 128 -> 128 @56x56, still lose: 285 against 270 us;
+    //  Darknet-YOLOv5x's forward, where pixel rows saved one round in five or six on some layers, ran 13.05 against 12.88 ms:
+    //  only a third fewer rounds or better -- one instead of two, two instead of three -- switch the geometry)
+    if (r_masked > 0 && (r_padded == 0 || maskk >= 2 || 3 * r_masked <= 2 * r_padded)) {
         masked = true;
         geometry(0);
     } else if (r_padded == 0) {
