@@ -262,6 +262,10 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
         // pixel (the chunk's byte offset applies), else the zero page
         auto span_src = [&](int mp, bool& ok) -> unsigned long {
             const bool inr = (unsigned)mp < (unsigned)Mp;
+            if constexpr (MASKED) {  // rows are the pixels themselves: no division
+                ok = inr;
+                return inr ? (unsigned long)xg + (unsigned long)((long)mp * ldx2 + cjA * 16) : zero_src;
+            }
             int b, i, j;
             ok = unpad(inr ? mp : 0, b, i, j) && inr;
             const long pix = ((long)b * H_ + i) * W_ + j;
