@@ -219,3 +219,58 @@ def test_the_dispatcher_takes_pixel_rows_only_where_they_save_a_tile_round():
         d = _desc(B, Cin, Cout, H, W, Cin, Cout, 0, 0, flip=False)
         name = _run("1", d, x, w, y, None, None, None, None)
         assert ("masked" in name) == want, name
+
+
+KSPLIT_SHAPES = [
+    (256, 512, 512, 7, 7),    # CSPDarknet-53 stage 5 at batch 256: 6-7 units per workgroup, four filter tiles
+    (128, 256, 256, 14, 14),  # stage 4 at the data-parallel per-GPU batch 128
+    (192, 512, 256, 9, 11),   # odd map, rows not a multiple of 32
+    (200, 256, 384, 8, 8),    # three filter tiles (do not divide 32), four chunks per group
+]
+
+
+@pytest.mark.parametrize("mode", MODES, ids=[m[0] for m in MODES])
+@pytest.mark.parametrize("shape", KSPLIT_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_k_split_between_the_two_groups(shape, mode):
+    """Round 5: where every workgroup's rows fit one group's tile, both groups take the same rows and half of the input
+    channels each, and group 1's partial sums reach group 0 through LDS (span6 KSPLIT).  Against the kernel the dispatcher
+    takes without it (VT_SPAN6_KSPLIT=0), on identical operands: another summation order -- two f32 partial sums added
+    once -- so one bf16 rounding of the output apart at most (two with a residual), and against float64 on a sample."""
+    B, Cin, Cout, H, W = shape
+    flags = mode[1]
+    torch.manual_seed(sum(shape) + 3)
+    slices = shape[0] % 3 == 0
+    ldx, ldy = (Cin + 32, Cout + 64) if slices else (Cin, Cout)
+    xb = torch.randn(B, H, W, ldx, device="cuda").to(torch.bfloat16)
+    x = xb[..., 16:16 + Cin] if slices else xb
+    w = (torch.randn(Cout, 9, Cin, device="cuda") * (2.0 / (9 * Cin)) ** 0.5).to(torch.bfloat16)
+    res = torch.randn(B, H, W, Cout, device="cuda").to(torch.bfloat16) if flags & N.VT_CONV_RESIDUAL else None
+    scale = torch.rand(Cout, device="cuda") + 0.5 if flags & N.VT_CONV_AFFINE else None
+    shift = torch.randn(Cout, device="cuda") if flags & N.VT_CONV_AFFINE else None
+    d = _desc(B, Cin, Cout, H, W, ldx, ldy, Cout if res is not None else 0, flags, flip=mode[0] == "residual")
+    outs = []
+    try:
+        for ks in (0, 1):
+            N.set_knob("VT_SPAN6_KSPLIT", ks)
+            yb = torch.full((B, H, W, ldy), float("nan"), device="cuda", dtype=torch.bfloat16)
+            y = yb[..., 32:32 + Cout] if slices else yb
+            st = N.stats_buffer(Cout) if flags & N.VT_CONV_STATS else None
+            name = _run("1", d, x, w, y, scale, shift, res, st)
+            outs.append((yb, y, N.stats_decode(st) if st is not None else None, name))
+    finally:
+        N.set_knob("VT_SPAN6_KSPLIT", 1)
+    (yb0, y0, s0, n0), (yb1, y1, s1, n1) = outs
+    assert "ksplit" not in n0 and "ksplit" in n1, (n0, n1)
+    assert torch.equal(torch.isnan(yb0.float()), torch.isnan(yb1.float()))  # nothing outside the slice was written
+    a, b = y0.float(), y1.float()
+    assert ((a - b).norm() / a.norm()).item() < 1e-3
+    torch.testing.assert_close(b, a, rtol=2.0 ** -6, atol=2e-2)
+    if s0 is not None:
+        torch.testing.assert_close(s1, s0, rtol=2e-3, atol=0.5)
+    # a float64 spot check of the plain convolution on one image (forward tap order only)
+    if mode[0] in ("plain", "stats"):
+        import torch.nn.functional as F
+        xi = x[:1].permute(0, 3, 1, 2).double()
+        wi = w.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).double()
+        want = F.conv2d(xi, wi, None, 1, 1).permute(0, 2, 3, 1)
+        assert ((y1[:1].double() - want).norm() / want.norm()).item() < 4e-3

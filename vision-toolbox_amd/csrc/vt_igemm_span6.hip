@@ -144,8 +144,9 @@ struct L6 {
     static constexpr int kPo = 0;
     static constexpr int kZ = kPo + 4 * kBMX * 4;
     static constexpr int kB = (kZ + 16 + 1023) / 1024 * 1024;
-    static constexpr int kA = kB + kNSB * kBSlot;
-    __host__ __device__ static constexpr int bytes(int npc) { return kA + 4 * npc * 1024; }
+    // (KSPLIT: a ring slot holds two slices, one per compute group)
+    __host__ __device__ static constexpr int a_off(bool ksplit) { return kB + kNSB * kBSlot * (ksplit ? 2 : 1); }
+    __host__ __device__ static constexpr int bytes(int npc, bool ksplit) { return a_off(ksplit) + 4 * npc * 1024; }
 };
 
 // sum of a value over the 16 lanes of its DPP row (lanes 16k .. 16k+15), returned in every lane of the row
@@ -191,13 +192,20 @@ __device__ __forceinline__ void wg_barrier() {
 
 // 12 waves: 0-3 compute group 0, 4-7 compute group 1, 8-11 loaders; three per SIMD = at most 168 registers
 // MASKED: rows are the pixels themselves and a tap that leaves the image reads a zero block (else: padded positions)
-template <int MODE, bool MASKED>  // epilogue: 0 plain (+ residual), 1 BatchNorm statistics, 2 affine (+ ReLU, + residual)
+// KSPLIT (layers whose whole row share fits ONE group's tile -- 512 -> 512 @7x7 at batch 256, the 14 x 14 layers at batch
+//   128): both groups work on the SAME rows, group 0 on the first half of the input channels and group 1 on the second;
+//   a ring slot carries both groups' filter slices; at the end group 1 hands its accumulators over through LDS and group 0
+//   adds them and runs the epilogue.  Half as many K-steps per launch at twice the MFMAs per tick, and every filter
+//   slice staged once per 224 rows instead of once per 112.  (One tile per workgroup by construction: the hand-over re-uses
+//   the ring and the span slots, which a loader running ahead into a next tile would still be filling.)
+template <int MODE, bool MASKED, bool KSPLIT>  // epilogue: 0 plain (+ residual), 1 BatchNorm statistics, 2 affine (+ ReLU, + residual)
 __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
     const IgemmArgs& p = a.p;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* sPo = (int*)(smem + L6::kPo);
     const char* sBb = smem + L6::kB;
-    const char* sAb = smem + L6::kA;
+    const char* sAb = smem + L6::a_off(KSPLIT);
+    constexpr int kBS = KSPLIT ? 2 * kBSlot : kBSlot;  // bytes per ring slot
     const int aslot_bytes = a.npc * 1024;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -215,13 +223,14 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
     if (nun <= 0) return;
     // group 0 takes the first ceil(nun/2) units, group 1 the rest; both cut their range into the SAME number of
     // tiles (the two groups run one schedule), heights within a group differing by at most one unit
-    const int nun0 = (nun + 1) >> 1;
+    const int nun0 = KSPLIT ? nun : (nun + 1) >> 1;
     const int ntile = __builtin_amdgcn_readfirstlane((nun0 + a.fmx - 1) / a.fmx);
-    const int nchunks = __builtin_amdgcn_readfirstlane(p.Cin / 32);
+    const int nchunks = __builtin_amdgcn_readfirstlane(KSPLIT ? p.Cin / 64 : p.Cin / 32);  // per compute group
+    const int koff = KSPLIT ? nchunks * 64 : 0;  // KSPLIT: byte offset of group 1's first channel chunk
     const int nsteps = nchunks * 9;
     // tile k of group g: units [gu0 + k*tb + min(k, te), + tb + (k < te)), gu0 = ua (g = 0) / ua + nun0 (g = 1)
-#define VT_G_NUN(g) ((g) ? nun - nun0 : nun0)
-#define VT_G_U0(g) ((g) ? ua + nun0 : ua)
+#define VT_G_NUN(g) ((g) && !KSPLIT ? nun - nun0 : nun0)
+#define VT_G_U0(g) ((g) && !KSPLIT ? ua + nun0 : ua)
 #define VT_TILE_U0(g, k) (VT_G_U0(g) + (k) * (VT_G_NUN(g) / ntile) + min((k), VT_G_NUN(g) % ntile))
 #define VT_TILE_F(g, k) (VT_G_NUN(g) / ntile + ((k) < VT_G_NUN(g) % ntile ? 1 : 0))
 
@@ -231,7 +240,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
         VT_S6_STAMP(0);
         const char* xg = (const char*)p.x;
         const char* wg = (const char*)p.w;
-        const unsigned a_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)(smem + L6::kA);
+        const unsigned a_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)(smem + L6::a_off(KSPLIT));
         const unsigned b_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)(smem + L6::kB);
         const unsigned m0_keep = get_m0();
         const long ldx2 = (long)p.ldx * 2;
@@ -302,10 +311,14 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
             const char* sb = wg + (long)ic * 64 + (long)T * cin2;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                set_m0(b_base + (unsigned)(slot * kBSlot + (2 * lj + i) * 1024));
+                set_m0(b_base + (unsigned)(slot * kBS + (2 * lj + i) * 1024));
                 glds_s(b_voff[i], sb);
+                if constexpr (KSPLIT) {
+                    set_m0(b_base + (unsigned)(slot * kBS + kBSlot + (2 * lj + i) * 1024));
+                    glds_s(b_voff[i], sb + koff);
+                }
             }
-            issued += 2;
+            issued += KSPLIT ? 4 : 2;
         };
         // this loader's quarter of the table of group g's tile that starts at padded position m0t (table half par):
         // where each row is stored, -1 for a padding position
@@ -359,7 +372,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
             for (int T = 0; T < 7; ++T)
                 if (lj + 4 * T < a.npc) {
                     set_m0(a_base + (unsigned)((g * 2) * aslot_bytes + (lj + 4 * T) * 1024));
-                    glds_v(ab_cur[g][T]);
+                    glds_v(ab_cur[g][T] + ((g == 1 && ((vm_cur[g] >> T) & 1u)) ? (unsigned long)koff : 0ul));
                     ++issued;
                 }
         }
@@ -380,7 +393,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
 #pragma unroll
                 for (int T = 0; T < 7; ++T)
                     if (lj + 4 * T < a.npc) {
-                        uint4* q = (uint4*)(smem + L6::kA + (g * 2) * aslot_bytes + (lj + 4 * T) * 1024 + lane * 16);
+                        uint4* q = (uint4*)(smem + L6::a_off(KSPLIT) + (g * 2) * aslot_bytes + (lj + 4 * T) * 1024 + lane * 16);
                         float f[8];
                         VecIO<bf16_t>::unpack(*q, f);
 #pragma unroll
@@ -415,7 +428,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
             asm volatile("" : "+v"(psc[e]), "+v"(psf[e]));
         }
         auto proto_piece = [&](int g, int slot, int TP, unsigned vmask) {
-            uint4* q = (uint4*)(smem + L6::kA + (g * 2 + slot) * aslot_bytes + (lj + 4 * TP) * 1024 + lane * 16);
+            uint4* q = (uint4*)(smem + L6::a_off(KSPLIT) + (g * 2 + slot) * aslot_bytes + (lj + 4 * TP) * 1024 + lane * 16);
             const uint4 raw = *q;
             float f[8];
             VecIO<bf16_t>::unpack(raw, f);
@@ -453,7 +466,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                     auto step = [&](auto Tc) {
                         constexpr int T = decltype(Tc)::value;
                         constexpr auto P = [](int t) { return (t >= 0 && t < NTP) ? 1 : 0; };
-                        constexpr int kYounger = 4 + 2 * (P(T - 1) + P(T - 2));
+                        constexpr int kYounger = (KSPLIT ? 8 : 4) + 2 * (P(T - 1) + P(T - 2));
                         // ---- even tick 2s: slice s (and everything older: both groups' spans of its chunk) has landed
                         if (!VT_DBG(4)) {
                             if (sleft > 2 && sleft != S) vmw<kYounger>();
@@ -486,18 +499,24 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                             const unsigned long base = nx ? ab_nxt[1][T] : ab_cur[1][T];
                             const unsigned v = ((nx ? vm_nxt[1] : vm_cur[1]) >> T) & 1u;
                             set_m0(m0g[1] + T * 4096);
-                            glds_v(base + (v ? cb64 : 0ul));
+                            glds_v(base + (v ? cb64 + (unsigned long)koff : 0ul));
                         }
                         // group 1 has left its MFMA tick of step s-1 (whose second pair of filter fragments it read
                         // during that tick): the ring slot of slice s-1 takes slice s+3
                         if (dma && sleft > 3) {
                             constexpr int T3 = (T + 3) % 9;
                             const char* sb = (T < 6 ? wb_cur : wb_nxt) + (long)(T3 * cin2);
-                            const unsigned m0b = b_base + (unsigned)(bnext * kBSlot + 2 * lj * 1024);
+                            const unsigned m0b = b_base + (unsigned)(bnext * kBS + 2 * lj * 1024);
                             set_m0(m0b);
                             glds_s(b_voff[0], sb);
                             set_m0(m0b + 1024);
                             glds_s(b_voff[1], sb);
+                            if constexpr (KSPLIT) {
+                                set_m0(m0b + kBSlot);
+                                glds_s(b_voff[0], sb + koff);
+                                set_m0(m0b + kBSlot + 1024);
+                                glds_s(b_voff[1], sb + koff);
+                            }
                         }
 #ifdef VT_SPAN6_PROTO_NORM
                         if constexpr (T >= 3 && T - 3 < NTP) {
@@ -545,6 +564,10 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
             vt_span6_stamps[blockIdx.x * 16 + 14] = clock64() - lc0;
         }
         vmw<0>();
+        if constexpr (KSPLIT) {
+            wg_barrier();  // every LDS-DMA of this workgroup has landed: group 1 may overwrite the ring and the span slots
+            wg_barrier();  // group 1's accumulators are in LDS
+        }
         set_m0(m0_keep);
         return;
     }
@@ -641,7 +664,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                     }
                     const unsigned long long tR0 = VT_DBG(16) ? clock64() : 0;
                     const char* A = sAg + a_off;  // computed during the previous MFMA tick (or at the tile's start)
-                    const char* Bt = sBb + ((bcur << 13) + b_lane);
+                    const char* Bt = sBb + (bcur * kBS + (KSPLIT ? grp * kBSlot : 0) + b_lane);
                     // three filter fragments are read in the read tick, the fourth during the MFMA tick into the
                     // first one's registers (168 registers per lane): its latency hides behind 2*FM MFMAs
                     uint4 af[FM], bf0, bf1, bf2;
@@ -710,6 +733,29 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
             }
 
             if (wave == 0 && k < 4) VT_S6_STAMP(5 + 3 * k);
+            if constexpr (KSPLIT) {
+                // group 1's half of the K sum goes to group 0 through LDS: wave w of either group holds the same sub-tile
+                if (grp == 0) wg_barrier();  // tick 2S: group 1's last MFMA tick
+                wg_barrier();                // the loaders have waited for their last LDS-DMA: ring and span slots are free
+                float* red = (float*)(smem + L6::kB) + (wave & 3) * (FM * 4 * 256) + lane * 4;
+                if (grp == 1) {
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) *(f32x4*)(red + (i * 4 + j) * 256) = acc[i][j];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                wg_barrier();
+                if (grp == 1) return;
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 o = *(const f32x4*)(red + (i * 4 + j) * 256);
+                        acc[i][j] += o;
+                        __builtin_amdgcn_sched_barrier(0);  // (one addend in flight at a time: the accumulators fill the file)
+                    }
+            }
             // ---- epilogue: two 16-byte stores per row fragment, straight from the accumulators ----------
             ArgsPtr Q = fresh_args();
             constexpr bool affine = MODE == 2, stats = MODE == 1;
@@ -825,7 +871,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
             default: run(I_<kFMX>{}); break;
         }
     }
-    if (grp == 0) wg_barrier();  // tick 2S: group 1's last MFMA tick
+    if (!KSPLIT && grp == 0) wg_barrier();  // tick 2S: group 1's last MFMA tick
     if (VT_DBG(16) && wave == 0 && lane == 0 && blockIdx.x < 512) {
         vt_span6_stamps[blockIdx.x * 16 + 15] = cwait;
         vt_span6_stamps[blockIdx.x * 16 + 3] = cR;
@@ -849,7 +895,8 @@ static int span6_run(IgemmArgs& a0, int dtype, void* stream, bool dry) {
     // one 12-wave workgroup per CU on 8 XCDs x 32 CUs with 160 KiB of LDS each: the grid, the row slots and the unit
     // split below are built for exactly that chip; any other device (or a partitioned one) takes the span kernel
     if (vt_device_cus() != 256) return -1;
-    if (enabled < 2 && (a0.Cout < 128 || a0.Wi < 14 || a0.Hi < 14)) return -1;  // (14 x 14: 15 % padding work, still 6 % faster: 74.2 -> 69.7 us)
+    if (enabled < 2 && a0.Cout < 128) return -1;
+    const bool small_map = a0.Wi < 14 || a0.Hi < 14;  // (without KSPLIT: not below 14 x 14, where it is 6 % faster: 74.2 -> 69.7 us)
     if (a0.sh != 1 || a0.sw != 1 || a0.Ho != a0.Hi || a0.Wo != a0.Wi) return -1;
     // (Cin >= 64: with a single channel chunk the next tile's piece sources would be needed before they are computed)
     if (a0.Cin % 32 != 0 || a0.Cin < 64 || a0.ntaps != 9 || a0.Cout < 64) return -1;
@@ -870,13 +917,12 @@ static int span6_run(IgemmArgs& a0, int dtype, void* stream, bool dry) {
     p.tiles_n = (p.Cout + 127) / 128;
     if (p.tiles_n > 8) return -1;
     const int g8 = 32 - 32 % p.tiles_n;  // working workgroups per XCD (one per CU; 32 % tiles_n CUs per XCD sit out)
-    // MFMA-bound layers only: enough rows to give every compute group at least 4 units
-    if ((long)p.M * p.tiles_n < 512L * 32 * 4) return -1;
     a.rslots = g8 / p.tiles_n;
+    int maxnun = 0;  // units of the workgroup with the most rows (set by geometry())
     // Rows: the positions of the padded (H+1) x (W+1) image (pad = 1: no masks anywhere), or the pixels themselves with a
     // per-tap validity bit per row (pad = 0: the MASKED kernel).  Returns the tile rounds of the slowest workgroup, 0 when
     // the geometry does not fit.
-    auto geometry = [&](int pad) -> int {
+    auto geometry = [&](int pad, bool ks = false) -> int {
         a.Hp = a0.Hi + pad, a.Wp = a0.Wi + pad;
         if ((long)a0.B * a.Hp * a.Wp > 0x3fffffffL) return 0;
         a.Mp = a0.B * a.Hp * a.Wp;
@@ -895,41 +941,59 @@ static int span6_run(IgemmArgs& a0, int dtype, void* stream, bool dry) {
         }
         a.ppt = (a.npc + 5) / 6;
         if (a.npc < 16 || a.npc > 28) return 0;  // 4..7 taps carry one piece per loader and group
-        if (L6::bytes(a.npc) > 160 * 1024) return 0;
+        if (L6::bytes(a.npc, ks) > 160 * 1024) return 0;
         int rounds = 1;
+        maxnun = 0;
         for (int xcd = 0; xcd < 8; ++xcd) {  // (the kernel's own split)
             const int ux0 = xcd * a.upx, ux1 = std::min(a.units, ux0 + a.upx);
             const int nx = std::max(0, ux1 - ux0);
             for (int rs = 0; rs < a.rslots; ++rs) {
                 const int nun = (int)((unsigned)(rs + 1) * (unsigned)nx / (unsigned)a.rslots) - (int)((unsigned)rs * (unsigned)nx / (unsigned)a.rslots);
                 rounds = std::max(rounds, ((nun + 1) / 2 + a.fmx - 1) / a.fmx);
+                maxnun = std::max(maxnun, nun);
             }
         }
         return rounds;
     };
     // VT_SPAN6_MASK: 0 never, 1 (default) where the pixel rows save a tile round, 2 wherever they fit (tests)
     const int maskk = VT_KNOB("VT_SPAN6_MASK", 1);
-    const int r_masked = maskk ? geometry(0) : 0;
-    const int r_padded = geometry(1);
+    // KSPLIT (VT_SPAN6_KSPLIT: 0 never, 1 default): the whole row share of EVERY workgroup fits one group's tile -- then both
+    // groups take the same rows (pixel rows: fewest units) and half of the input channels each.  At least four chunks per
+    // group; the hand-over of group 1's accumulators (4 waves x 28 KiB) re-uses the ring and the span slots.
+    bool ksplit = false;
+    if (VT_KNOB("VT_SPAN6_KSPLIT", 1) && maskk && a0.Cin % 64 == 0 && a0.Cin >= 256 && (long)p.M * p.tiles_n >= 24576L) {
+        if (geometry(0, true) > 0 && maxnun <= a.fmx && kNSB * 2 * kBSlot + 4 * a.npc * 1024 >= 4 * kFMX * 4 * 1024) ksplit = true;
+    }
+    if (!ksplit) {
+        if (enabled < 2 && small_map) return -1;
+        // MFMA-bound layers only: enough rows to give every compute group at least 4 units
+        if ((long)p.M * p.tiles_n < 512L * 32 * 4) return -1;
+    }
+    const int r_masked = (maskk && !ksplit) ? geometry(0) : 0;
+    const int r_padded = ksplit ? 0 : geometry(1);
     bool masked = false;
     // (a masked step costs ~13 % more than a padded one -- 128 -> 128 @28x28, same tile count: 72.6 against 65.0 us -- so seven
     //  rounds of pixels against eight of padded positions, 128 -> 128 @56x56, still lose: 285 against 270 us;
     //  Darknet-YOLOv5x's forward, where pixel rows saved one round in five or six on some layers, ran 13.05 against 12.88 ms:
     //  only a third fewer rounds or better -- one instead of two, two instead of three -- switch the geometry)
-    if (r_masked > 0 && (r_padded == 0 || maskk >= 2 || 3 * r_masked <= 2 * r_padded)) {
+    if (ksplit) {
+        masked = true;
+        geometry(0, true);
+    } else if (r_masked > 0 && (r_padded == 0 || maskk >= 2 || 3 * r_masked <= 2 * r_padded)) {
         masked = true;
         geometry(0);
     } else if (r_padded == 0) {
         return -1;
     }
-    const int smem = L6::bytes(a.npc);
+    const int smem = L6::bytes(a.npc, ksplit);
     a.hp_magic = (unsigned)((0x100000000ull + a.Hp - 1) / a.Hp);
     a.wp_magic = (unsigned)((0x100000000ull + a.Wp - 1) / a.Wp);
     const int mode = (p.flags & VT_CONV_STATS) ? 1 : ((p.flags & VT_CONV_AFFINE) ? 2 : 0);
     if (mode == 1 && (p.flags & (VT_CONV_AFFINE | VT_CONV_RELU | VT_CONV_RESIDUAL))) return -1;
     if (mode == 0 && (p.flags & VT_CONV_RELU)) return -1;
-    auto kern = masked ? (mode == 1 ? span6_kernel<1, true> : (mode == 2 ? span6_kernel<2, true> : span6_kernel<0, true>))
-                       : (mode == 1 ? span6_kernel<1, false> : (mode == 2 ? span6_kernel<2, false> : span6_kernel<0, false>));
+    auto kern = ksplit ? (mode == 1 ? span6_kernel<1, true, true> : (mode == 2 ? span6_kernel<2, true, true> : span6_kernel<0, true, true>))
+                : masked ? (mode == 1 ? span6_kernel<1, true, false> : (mode == 2 ? span6_kernel<2, true, false> : span6_kernel<0, true, false>))
+                         : (mode == 1 ? span6_kernel<1, false, false> : (mode == 2 ? span6_kernel<2, false, false> : span6_kernel<0, false, false>));
     {
         // (in the dry run too: the only fallible step of a launch, so a caller that splits the columns over two kernels
         //  knows this half cannot fail once the other one has been issued)
@@ -937,7 +1001,8 @@ static int span6_run(IgemmArgs& a0, int dtype, void* stream, bool dry) {
         if (rc != VT_OK) return rc;
     }
     if (dry) return VT_OK;
-    vt_note_kernel(masked ? "span6_kernel<bf16,2x4+4 waves,FM%d,masked>" : "span6_kernel<bf16,2x4+4 waves,FM%d>", kFMX);
+    vt_note_kernel(ksplit ? "span6_kernel<bf16,2x4+4 waves,FM%d,masked,ksplit>"
+                          : (masked ? "span6_kernel<bf16,2x4+4 waves,FM%d,masked>" : "span6_kernel<bf16,2x4+4 waves,FM%d>"), kFMX);
     hipLaunchKernelGGL(kern, dim3(8 * 32), dim3(768), smem, (hipStream_t)stream, a);
     VT_CHECK_LAUNCH("vt_conv_igemm(span6)");
     if (kDiag && (a.debug & 16)) {
