@@ -676,10 +676,16 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                         if constexpr (MASKED) {
                             // (opaque: the 63 lane masks of a tile are not to be hoisted into SGPR pairs -- they do not fit
                             //  and came back as ~13 v_readlane per step -- but tested here)
-                            unsigned mk = tmask[i / 3];
-                            asm volatile("" : "+v"(mk));
-                            const bool inside = (mk >> (9 * (i % 3) + T)) & 1u;
-                            af[i] = *(const uint4*)(inside ? A + i * 1024 : zfrag);
+                            const int mk = (int)tmask[i / 3];
+                            // two vector instructions per fragment: the validity bit spread over a word (v_bfe_i32), then a
+                            // bitwise select between the row's LDS address and the zero block's (v_bfi_b32)
+                            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                            typedef __attribute__((address_space(3))) const u32x4_t* lds_u4;
+                            unsigned sel;  // (asm: the compiler expands the builtin into two shifts, and hoists a plain compare)
+                            asm volatile("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(mk), "n"(9 * (i % 3) + T));
+                            const unsigned ar = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)(A + i * 1024);
+                            const unsigned az = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)zfrag;
+                            af[i] = __builtin_bit_cast(uint4, *(lds_u4)(unsigned long)((ar & sel) | (az & ~sel)));
                         } else {
                             af[i] = *(const uint4*)(A + i * 1024);  // padded coordinates: no masks, one address register
                         }
@@ -920,8 +926,9 @@ static int span6_run(IgemmArgs& a0, int dtype, void* stream, bool dry) {
     a.rslots = g8 / p.tiles_n;
     int maxnun = 0;  // units of the workgroup with the most rows (set by geometry())
     // Rows: the positions of the padded (H+1) x (W+1) image (pad = 1: no masks anywhere), or the pixels themselves with a
-    // per-tap validity bit per row (pad = 0: the MASKED kernel).  Returns the tile rounds of the slowest workgroup, 0 when
-    // the geometry does not fit.
+    // per-tap validity bit per row (pad = 0: the MASKED kernel).  Returns the cost of the slowest workgroup -- its tile rounds
+    // plus the 32-row units of its larger group: a launch's time follows (rounds x a + units x b) x K-steps with a ~ b,
+    // fitted on nine layer shapes of the three models (NOTEBOOK R5.17) -- or 0 when the geometry does not fit.
     auto geometry = [&](int pad, bool ks = false) -> int {
         a.Hp = a0.Hi + pad, a.Wp = a0.Wi + pad;
         if ((long)a0.B * a.Hp * a.Wp > 0x3fffffffL) return 0;
@@ -942,18 +949,18 @@ static int span6_run(IgemmArgs& a0, int dtype, void* stream, bool dry) {
         a.ppt = (a.npc + 5) / 6;
         if (a.npc < 16 || a.npc > 28) return 0;  // 4..7 taps carry one piece per loader and group
         if (L6::bytes(a.npc, ks) > 160 * 1024) return 0;
-        int rounds = 1;
+        int cost = 1;
         maxnun = 0;
         for (int xcd = 0; xcd < 8; ++xcd) {  // (the kernel's own split)
             const int ux0 = xcd * a.upx, ux1 = std::min(a.units, ux0 + a.upx);
             const int nx = std::max(0, ux1 - ux0);
             for (int rs = 0; rs < a.rslots; ++rs) {
                 const int nun = (int)((unsigned)(rs + 1) * (unsigned)nx / (unsigned)a.rslots) - (int)((unsigned)rs * (unsigned)nx / (unsigned)a.rslots);
-                rounds = std::max(rounds, ((nun + 1) / 2 + a.fmx - 1) / a.fmx);
+                cost = std::max(cost, ((nun + 1) / 2 + a.fmx - 1) / a.fmx + (nun + 1) / 2);
                 maxnun = std::max(maxnun, nun);
             }
         }
-        return rounds;
+        return cost;
     };
     // VT_SPAN6_MASK: 0 never, 1 (default) where the pixel rows save a tile round, 2 wherever they fit (tests)
     const int maskk = VT_KNOB("VT_SPAN6_MASK", 1);
@@ -972,14 +979,13 @@ static int span6_run(IgemmArgs& a0, int dtype, void* stream, bool dry) {
     const int r_masked = (maskk && !ksplit) ? geometry(0) : 0;
     const int r_padded = ksplit ? 0 : geometry(1);
     bool masked = false;
-    // (a masked step costs ~13 % more than a padded one -- 128 -> 128 @28x28, same tile count: 72.6 against 65.0 us -- so seven
-    //  rounds of pixels against eight of padded positions, 128 -> 128 @56x56, still lose: 285 against 270 us;
-    //  Darknet-YOLOv5x's forward, where pixel rows saved one round in five or six on some layers, ran 13.05 against 12.88 ms:
-    //  only a third fewer rounds or better -- one instead of two, two instead of three -- switch the geometry)
+    // (a masked step costs ~5 % more than a padded one -- two vector instructions per fragment read -- so the pixel rows are
+    //  taken where the model promises 10 % or more: one tile instead of two at 14 x 14 (-25 %), three instead of four at 40 x 40
+    //  (-7 %); not at 28 x 28 (16 : 15, measured -2.5 % / 0 %), 20 x 20 (12 : 11, +5 %), 56 x 56 (59 : 56, +1 %), 112 x 112 (+7 %))
     if (ksplit) {
         masked = true;
         geometry(0, true);
-    } else if (r_masked > 0 && (r_padded == 0 || maskk >= 2 || 3 * r_masked <= 2 * r_padded)) {
+    } else if (r_masked > 0 && (r_padded == 0 || maskk >= 2 || 10 * r_padded > 11 * r_masked)) {
         masked = true;
         geometry(0);
     } else if (r_padded == 0) {
