@@ -123,3 +123,25 @@ def test_group_entry_rejects_bad_arguments():
     null = (C.c_void_p * 1)(None)
     assert N.lib().vt_conv_wgrad_group(C.byref(d), 1, null, one(dzd), one(dw), 9 * 64, stream()) == N.VT_ERR_INVALID
     N.check(N.lib().vt_memset(vp(dw), 0, 16, stream()))
+
+
+@pytest.mark.parametrize("n,shape", [(8, (4, 128, 128, 28, 28)), (5, (3, 256, 192, 14, 14)), (2, (2, 72, 40, 9, 7))], ids=str)
+def test_grouped_launch_of_1x1_layers_on_the_general_kernel(n, shape):
+    """vt_conv_wgrad_group on 1x1 stride-1 layers (DarknetBlock.conv1, reference darknet.py:23): one launch of the general
+    kernel over the group, each layer against the float64 product of its own bf16 operands, accumulated into the existing
+    gradient; channel counts that are not multiples of the 128-wide tiles included."""
+    B, Cin, Cout, H, W = shape
+    g = torch.Generator().manual_seed(n * 31 + Cin)
+    xs = [torch.randn(B, H, W, Cin, generator=g).to(torch.bfloat16).cuda() for _ in range(n)]
+    dzs = [torch.randn(B, H, W, Cout, generator=g).to(torch.bfloat16).cuda() for _ in range(n)]
+    d = conv_desc(N.VT_BF16, xs[0], Cin, Cout, 1, 1, 0, Cout)
+    dws = [torch.full((Cout, Cin), float(i), device="cuda") for i in range(n)]
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    before = N.launch_count()
+    N.check(N.lib().vt_conv_wgrad_group(C.byref(d), n, arr(xs), arr(dzs), arr(dws), Cin, stream()))
+    torch.cuda.synchronize()
+    assert N.launch_count() - before == 1, "one launch for the group"
+    assert N.last_kernel_name().startswith("wgrad_kernel"), N.last_kernel_name()
+    for i in range(n):
+        ref = dzs[i].double().reshape(-1, Cout).t() @ xs[i].double().reshape(-1, Cin)
+        assert rel_err((dws[i] - float(i)).cpu(), ref.cpu()) < 2e-5, i

@@ -29,6 +29,8 @@
 
 namespace {
 
+constexpr int kWgMaxGroup = 8;
+
 struct WgradArgs {
     const void* x;
     const void* dz;
@@ -40,6 +42,12 @@ struct WgradArgs {
     long slab_stride;  // elements per pixel split: Cout * ldgw
     int8_t dh[VT_MAX_TAPS];
     int8_t dwv[VT_MAX_TAPS];
+    // grouped launch (round 5): nlayers > 1 same-shape layers, layer l = items [l * tiles * split, (l+1) * tiles * split);
+    // x / dz / dw above are layer 0's
+    int nlayers;
+    const void* xs[kWgMaxGroup];
+    const void* dzs[kWgMaxGroup];
+    float* dws[kWgMaxGroup];
 };
 
 __device__ __attribute__((aligned(16))) unsigned int vt_wg_zero16[4];
@@ -96,9 +104,12 @@ __global__ void __launch_bounds__(256 * G) wgrad_kernel(const WgradArgs p) {
     const int wave = gwave & 3;       // wave inside the group
     const int wm = wave >> 1, wn = wave & 1;
     // item = (pixel split, tile), tiles fastest: the workgroups of one XCD share a few pixel splits' rows of dz and x
-    const unsigned item = vt_xcd_item(blockIdx.x, gridDim.x, p.xcds);
+    const unsigned item0 = vt_xcd_item(blockIdx.x, gridDim.x, p.xcds);
     const int ntile = p.tiles_n * p.tiles_k;
-    if (item >= (unsigned)(ntile * p.split)) return;
+    const unsigned per_layer = (unsigned)(ntile * p.split);
+    if (item0 >= per_layer * (unsigned)p.nlayers) return;
+    const int layer = __builtin_amdgcn_readfirstlane((int)(item0 / per_layer));
+    const unsigned item = item0 - (unsigned)layer * per_layer;
     const int bsplit = (int)(item / (unsigned)ntile), btile = (int)(item - (unsigned)bsplit * ntile);
     const int tile_n = btile % p.tiles_n, tile_k = btile / p.tiles_n;
     const int n0 = tile_n * 128, k0 = tile_k * 128;
@@ -111,8 +122,9 @@ __global__ void __launch_bounds__(256 * G) wgrad_kernel(const WgradArgs p) {
         if (t < p.ntaps && tid == t) sTap[t] = make_int2(p.dh[t], p.dwv[t]);
     __syncthreads();
 
-    const T* __restrict__ xg = (const T*)p.x;
-    const T* __restrict__ zg = (const T*)p.dz;
+    const T* __restrict__ xg = (const T*)(p.nlayers > 1 ? p.xs[layer] : p.x);
+    const T* __restrict__ zg = (const T*)(p.nlayers > 1 ? p.dzs[layer] : p.dz);
+    float* __restrict__ dwg = p.nlayers > 1 ? p.dws[layer] : p.dw;
     const unsigned long zero_src = (unsigned long)(const void*)vt_wg_zero16;
     const unsigned ring_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)sRing +
                                (unsigned)(grp * kNS * STAGE * (int)sizeof(T));
@@ -344,7 +356,7 @@ __global__ void __launch_bounds__(256 * G) wgrad_kernel(const WgradArgs p) {
                 if (p.slab)
                     p.slab[(long)bsplit * p.slab_stride + (long)n * p.ldgw + k] = v;
                 else
-                    atomicAdd(p.dw + ((long)n * p.ldgw + k), v);
+                    atomicAdd(dwg + ((long)n * p.ldgw + k), v);
             }
         }
         if (HALVES > 1) __syncthreads();
@@ -416,6 +428,9 @@ extern "C" int vt_conv_wgrad_slabs(const vt_conv_desc* d, const void* x, const v
 // n filter gradients of ONE descriptor (same-shape layers: the 3x3 convs of a stage's DarknetBlocks, an OSA chain) in as
 // few launches as the kernels allow: the CU-owning kernel takes up to 8 layers per launch and pays its prologue and its
 // f32 atomic flush once per launch; shapes it does not cover run layer by layer.
+static int wgrad_general(const vt_conv_desc* d, int nl, const void* const* xs, const void* const* dzs, float* const* dws,
+                         int32_t ldgw, float* scratch, int64_t scratch_bytes, bool slabs, void* stream);
+
 extern "C" int vt_conv_wgrad_group(const vt_conv_desc* d, int32_t n, const void* const* x, const void* const* dz,
                                    float* const* dw, int32_t ldgw, void* stream) {
     VT_REQUIRE(d && x && dz && dw && n >= 1, VT_ERR_INVALID, "vt_conv_wgrad_group: bad argument");
@@ -435,6 +450,16 @@ extern "C" int vt_conv_wgrad_group(const vt_conv_desc* d, int32_t n, const void*
                 d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->oHs == 1 && d->oWs == 1 &&
                 d->oh0 == 0 && d->ow0 == 0 && d->oH == d->Ho && d->oW == d->Wo)
                 rc = vt_wgrad6_group(d, g, x + i, dz + i, dw + i, ldgw, stream);
+            // 1x1 stride-1 layers (the DarknetBlock / CSP 1x1 units of a stage): one launch of the general kernel over the
+            // group -- a launch of one such layer is mostly its f32 atomic flush (256 workgroups x 64 KiB) and its ramp
+            if (rc == -1 && VT_KNOB("VT_WGRAD_GROUP_1X1", 1) && d->dtype == VT_BF16 && d->ntaps == 1 && d->sh == 1 && d->sw == 1 &&
+                d->Ho == d->Hi && d->Wo == d->Wi && d->h0 + d->dh[0] == 0 && d->w0 + d->dw[0] == 0 && ldgw >= d->Cin &&
+                in_elems < 0x7fffffffL && M * d->ldy < 0x7fffffffL && d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->ldx % 8 == 0 &&
+                d->ldy % 8 == 0 && d->oHs == 1 && d->oWs == 1 && d->oh0 == 0 && d->ow0 == 0 && d->oH == d->Ho && d->oW == d->Wo) {
+                bool aligned = true;
+                for (int k = 0; k < g; ++k) aligned = aligned && vt_aligned16(x[i + k]) && vt_aligned16(dz[i + k]);
+                if (aligned) rc = wgrad_general(d, g, x + i, dz + i, dw + i, ldgw, nullptr, 0, false, stream);
+            }
         }
         if (rc == -1) {  // one by one (argument checks, every kernel family)
             g = 1;
@@ -480,9 +505,23 @@ static int wgrad_impl(const vt_conv_desc* d, const void* x, const void* dz, floa
         if (rc >= 0) return rc;
     }
 
+    return wgrad_general(d, 1, &x, &dz, &dw, ldgw, scratch, scratch_bytes, slabs, stream);
+}
+
+// the general kernel on nl >= 1 same-shape layers (nl > 1: one launch, the pixel splits -- and with them the f32 atomic
+// flush, #workgroups x 64 KiB at ~1.3 TB/s -- sized for the whole group; never with slabs)
+static int wgrad_general(const vt_conv_desc* d, int nl, const void* const* xs, const void* const* dzs, float* const* dws,
+                         int32_t ldgw, float* scratch, int64_t scratch_bytes, bool slabs, void* stream) {
+    const int epc = vt_epc(d->dtype);
+    const long M = (long)d->B * d->Ho * d->Wo;
+    const void* x = xs[0];
+    const void* dz = dzs[0];
+    float* dw = dws[0];
     WgradArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x, a.dz = dz, a.dw = dw;
+    a.nlayers = nl;
+    for (int i = 0; i < nl && i < kWgMaxGroup; ++i) a.xs[i] = xs[i], a.dzs[i] = dzs[i], a.dws[i] = dws[i];
     a.B = d->B, a.Hi = d->Hi, a.Wi = d->Wi, a.Cin = d->Cin, a.ldx = d->ldx;
     a.Ho = d->Ho, a.Wo = d->Wo, a.sh = d->sh, a.sw = d->sw, a.h0 = d->h0, a.w0 = d->w0;
     a.Cout = d->Cout, a.ldy = d->ldy, a.ntaps = d->ntaps;
@@ -505,7 +544,7 @@ static int wgrad_impl(const vt_conv_desc* d, const void* x, const void* dz, floa
     // 1x1 layers on the smaller maps are short: their cost is the atomic flush (#workgroups x 64 KiB
     // at ~1.3 TB/s), so they get one workgroup per CU instead of two (measured 38 -> 32 us)
     const int tgt = (d->ntaps == 1 && M <= 262144 && target == 512) ? 256 : target;
-    long split = tgt / tiles;
+    long split = tgt / (tiles * nl);
     // steps per wave group and workgroup, at least (8 until round 3; 24 measured 12.29 vs 12.41 ms at batch 128, same at 256)
     const int min_steps = (24);
     const long max_split = (M + (long)min_steps * pk * G - 1) / ((long)min_steps * pk * G);
@@ -527,7 +566,7 @@ static int wgrad_impl(const vt_conv_desc* d, const void* x, const void* dz, floa
     hipStream_t st = (hipStream_t)stream;
     a.split = (int)split;
     a.xcds = (8);
-    dim3 grid(vt_xcd_grid(tiles * split));
+    dim3 grid(vt_xcd_grid(tiles * split * nl));
     const int stage = 2 * pk * 128 * vt_elem_size(d->dtype);  // 16 KiB
     const bool unit = d->ntaps == 1 && d->sh == 1 && d->sw == 1 && d->h0 + d->dh[0] == 0 && d->w0 + d->dw[0] == 0 &&
                       d->Ho == d->Hi && d->Wo == d->Wi;

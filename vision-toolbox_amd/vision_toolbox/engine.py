@@ -288,6 +288,10 @@ class Builder:
         # filter gradient before the optimiser (or the bucket all-reduce, which is cut behind the op that completes the
         # bucket), and the arena keeps every x / dz.  VT_WGRAD_GROUP=1: one layer per launch.
         self.wgrad_group = max(1, min(8, int(os.environ.get("VT_WGRAD_GROUP", "8"))))
+        # the 1x1 units' filter gradients held back and grouped too?  Off: 8 layers in one launch of the general kernel are
+        # cheaper alone (one atomic flush), but released at the end of a stage they no longer run beside their own units'
+        # BatchNorm passes: step 20.31 -> 20.43 ms (NOTEBOOK R5.18).  VT_WGRAD_GROUP_1X1=1 turns it on.
+        self.wgrad_group_1x1 = os.environ.get("VT_WGRAD_GROUP_1X1", "0") == "1"
         # ... on the side stream (0) or in line on the main stream (1): the CU-owning kernel shares nothing with the
         # kernels beside it (12 waves x 168 registers, 104 KiB of LDS), so the side stream buys it no overlap
         self.wgrad_inline = os.environ.get("VT_WGRAD_INLINE", "0") != "0"
@@ -703,10 +707,13 @@ class Builder:
             self.maxpool3x3s2(y, out=pool_out, name=name + ".max_pool")  # (no normalise pass to fuse it into)
 
         wg_key = None
+        # (round 5: the 1x1 stride-1 units of a stage too -- DarknetBlock.conv1, darknet.py:23 -- through the general
+        #  kernel's grouped launch: a launch of one such layer is mostly its atomic flush and its ramp)
+        grp3 = k == 3 and s == 1 and dil == 1 and pad == 1 and x.C > 32 and Cout > 32
+        grp1 = k == 1 and s == 1 and pad == 0 and self.wgrad_group_1x1
         if (track and has_bn and not fused and not stem_fused and not padded and w.requires_grad and dt == N.VT_BF16 and
-                k == 3 and s == 1 and dil == 1 and pad == 1 and x.C > 32 and Cout > 32 and self.wgrad_group > 1 and
-                not self.deterministic):
-            wg_key = (B, x.H, x.W, x.C, x.ld, Cout, ldw)
+                (grp3 or grp1) and self.wgrad_group > 1 and not self.deterministic):
+            wg_key = (k, B, x.H, x.W, x.C, x.ld, Cout, ldw)
             self._wg_expect[wg_key] = self._wg_expect.get(wg_key, 0) + 1
 
         if track:
