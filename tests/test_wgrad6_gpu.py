@@ -138,8 +138,12 @@ def test_grouped_launch_of_1x1_layers_on_the_general_kernel(n, shape):
     dws = [torch.full((Cout, Cin), float(i), device="cuda") for i in range(n)]
     arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
     before = N.launch_count()
-    N.check(N.lib().vt_conv_wgrad_group(C.byref(d), n, arr(xs), arr(dzs), arr(dws), Cin, stream()))
-    torch.cuda.synchronize()
+    N.set_knob("VT_WGRAD_GROUP_1X1", 1)  # (off by default: NOTEBOOK R5.18)
+    try:
+        N.check(N.lib().vt_conv_wgrad_group(C.byref(d), n, arr(xs), arr(dzs), arr(dws), Cin, stream()))
+        torch.cuda.synchronize()
+    finally:
+        N.set_knob("VT_WGRAD_GROUP_1X1", 0)
     assert N.launch_count() - before == 1, "one launch for the group"
     assert N.last_kernel_name().startswith("wgrad_kernel"), N.last_kernel_name()
     for i in range(n):

@@ -452,7 +452,9 @@ extern "C" int vt_conv_wgrad_group(const vt_conv_desc* d, int32_t n, const void*
                 rc = vt_wgrad6_group(d, g, x + i, dz + i, dw + i, ldgw, stream);
             // 1x1 stride-1 layers (the DarknetBlock / CSP 1x1 units of a stage): one launch of the general kernel over the
             // group -- a launch of one such layer is mostly its f32 atomic flush (256 workgroups x 64 KiB) and its ramp
-            if (rc == -1 && VT_KNOB("VT_WGRAD_GROUP_1X1", 1) && d->dtype == VT_BF16 && d->ntaps == 1 && d->sh == 1 && d->sw == 1 &&
+            // (VT_WGRAD_GROUP_1X1=1: off by default -- the engine does not hold these layers back (NOTEBOOK R5.18), and
+            //  without the knob every launch list runs exactly the launches it ran before this path existed)
+            if (rc == -1 && VT_KNOB("VT_WGRAD_GROUP_1X1", 0) && d->dtype == VT_BF16 && d->ntaps == 1 && d->sh == 1 && d->sw == 1 &&
                 d->Ho == d->Hi && d->Wo == d->Wi && d->h0 + d->dh[0] == 0 && d->w0 + d->dw[0] == 0 && ldgw >= d->Cin &&
                 in_elems < 0x7fffffffL && M * d->ldy < 0x7fffffffL && d->Cin % 8 == 0 && d->Cout % 8 == 0 && d->ldx % 8 == 0 &&
                 d->ldy % 8 == 0 && d->oHs == 1 && d->oWs == 1 && d->oh0 == 0 && d->ow0 == 0 && d->oH == d->Ho && d->oW == d->Wo) {
