@@ -139,8 +139,9 @@ int vt_conv_wgrad_slabs(const vt_conv_desc* d, const void* x, const void* dz, fl
  * (darknet.py:20-28) or of an OSA chain (vovnet.py:41-44) -- in as few launches as the kernels allow: the CU-owning
  * stride-1 3x3 kernel takes up to 8 layers per launch and pays its prologue and its f32 atomic flush once per launch
  * (a filter gradient has no consumer before the optimiser, so a caller may hold the layers of a stage back until the
- * last one's dz exists).  Shapes that kernel does not cover run one by one, exactly as vt_conv_wgrad.  x / dz / dw are
- * HOST arrays of n device pointers. */
+ * last one's dz exists).  Shapes that kernel does not cover run one by one, exactly as vt_conv_wgrad -- except, with
+ * the knob VT_WGRAD_GROUP_1X1=1, 1x1 stride-1 layers, which then share launches of the general kernel (up to 8 layers,
+ * one atomic flush; off by default).  x / dz / dw are HOST arrays of n device pointers. */
 int vt_conv_wgrad_group(const vt_conv_desc* d, int32_t n, const void* const* x, const void* const* dz,
                         float* const* dw, int32_t ldgw, void* stream);
 
