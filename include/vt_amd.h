@@ -103,10 +103,6 @@ uint64_t vt_launch_count(void);
  * from the environment variable of the same name ONCE per process; this call sets it afterwards (the GPU tests force a
  * kernel with it).  No switch changes results beyond summation order. */
 int vt_set_knob(const char* name, int32_t value);
-/* Measurement aid: `wgs` (<= 256) workgroups of 256 threads holding `lds_bytes` of LDS each that idle for `microseconds`
- * of wall clock on `stream` -- the CU footprint of a collective library's channel kernels, to measure what it costs the
- * step's CU-owning kernels (tools/rccl_hog.py).  Computes nothing; every wave leaves by the clock alone. */
-int vt_debug_hog(int32_t wgs, int32_t lds_bytes, double microseconds, void* stream);
 int vt_memset(void* ptr, int value, uint64_t bytes, void* stream);
 
 /* ---- convolution --------------------------------------------------------

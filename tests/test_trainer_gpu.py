@@ -312,9 +312,11 @@ def test_validation_step_matches_the_oracle(name, dtype):
     train step so that the running statistics are not the initial ones.  Nothing is updated by validate()."""
     ncls, B, S = 24, 12, 96
     x, y = filler.images(B, S), filler.labels(B, ncls)
-    # (launch lists run directly, as bench.py runs them; the captured-graph form of a step has its own test above)
+    # (the default TrainStep: launch lists run directly, as bench.py runs them; the captured-graph form is opt-in and has its
+    #  own tests above and below)
     ts = TrainStep(getattr(backbones, name)(), ncls, B, S, dtype, lr=1e-3, momentum=0.9, weight_decay=1e-4,
-                   label_smoothing=0.1, device="cuda", use_graphs=False)
+                   label_smoothing=0.1, device="cuda")
+    assert ts.use_graphs is False
     filler.fill_module(ts.model, "va.")
     ts.weights_changed()
     ts.step(x.cuda(), y.cuda())
@@ -342,6 +344,30 @@ def test_validation_step_matches_the_oracle(name, dtype):
     # a second call repeats (same sums, nothing accumulates across calls)
     again = ts.validate()
     assert again["count"] == B and again["correct"] == got["correct"] and abs(again["loss"] - got["loss"]) < 1e-5
+
+
+@pytest.mark.parametrize("bucket_mb", ["1", "4"])
+def test_captured_data_parallel_segments_equal_the_eager_schedule(bucket_mb):
+    """the data-parallel trainer cuts the backward list behind every op that completes a gradient bucket,
+    and a cut may land inside a run of held filter gradients (one FORK, up to eight side-stream ops) -- the next segment
+    then begins with side-stream ops and no fork.  Captured per segment (use_graphs=True) those launches must still be part
+    of the graph: tools/dp_graph_check.py (a one-rank gloo group, VT_DP_WORLD1=1) asserts that such segments exist at this
+    bucket size and that every parameter gradient of two replays equals the eager schedule's."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, str(root / "tools" / "dp_graph_check.py"), bucket_mb], capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+    assert r.returncode == 0 and "DP_GRAPH_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    buf = torch.zeros(16, device="cuda")  # the launch-count guard of this module wants a launch here too
+    N.check(N.lib().vt_memset(buf.data_ptr(), 0, 64, int(torch.cuda.current_stream().cuda_stream)))
 
 
 def test_grouped_filter_gradients_equal_the_ungrouped_ones(monkeypatch):

@@ -102,6 +102,14 @@ int vt_comm_init(const void* id128, int32_t rank, int32_t world) {
 // order whatever streams they sit on: with the statistics exchanges (main stream, on the critical path of every layer)
 // and the multi-megabyte bucket all-reduces (filter-gradient stream) on one communicator, each exchange would wait for
 // the bucket issued before it -- and for the filter gradients queued ahead of that bucket.  Invisible with one rank.
+// CO-RESIDENCY ASSUMPTION: the two communicators' kernels are issued from two streams with no cross-rank order
+// between them, which RCCL / NCCL document as safe only while both collectives can be resident at once -- rank A may start
+// the bucket all-reduce first and rank B the statistics exchange; each then needs its peer's kernel of the SAME communicator
+// to be running.  They can be here: a collective's channel kernels take a few workgroups (<= 64 KiB of LDS), the CU-owning
+// kernels of the step (span6 / wgrad6 / pspan: one 12-wave workgroup per CU) leave at least a wave slot and 56 KiB of LDS
+// on every CU and, being persistent over a bounded tile list, always drain.  No multi-rank soak run exists (one-GPU
+// boxes); the environment variable VT_STAT_COMM=0 (read by ensure_library_comm) keeps the single-communicator form, where
+// issue order alone is the cross-rank order, at the price described above.
 int vt_comm_init_stat(const void* id128) {
     VT_REQUIRE(id128, VT_ERR_INVALID, "vt_comm_init_stat: null id");
     std::lock_guard<std::mutex> lk(g_mu);

@@ -283,34 +283,7 @@ struct Graph {
 
 extern "C" {
 
-int vt_version(void) { return 102; }  // 102: round 5 (vt_conv_wgrad_group, vt_softmax_xent_eval, vt_comm_init_stat, vt_debug_hog)
-// Measurement aid (tools/rccl_hog.py): `wgs` workgroups of 256 threads that hold `lds_bytes` of LDS each and do nothing
-// until `microseconds` of wall clock have passed -- the footprint of a collective library's channel kernels beside the
-// step's own kernels (persistent, CU-owning kernels with static partitions wait for their slowest CU).
-// Every wave leaves by the clock alone: no flag, no dependence on another workgroup.
-namespace {
-__global__ void __launch_bounds__(256) hog_kernel(unsigned long long ticks, int lds_bytes, unsigned* sink) {
-    extern __shared__ char hog_smem[];
-    if (threadIdx.x * 4 < (unsigned)lds_bytes) ((volatile unsigned*)hog_smem)[threadIdx.x] = threadIdx.x;  // (the allocation is real)
-    const unsigned long long t0 = wall_clock64();  // 100 MHz
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-    if (sink && ticks == ~0ull) sink[0] = ((volatile unsigned*)hog_smem)[0];
-}
-}  // namespace
-
-extern "C" int vt_debug_hog(int32_t wgs, int32_t lds_bytes, double microseconds, void* stream) {
-    VT_REQUIRE(wgs >= 1 && wgs <= 256 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && microseconds >= 0 && microseconds <= 1e6,
-               VT_ERR_INVALID, "vt_debug_hog: bad argument");
-    if (lds_bytes > 64 * 1024) {
-        const int rc = vt_raise_dynamic_lds((const void*)hog_kernel, lds_bytes, "vt_debug_hog");
-        if (rc != VT_OK) return rc;
-    }
-    hipLaunchKernelGGL(hog_kernel, dim3(wgs), dim3(256), lds_bytes, (hipStream_t)stream,
-                       (unsigned long long)(microseconds * 100.0), lds_bytes, (unsigned*)nullptr);
-    VT_CHECK_LAUNCH("vt_debug_hog");
-    return VT_OK;
-}
-
+int vt_version(void) { return 103; }  // 103: round 6 (vt_debug_hog left the library: tools/diag/vt_diag_hog.hip)
 int vt_set_knob(const char* name, int32_t value) {
     VT_REQUIRE(name && strlen(name) < 48, VT_ERR_INVALID, "vt_set_knob: bad name");
     // (a knob set before its first use overrides the environment: the slot exists from here on)
@@ -396,12 +369,29 @@ static int run_ops_impl(const vt_op* ops, int32_t n, void* const* bases, int32_t
     hipEvent_t& mark = bag ? capture_mark : eager_mark;
     const int stop_events = (1);
     hipEvent_t fork_ev = nullptr;  // completion event of the kernel right before the next FORK (see vt_common.h)
+    // Capture only: the side stream belongs to the capture from its first wait on the capturing stream.  A list that is
+    // captured in SEGMENTS (the data-parallel trainer cuts the backward list behind every op that completes a gradient
+    // bucket) may begin with side-stream ops whose FORK sits in the previous segment: eagerly the in-order side stream
+    // carries that dependency across the cut; a capture would launch those ops on a stream that is not capturing -- they
+    // would run once, at capture time, and be missing from the graph.  So the first side-stream op of a capture that no
+    // FORK precedes forks by itself (behind the main stream's position, which is behind the previous segment's graph).
+    bool side_captured = false;
+    auto capture_fork = [&]() -> int {
+        if (!bag || !two || side_captured) return VT_OK;
+        side_captured = true;
+        return stream_wait((hipStream_t)side, (hipStream_t)stream, bag);
+    };
     for (int i = 0; i < n; ++i) {
         vt_op op = ops[i];
         const bool on_side = (op.kind & VT_OP_SIDE_STREAM) != 0;
         op.kind &= ~VT_OP_SIDE_STREAM;
         int rc = VT_OK;
+        if (on_side && op.kind != VT_OP_FORK && op.kind != VT_OP_FORK_MARK && op.kind != VT_OP_FORK_WAIT && op.kind != VT_OP_JOIN) {
+            rc = capture_fork();
+            if (rc != VT_OK) return rc;
+        }
         if (op.kind == VT_OP_FORK) {
+            if (bag && two) side_captured = true;
             if (two && fork_ev) {
                 if (hipStreamWaitEvent((hipStream_t)side, fork_ev, 0) != hipSuccess) {
                     vt_set_error("fork: waiting for the producer's completion event failed");
@@ -447,7 +437,10 @@ static int run_ops_impl(const vt_op* ops, int32_t n, void* const* bases, int32_t
                 }
             }
         } else if (op.kind == VT_OP_FORK_WAIT) {
-            if (two) {
+            if (two && bag && mark == nullptr) {
+                rc = capture_fork();  // (the mark sits in a previous segment's capture: wait for the main stream's position)
+            } else if (two) {
+                if (bag) side_captured = true;
                 if (mark == nullptr) {
                     vt_set_error("fork wait without a preceding mark");
                     rc = VT_ERR_INVALID;
@@ -457,8 +450,10 @@ static int run_ops_impl(const vt_op* ops, int32_t n, void* const* bases, int32_t
                 }
             }
         } else if (op.kind == VT_OP_JOIN) {
-            // (unconditional: an earlier SEGMENT of the same list may have left side work open, VT_RUN_LEAVE_SIDE_OPEN)
-            if (two) rc = stream_wait((hipStream_t)stream, (hipStream_t)side, bag);
+            // (unconditional: an earlier SEGMENT of the same list may have left side work open, VT_RUN_LEAVE_SIDE_OPEN;
+            //  capture: a side stream that has not joined this capture has nothing of it to wait for -- every captured
+            //  segment joins its own side work before it ends)
+            if (two && (!bag || side_captured)) rc = stream_wait((hipStream_t)stream, (hipStream_t)side, bag);
             side_dirty = false;
         } else if (op.kind == VT_OP_BN_EVAL_COEFFS && i + 1 < n &&
                    (ops[i + 1].kind & ~VT_OP_SIDE_STREAM) == VT_OP_BN_EVAL_COEFFS) {

@@ -436,7 +436,9 @@ extern "C" int vt_conv_wgrad_group(const vt_conv_desc* d, int32_t n, const void*
     VT_REQUIRE(d && x && dz && dw && n >= 1, VT_ERR_INVALID, "vt_conv_wgrad_group: bad argument");
     for (int i = 0; i < n; ++i)
         VT_REQUIRE(x[i] && dz[i] && dw[i], VT_ERR_INVALID, "vt_conv_wgrad_group: null operand %d", i);
-    const int maxg = VT_KNOB("VT_WGRAD6_GROUP", 8);
+    // (clamped to what one launch's argument block carries: kWgMaxGroup layers in the general kernel, 8 in wgrad6)
+    int maxg = VT_KNOB("VT_WGRAD6_GROUP", 8);
+    maxg = maxg < 1 ? 1 : (maxg > kWgMaxGroup ? kWgMaxGroup : maxg);
     int i = 0;
     while (i < n) {
         int g = n - i < maxg ? n - i : maxg;

@@ -213,7 +213,6 @@ SYMBOLS = {
     "vt_bn_finalize": (_i32, [_vp, _i32, _f64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vt_stat_fold": (_i32, [_vp, _i32, _vp]),
     "vt_stat_sync": (_i32, [_vp, _i32, _vp]),
-    "vt_debug_hog": (_i32, [_i32, _i32, C.c_double, _vp]),
     "vt_comm_unique_id": (_i32, [_vp]),
     "vt_comm_init": (_i32, [_vp, _i32, _i32]),
     "vt_comm_world": (_i32, []),

@@ -77,8 +77,14 @@ def ensure_library_comm(group=None, device: Optional[torch.device] = None, stat_
     an id -- a purely local call) and the ranks all-reduce an ok flag BEFORE the id broadcast; a rank that cannot bind
     therefore raises on every rank instead of leaving the others blocked in the broadcast or in RCCL's bootstrap.  The
     collective join is followed by a second agreed flag.  `stat_comm`: also create the second communicator that
-    vt_stat_sync uses (SyncBatchNorm exchanges must not queue behind bucket all-reduces of the same communicator)."""
+    vt_stat_sync uses (SyncBatchNorm exchanges must not queue behind bucket all-reduces of the same communicator).  Two
+    communicators driven from two streams rely on both collectives being co-resident on the device (vt_comm.hip); the
+    environment variable VT_STAT_COMM=0 keeps everything on the one communicator, whose issue order is the cross-rank order."""
     import ctypes
+    import os
+
+    if os.environ.get("VT_STAT_COMM", "1") == "0":
+        stat_comm = False
 
     from . import _native as N
 
@@ -128,17 +134,19 @@ def ensure_library_comm(group=None, device: Optional[torch.device] = None, stat_
     return world
 
 
-def self_test_library_comm(device: torch.device, timeout_s: float = 30.0) -> bool:
+def self_test_library_comm(device: torch.device, timeout_s: float = 30.0, group=None) -> bool:
     """One small vt_allreduce_bucket on a stream of its own, polled from the host for at most `timeout_s`: True when it
     completed with the right sum.  A communicator that came up but whose first collective never finishes (a rank missing,
     a transport that does not connect) then costs one stuck 1 MiB kernel instead of the whole job -- the caller agrees on
-    the verdict over torch.distributed and falls back (bench.py); the library communicator is NOT used after a False."""
+    the verdict over torch.distributed and falls back (bench.py); the library communicator is NOT used after a False.
+    `group`: the process group the communicator was built over (ensure_library_comm's) -- the rank that seeds the buffer is
+    the rank INSIDE that group, which for a subgroup differs from the global one."""
     import time
 
     from . import _native as N
 
     L = N.lib()
-    world, rank = L.vt_comm_world(), dist.get_rank()
+    world, rank = L.vt_comm_world(), dist.get_rank(group)
     if not world:
         return False
     with torch.cuda.device(device):

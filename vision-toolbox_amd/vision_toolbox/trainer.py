@@ -13,8 +13,10 @@ program per rank:
 The step is one launch list cut into segments at the bucket boundaries; every segment runs
 through the native executor on two streams (main + filter-gradient side stream, left open
 across segments so N > 1 keeps the N = 1 schedule; the bucket all-reduce is issued with the
-side stream current).  hipGraph replay of the same segments is available (graphs=True) but
-measured slower than eager two-stream execution.  BatchNorm uses per-rank batch statistics by
+side stream current).  hipGraph replay of the same segments is OPT-IN (use_graphs=True): it
+measured 6 % slower than eager two-stream execution (21.2 against 20.0 ms) and one replay
+ended in a host fault inside hipGraphLaunch that five re-runs did not reproduce (NOTEBOOK
+R5.18, R6.1), so the default entry never goes through it.  BatchNorm uses per-rank batch statistics by
 default; sync_bn=True gives the reference recipe's SyncBatchNorm (configs/base.yaml:22) at the
 cost of 134 small collectives per step.
 
@@ -146,7 +148,7 @@ class TrainStep:
         device: Optional[torch.device] = None,
         process_group=None,
         bucket_mb: float = 16.0,
-        use_graphs: bool = True,
+        use_graphs: bool = False,  # opt-in: slower than the two-stream executor, see the module docstring
         plan_only: bool = False,
         sync_bn: bool = False,
         mix: bool = False,
