@@ -449,6 +449,52 @@ def pmc_traffic_live(layer: str, kernel_substr: str, timeout_s: int = 150):
             "fetch_kb_raw": out["FETCH_SIZE"], "write_kb": out["WRITE_SIZE"]}
 
 
+def rocprof_launch_avg_live(kernel_substr: str, per_step: int, steps: int = 4, timeout_s: int = 240):
+    """The dominant kernel's launch duration as rocprofv3 sees it IN THE STEP, measured now: a child run of this script
+    (`--steps-only`: the train steps and nothing else) under `rocprofv3 --kernel-trace`; the dispatches whose name
+    contains `kernel_substr` are grouped by (name, LDS bytes, grid) and the group with `per_step` dispatches per step is
+    averaged (ties: the largest LDS allocation -- the dominant layer's span is the widest).  The same number can be read
+    off profiles/r06_*_bench_kernel_stats.csv; VERDICT r05 #7b: HIP events around the launch see the launch boundary too
+    (~4-5 us more), so the line carries both.  None if the profiler is unavailable."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    tmp = tempfile.mkdtemp(prefix="vt_kt_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            env.pop(k, None)
+        warm = 2
+        subprocess.run([prof, "--kernel-trace", "--output-format", "csv", "-d", tmp, "--", sys.executable,
+                        str(ROOT / "bench.py"), "--steps", str(steps), "--warmup", str(warm), "--steps-only", "--no-cpu-baseline",
+                        "--no-pmc", "--no-secondary"], cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL)
+        groups = defaultdict(list)
+        for f in glob.glob(f"{tmp}/**/*kernel_trace.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if kernel_substr in r.get("Kernel_Name", "").replace(", ", ","):
+                    key = (r["Kernel_Name"], int(r.get("LDS_Block_Size", 0) or 0), r.get("Grid_Size", ""))
+                    groups[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        want = per_step * (steps + warm)
+        cands = [(k, v) for k, v in groups.items() if len(v) == want]
+        if not cands:
+            return None
+        (name, lds, grid), v = max(cands, key=lambda kv: kv[0][1])
+        v = v[per_step * warm:]  # the timed steps
+        return {"ms": sum(v) / len(v) / 1e6, "launches": len(v), "kernel_symbol": name[:96], "lds_bytes": lds}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def _percentiles(v):
     v = sorted(v)
     pick = lambda q: v[min(len(v) - 1, int(round(q * (len(v) - 1))))]
@@ -553,7 +599,16 @@ def cpu_baseline(budget_s: float = 75.0):
     sec = timed(make_step(bs), 2, 10)
     value_best = bs / sec
     torch.set_num_threads(best19)
-    d19_best = timed(d19, 3, 10) * 1e3
+    # (median of 30 single timings: the boxes share their host, a mean over 10 gave 4.9-8.3 ms from run to run)
+    for _ in range(3):
+        d19()
+    singles = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        d19()
+        singles.append((time.perf_counter() - t0) * 1e3)
+    singles.sort()
+    d19_best = singles[len(singles) // 2]
     all_cores = sweep.get(cores, {}).get("train_b8_images_per_sec")
     torch.set_num_threads(best)
     return {"value": round(value_best, 3), "unit": "images/sec", "cores": best, "kind": "port",
@@ -561,10 +616,11 @@ def cpu_baseline(budget_s: float = 75.0):
             "physical_cores": cores, "cgroup_cpu_quota": quota, "thread_sweep": {str(k): v for k, v in sweep.items()},
             "cpu_model": cpu_model, "logical_cpus": os.cpu_count(),
             "darknet19_fwd_b1_ms": round(d19_best, 2), "darknet19_threads": best19,
+            "darknet19_fwd_b1_ms_p10_p90": [round(singles[3], 2), round(singles[26], 2)],
             "sample": f"oracle/torch_ref.py CSPDarknet-53 fp32 train step (fwd+CE+bwd+SGD), batch {bs} @224, 10 timed steps "
                       f"after 2 warm-up at {best} threads (the best of the sweep {list(sweep)}; sweep entries: batch-8 step, "
                       f"1 warm-up + 1 timed; value_all_cores = the sweep entry at {cores} threads); Darknet-19 forward batch 1 "
-                      f"@224 (BASELINE configs[0]) 3 warm-up + 10 timed at {best19} threads; torch {torch.__version__} CPU; "
+                      f"@224 (BASELINE configs[0]) median of 30 timed after 3 warm-up at {best19} threads; torch {torch.__version__} CPU; "
                       f"{time.perf_counter() - t_start:.0f}s of CPU work in all"}
 
 
@@ -875,6 +931,10 @@ def main():
         if world == 1 and not args.no_pmc:
             # (the rocprof rows are matched by the name the dispatcher reported for this layer, e.g. "span6_kernel")
             traffic = pmc_traffic_live("128,128,3,1,28", (standalone_name or dom["kernel"]).split("<")[0])
+        rocprof_avg = None
+        if world == 1 and not args.no_pmc and insitu is not None and args.model == "cspdarknet53" and args.batch == 256:
+            # (MODE 1 = the statistics epilogue = the forward launches; 8 DarknetBlock.conv2 units of stage 2 per step)
+            rocprof_avg = rocprof_launch_avg_live("span6_kernel<1,", 8)
         # HBM-bound layers of stages 0-1 as the step runs them, in situ (HBM fraction on the early-stage convs)
         hbm_layers = hbm_layers_insitu(ts, args.batch) if args.model == "cspdarknet53" and args.image_size == 224 else []
         cfg = ("BASELINE configs[1]" if (world == 1 and args.batch == 256) else
@@ -918,6 +978,13 @@ def main():
                                             if traffic else None),
                          "algorithmic_bytes": 2.0 * (args.batch * 28 * 28 * 256 + 128 * 1152),
                          "kernel": dom["kernel"], "launch_ms": round(dom["ms"], 4), "launches_timed": dom["n"],
+                         # the same launches as rocprofv3's kernel trace of the step sees them (kernel start to end,
+                         # without the launch boundary the in-situ HIP events include) and the fraction that follows
+                         "launch_ms_rocprof": round(rocprof_avg["ms"], 4) if rocprof_avg else None,
+                         "frac_rocprof": round(dom["flops"] / (rocprof_avg["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
+                         if rocprof_avg else None,
+                         "rocprof_source": ({k: rocprof_avg[k] for k in ("launches", "kernel_symbol", "lds_bytes")}
+                                            if rocprof_avg else None),
                          "measured": "in situ (events around the layer's launches inside the step's forward list)"
                          if insitu else "standalone", "layer": dom["shape"]},
             "roofline_layers": layers,
