@@ -57,15 +57,9 @@ constexpr int kBMX = 32 * kFMX;     // rows of the tallest tile of one group
 
 // dev diagnostics (VT_SPAN6_ABL bit 16): wall-clock stamps (100 MHz) per workgroup; never read by the kernel itself
 __device__ unsigned long long vt_span6_stamps[512 * 16];
-__device__ unsigned long long vt_span6_pstamps[512 * 16];  // prologue detail (loader 0 / compute wave 0), see VT_S6_PSTAMP
 #define VT_S6_STAMP(k)                                                                                        \
     do {                                                                                                      \
         if (VT_DBG(16) && lane == 0 && blockIdx.x < 512) vt_span6_stamps[blockIdx.x * 16 + (k)] = wall_clock64(); \
-    } while (0)
-
-#define VT_S6_PSTAMP(k)                                                                                        \
-    do {                                                                                                      \
-        if (VT_DBG(16) && lane == 0 && blockIdx.x < 512) vt_span6_pstamps[blockIdx.x * 16 + (k)] = wall_clock64(); \
     } while (0)
 
 __device__ __attribute__((aligned(16))) unsigned int vt_span6_zero16[4];  // source of every padding row
@@ -83,7 +77,6 @@ struct S6Args {
     int Hp, Wp, Mp;  // the image H x W and the number of positions B*H*W (round 5: rows are the pixels themselves; the
                      // names date from the padded (H+1) x (W+1) enumeration, see the kernel's compute-wave comment)
     unsigned hp_magic, wp_magic;  // ceil(2^32 / Hp), ceil(2^32 / Wp): quotients by multiply-high (+ one correction)
-    int s64b, s64i, s64j;         // 64 positions = s64b images + s64i rows + s64j columns of the padded image (tile_bases)
     int dtap[9];     // span row of every tap
     int tsel[9];     // tap t reads row i + er - 1, column j + ec - 1: er | ec << 2  (er, ec in 0..2)
     int debug;       // dev ablations (VT_SPAN6_ABL): 1 no DMA in the loop, 2 no MFMA / reads, 4 no vmcnt wait, 16 stamps
@@ -241,100 +234,66 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
 #define VT_TILE_U0(g, k) (VT_G_U0(g) + (k) * (VT_G_NUN(g) / ntile) + min((k), VT_G_NUN(g) % ntile))
 #define VT_TILE_F(g, k) (VT_G_NUN(g) / ntile + ((k) < VT_G_NUN(g) % ntile ? 1 : 0))
 
-    // ---- address arithmetic shared by the loader waves and, in the prologue only, the compute waves ----------------
-    const int lj = wave & 3;  // loader index (waves 8..11) / the quarter of the prologue's work a compute wave takes
-    const char* xg = (const char*)p.x;
-    const unsigned a_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)(smem + L6::a_off(KSPLIT));
-    const unsigned m0_keep = get_m0();
-    const long ldx2 = (long)p.ldx * 2;
-    const int Mp = a.Mp, Wp = a.Wp, Hp = a.Hp, W_ = p.Wi, H_ = p.Hi;
-    const unsigned wp_magic = a.wp_magic, hp_magic = a.hp_magic;
-    const unsigned long zero_src = (unsigned long)(const void*)vt_span6_zero16;
-
-    // Pixels are enumerated in PADDED coordinates: every image is (H+1) x (W+1) positions whose extra row and
-    // column are zero pixels, so a tap is a constant offset in the flat padded index (the zero column right of
-    // row i is the one left of row i+1, the zero row below an image the one above the next) and the compute
-    // waves need no masks at all.  The span is built from the unpadded tensor: LDS row r of a piece is
-    // padded position mp; its source is pixel (b, i, j) or the zero page.
-    // span piece = 16 rows x 64 B: lane owns row (lane>>2), source chunk (lane&3)^swzA(lane>>4)
-    const int cjA = (lane & 3) ^ swzA(lane >> 4);
-    // (b, i, j) of padded position mp (0 <= mp < Mp); false for a padding position
-    auto unpad = [&](int mp, int& b_, int& i_, int& j_) -> bool {
-        int q = (int)__umulhi((unsigned)mp, wp_magic);
-        int j = mp - q * Wp;
-        if (j < 0) j += Wp, --q;
-        int b = (int)__umulhi((unsigned)q, hp_magic);
-        int i = q - b * Hp;
-        if (i < 0) i += Hp, --b;
-        b_ = b, i_ = i, j_ = j;
-        return j < W_ && i < H_;
-    };
-    // The padded -> pixel mapping of a wave's pieces (piece T of group g = span rows 16*(lj + 4T) ..) depends on
-    // the tile only, not on the channel chunk: it is computed once per tile (behind taps 6 / 7 of the previous
-    // tile's first chunk) and a piece in the step loop costs one add.  ab[T]: global source (channel chunk 0) of this
-    // lane's 16 bytes of piece T's row; vm bit T: a real pixel (the chunk's byte offset applies), else the zero page.
-    // Round 6: ONE division per tile -- piece T's row is position mp0 + 64 T, so (b, i, j) advance by the host-computed
-    // digits of 64 in the (Hp, Wp) number system with at most one carry each (was: seven divisions, ~45 vector
-    // instructions per piece of a prologue that the first tick waits for).
-    auto tile_bases = [&](int m0t, unsigned long (&ab)[7], unsigned& vm) {
-        vm = 0;
-        const int mp0 = m0t + a.dmin + lj * 16 + (lane >> 2);
-        if constexpr (MASKED) {  // rows are the pixels themselves: no division
-#pragma unroll
-            for (int T = 0; T < 7; ++T) {
-                const int mp = mp0 + 64 * T;
-                const bool ok = (unsigned)mp < (unsigned)Mp;
-                ab[T] = ok ? (unsigned long)xg + (unsigned long)((long)mp * ldx2 + cjA * 16) : zero_src;
-                vm |= (ok ? 1u : 0u) << T;
-            }
-        } else {
-            ArgsPtr Q = fresh_args();
-            const int sb = Q->s64b, si = Q->s64i, sj = Q->s64j, B_ = Q->p.B;
-            int b, i, j;
-            // (mp0 >= -Wp - 1: one image further on the division sees a non-negative position)
-            unpad(mp0 + Hp * Wp, b, i, j);
-            --b;
-#pragma unroll
-            for (int T = 0; T < 7; ++T) {
-                const bool ok = b >= 0 && b < B_ && i < H_ && j < W_;  // (b < B: mp < Mp)
-                const long pix = ((long)b * H_ + i) * W_ + j;
-                ab[T] = ok ? (unsigned long)xg + (unsigned long)(pix * ldx2 + cjA * 16) : zero_src;
-                vm |= (ok ? 1u : 0u) << T;
-                j += sj;
-                if (j >= Wp) j -= Wp, ++i;
-                i += si;
-                if (i >= Hp) i -= Hp, ++b;
-                b += sb;
-            }
-        }
-    };
-    // this wave's quarter of the table of group g's tile that starts at padded position m0t (table half par):
-    // where each row is stored, -1 for a padding position
-    auto row_tables = [&](int g, int par, int m0t) {
-        ArgsPtr Q = fresh_args();
-        constexpr int QR = (kBMX + 3) / 4;
-        const int r = lj * QR + lane;
-        if (lane < QR && r < kBMX) {
-            const int mp = m0t + r;
-            int po = -1;
-            if (mp < Mp) {
-                int b, i, j;
-                if (unpad(mp, b, i, j))
-                    po = (b * Q->p.oH + (i * Q->p.oHs + Q->p.oh0)) * Q->p.oW + (j * Q->p.oWs + Q->p.ow0);
-            }
-            sPo[(g * 2 + par) * kBMX + r] = po;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // written before this wave's next barrier
-    };
-
     if (wave >= 8) {
         // =========================== loader waves ==================================================
+        const int lj = wave - 8;  // 0..3
         VT_S6_STAMP(0);
+        const char* xg = (const char*)p.x;
         const char* wg = (const char*)p.w;
+        const unsigned a_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)(smem + L6::a_off(KSPLIT));
         const unsigned b_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)(smem + L6::kB);
+        const unsigned m0_keep = get_m0();
+        const long ldx2 = (long)p.ldx * 2;
         const int cin2 = p.Cin * 2;
+        const int Mp = a.Mp, Wp = a.Wp, Hp = a.Hp, W_ = p.Wi, H_ = p.Hi;
+        const unsigned wp_magic = a.wp_magic, hp_magic = a.hp_magic;
+        const unsigned long zero_src = (unsigned long)(const void*)vt_span6_zero16;
+
+        // Pixels are enumerated in PADDED coordinates: every image is (H+1) x (W+1) positions whose extra row and
+        // column are zero pixels, so a tap is a constant offset in the flat padded index (the zero column right of
+        // row i is the one left of row i+1, the zero row below an image the one above the next) and the compute
+        // waves need no masks at all.  The loaders build the span from the unpadded tensor: LDS row r of a piece is
+        // padded position mp; its source is pixel (b, i, j) or the zero page.
+        // span piece = 16 rows x 64 B: lane owns row (lane>>2), source chunk (lane&3)^swzA(lane>>4)
+        const int cjA = (lane & 3) ^ swzA(lane >> 4);
+        // (b, i, j) of padded position mp (0 <= mp < Mp); false for a padding position
+        auto unpad = [&](int mp, int& b_, int& i_, int& j_) -> bool {
+            int q = (int)__umulhi((unsigned)mp, wp_magic);
+            int j = mp - q * Wp;
+            if (j < 0) j += Wp, --q;
+            int b = (int)__umulhi((unsigned)q, hp_magic);
+            int i = q - b * Hp;
+            if (i < 0) i += Hp, --b;
+            b_ = b, i_ = i, j_ = j;
+            return j < W_ && i < H_;
+        };
+        // global source (channel chunk 0) of this lane's 16 bytes of the span row at padded position mp; `ok`: a real
+        // pixel (the chunk's byte offset applies), else the zero page
+        auto span_src = [&](int mp, bool& ok) -> unsigned long {
+            const bool inr = (unsigned)mp < (unsigned)Mp;
+            if constexpr (MASKED) {  // rows are the pixels themselves: no division
+                ok = inr;
+                return inr ? (unsigned long)xg + (unsigned long)((long)mp * ldx2 + cjA * 16) : zero_src;
+            }
+            int b, i, j;
+            ok = unpad(inr ? mp : 0, b, i, j) && inr;
+            const long pix = ((long)b * H_ + i) * W_ + j;
+            return ok ? (unsigned long)xg + (unsigned long)(pix * ldx2 + cjA * 16) : zero_src;
+        };
+        // The padded -> pixel mapping of this wave's pieces (piece T of group g = span rows 16*(lj + 4T) ..) depends on
+        // the tile only, not on the channel chunk: it is computed once per tile (behind taps 6 / 7 of the previous
+        // tile's first chunk) and a piece in the step loop costs one add.
         unsigned long ab_cur[2][7], ab_nxt[2][7];
         unsigned vm_cur[2] = {0, 0}, vm_nxt[2] = {0, 0};  // bit T: piece T's row of this lane is a real pixel
+        auto tile_bases = [&](int m0t, unsigned long (&ab)[7], unsigned& vm) {
+            vm = 0;
+#pragma unroll
+            for (int T = 0; T < 7; ++T) {
+                bool ok;
+                ab[T] = span_src(m0t + a.dmin + (lj + 4 * T) * 16 + (lane >> 2), ok);
+                vm |= (ok ? 1u : 0u) << T;
+            }
+        };
         // filter slice = 8 pieces of 16 rows, this loader's are q = 2*lj, 2*lj+1; row n = 16q + (lane>>2); the
         // fragment reads address row n with chunk position kq ^ swz4(n>>3), so the source chunk is
         // (lane&3) ^ swz4(2q + (lane>>5)).  Rows past Cout (N tail) are clamped: their outputs are never stored.
@@ -346,6 +305,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
             const int cj = (lane & 3) ^ swz4(2 * q + (lane >> 5));
             b_voff[i] = (unsigned)(((long)n * p.ldw + cj * 8) * 2);
         }
+        int issued = 0;  // LDS-DMA instructions this wave has issued
 
         auto issue_slice = [&](int slot, int ic, int T) {
             const char* sb = wg + (long)ic * 64 + (long)T * cin2;
@@ -358,17 +318,36 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                     glds_s(b_voff[i], sb + koff);
                 }
             }
+            issued += KSPLIT ? 4 : 2;
+        };
+        // this loader's quarter of the table of group g's tile that starts at padded position m0t (table half par):
+        // where each row is stored, -1 for a padding position
+        auto row_tables = [&](int g, int par, int m0t) {
+            ArgsPtr Q = fresh_args();
+            constexpr int QR = (kBMX + 3) / 4;
+            const int r = lj * QR + lane;
+            if (lane < QR && r < kBMX) {
+                const int mp = m0t + r;
+                int po = -1;
+                if (mp < Mp) {
+                    int b, i, j;
+                    if (unpad(mp, b, i, j))
+                        po = (b * Q->p.oH + (i * Q->p.oHs + Q->p.oh0)) * Q->p.oW + (j * Q->p.oWs + Q->p.ow0);
+                }
+                sPo[(g * 2 + par) * kBMX + r] = po;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // written before this wave's next barrier
         };
 
-        // ---- prologue: slices 0..2 and the piece sources of both groups' first tiles -----------------------------
-        // Round 6: the FIRST chunk's span pieces and the first tiles' row tables come from the COMPUTE waves, which
-        // have nothing to do before the first tick (compute wave w of group g takes the pieces this loader takes for
-        // group g in the loop, below): the first tick waited for ~1250 loader instructions in a row -- 6.0 us before
-        // the last prologue LDS-DMA was even issued (profiles/r04_span6_phases.json) -- and now for the longer of a
-        // loader's share (slices, piece sources for the chunks that follow) and a compute wave's (one group's piece
-        // sources, seven LDS-DMAs, a quarter of a row table).  The first wait of the loop is a full one.
+        // ---- prologue: both groups' first span chunk, slices 0..2, the first tiles' row tables -----------
         const long S = (long)ntile * nsteps;  // steps of each group
         int m0c[2] = {VT_TILE_U0(0, 0) * 32, VT_TILE_U0(1, 0) * 32};
+        // Round 4: the three filter slices go out FIRST (their addresses cost nothing), then each group's piece sources
+        // and pieces: the first loads are in flight while the ~600 vector instructions of the two tile_bases calls run,
+        // instead of behind them (the stamps put the first tick 6.8 us after the launch, 6.0 of them before the last
+        // prologue DMA was issued).  The first wait of the loop is then a full one: its counted form assumes the spans
+        // are older than slice 0.
+        int h0 = 0, h1 = 0, h2 = 0;  // `issued` right after this wave's share of slices s, s+1, s+2 went out
         int sic = 0, sT = 0;         // (chunk, tap) of the next slice to issue; slices repeat per tile
         long sg = 0;                 // its step
         auto next_slice = [&]() {
@@ -380,17 +359,53 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                     if (++sic == nchunks) sic = 0;
                 }
             }
+            h0 = h1, h1 = h2, h2 = issued;
         };
         next_slice();
         next_slice();
         next_slice();
-        VT_S6_PSTAMP(0);
-        tile_bases(m0c[0], ab_cur[0], vm_cur[0]);
-        tile_bases(m0c[1], ab_cur[1], vm_cur[1]);
-        VT_S6_PSTAMP(1);
+        (void)h0;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            tile_bases(m0c[g], ab_cur[g], vm_cur[g]);
+#pragma unroll
+            for (int T = 0; T < 7; ++T)
+                if (lj + 4 * T < a.npc) {
+                    set_m0(a_base + (unsigned)((g * 2) * aslot_bytes + (lj + 4 * T) * 1024));
+                    glds_v(ab_cur[g][T] + ((g == 1 && ((vm_cur[g] >> T) & 1u)) ? (unsigned long)koff : 0ul));
+                    ++issued;
+                }
+        }
+        row_tables(0, 0, m0c[0]);
+        row_tables(1, 0, m0c[1]);
         if (lj == 0 && lane < 4) ((unsigned*)(smem + L6::kZ))[lane] = 0u;  // the fragment of a tap outside the image
+#ifdef VT_SPAN6_PROTO_NORM
+        {  // the first chunk of the first tiles: everything of the prologue must have landed (the loop's first wait is a full one anyway)
+            vmw<0>();
+            float psc0[8], psf0[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                psc0[e] = 1.0f, psf0[e] = 0.0f;
+                asm volatile("" : "+v"(psc0[e]), "+v"(psf0[e]));
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int T = 0; T < 7; ++T)
+                    if (lj + 4 * T < a.npc) {
+                        uint4* q = (uint4*)(smem + L6::a_off(KSPLIT) + (g * 2) * aslot_bytes + (lj + 4 * T) * 1024 + lane * 16);
+                        float f[8];
+                        VecIO<bf16_t>::unpack(*q, f);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = fmaxf(fmaf(f[e], psc0[e], psf0[e]), 0.f);
+                        uint4 o = VecIO<bf16_t>::pack(f);
+                        if (!((vm_cur[g] >> T) & 1u)) o = make_uint4(0, 0, 0, 0);
+                        *q = o;
+                    }
+        }
+#endif
         VT_S6_STAMP(1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // zero block written before barrier 0
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // zero block and first tables written before barrier 0
 
         // Tick t starts with barrier t.  Group 0 reads step s in tick 2s, group 1 in tick 2s+1 (and both re-read the
         // slice during their MFMA ticks 2s+1 / 2s+2), so a slice's ring slot is free from barrier 2s+3 on; group g's
@@ -399,6 +414,31 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
         //   odd tick:  [its piece of group 1's next span] [its two pieces of slice s+3]
         // so before the even tick of tap T exactly 4 + 2 * (P(T-1) + P(T-2)) of its instructions are younger than
         // slice s (P(t) = 1 for 0 <= t < NTP): compile-time counts.
+#ifdef VT_SPAN6_PROTO_NORM
+        // PROTOTYPE (diagnostic builds only): consumer-side normalise in the loader waves.  A span piece
+        // that has landed (retired by the counted wait three taps after its issue) is rewritten in place as
+        // relu(x * scale + shift) -- ds_read_b128, 8 x (unpack, fma, max), pack, ds_write_b128 -- before the compute groups
+        // read the chunk; rows sourced from the zero page stay zero (the loader's own per-piece row mask).  scale = 1,
+        // shift = 0 here (kept opaque to the compiler): the launch computes conv(relu(x)), which is what the harness checks;
+        // the instruction stream is the one a real per-channel normalise would have, less two LDS reads per chunk.
+        float psc[8], psf[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            psc[e] = 1.0f, psf[e] = 0.0f;
+            asm volatile("" : "+v"(psc[e]), "+v"(psf[e]));
+        }
+        auto proto_piece = [&](int g, int slot, int TP, unsigned vmask) {
+            uint4* q = (uint4*)(smem + L6::a_off(KSPLIT) + (g * 2 + slot) * aslot_bytes + (lj + 4 * TP) * 1024 + lane * 16);
+            const uint4 raw = *q;
+            float f[8];
+            VecIO<bf16_t>::unpack(raw, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = fmaxf(fmaf(f[e], psc[e], psf[e]), 0.f);
+            uint4 o = VecIO<bf16_t>::pack(f);
+            if (!((vmask >> TP) & 1u)) o = make_uint4(0, 0, 0, 0);
+            *q = o;
+        };
+#endif
         unsigned long long lwait = 0;
         const unsigned long long lc0 = clock64();
         int acur = 0;                    // span slot (both groups) of the chunk being read
@@ -439,6 +479,12 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                             set_m0(m0g[0] + T * 4096);
                             glds_v(base + (v ? cb64 : 0ul));
                         }
+#ifdef VT_SPAN6_PROTO_NORM
+                        if constexpr (T >= 3 && T - 3 < NTP) {  // group 0's piece of tap T - 3 has landed (this tick's wait)
+                            proto_piece(0, acur ^ 1, T - 3, nx ? vm_nxt[0] : vm_cur[0]);
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        }
+#endif
                         // the next tiles' row tables, behind taps 6 (group 0) and 7 (group 1) of this tile's first chunk:
                         // the halves they go to were last read by the previous tiles' epilogues, which every compute
                         // wave left before this tile's first ticks
@@ -472,6 +518,12 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                                 glds_s(b_voff[1], sb + koff);
                             }
                         }
+#ifdef VT_SPAN6_PROTO_NORM
+                        if constexpr (T >= 3 && T - 3 < NTP) {
+                            proto_piece(1, acur ^ 1, T - 3, nx ? vm_nxt[1] : vm_cur[1]);
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        }
+#endif
                         if (T == 7 && ic == 0 && has_next) {
                             row_tables(1, (k + 1) & 1, m0n[1]);
                             tile_bases(m0n[1], ab_nxt[1], vm_nxt[1]);
@@ -536,25 +588,6 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
     int bcur = 0, acur = 0;
     unsigned long long cwait = 0, cR = 0, cM = 0;
 
-    {
-        // ---- prologue (round 6): this wave's share of its group's first span chunk and first row table -------------
-        const int m0g = VT_TILE_U0(grp, 0) * 32;
-        unsigned long ab0[7];
-        unsigned vm0;
-        tile_bases(m0g, ab0, vm0);
-        if (wave == 0) VT_S6_PSTAMP(2);
-#pragma unroll
-        for (int T = 0; T < 7; ++T)
-            if (lj + 4 * T < a.npc) {
-                set_m0(a_base + (unsigned)((grp * 2) * aslot_bytes + (lj + 4 * T) * 1024));
-                glds_v(ab0[T] + ((grp == 1 && ((vm0 >> T) & 1u)) ? (unsigned long)koff : 0ul));
-            }
-        if (wave == 0) VT_S6_PSTAMP(3);
-        row_tables(grp, 0, m0g);
-        vmw<0>();  // landed before this wave's next barrier: group 0 reads the chunk in tick 0, group 1 in tick 1
-        set_m0(m0_keep);
-        if (wave == 0) VT_S6_PSTAMP(4);
-    }
     if (grp == 1) wg_barrier();  // tick 0: group 0 reads its first step
 
     for (int k = 0; k < ntile; ++k) {
@@ -959,7 +992,6 @@ static int span6_run(IgemmArgs& a0, int dtype, void* stream, bool dry) {
         return -1;
     }
     const int smem = L6::bytes(a.npc, ksplit);
-    a.s64j = 64 % a.Wp, a.s64i = (64 / a.Wp) % a.Hp, a.s64b = (64 / a.Wp) / a.Hp;
     a.hp_magic = (unsigned)((0x100000000ull + a.Hp - 1) / a.Hp);
     a.wp_magic = (unsigned)((0x100000000ull + a.Wp - 1) / a.Wp);
     const int mode = (p.flags & VT_CONV_STATS) ? 1 : ((p.flags & VT_CONV_AFFINE) ? 2 : 0);
@@ -1000,15 +1032,6 @@ static int span6_run(IgemmArgs& a0, int dtype, void* stream, bool dry) {
             std::sort(en.begin(), en.end());
             fprintf(stderr, "[span6 stamps] shader cycles, mean per WG: loader 0 waiting in barriers %.0f of %.0f in its loop; compute wave 0 waiting in barriers %.0f, read-tick work %.0f, MFMA-tick work %.0f\n",
                     avg[13], avg[14], avg[15], avg[3], avg[12]);
-            {
-                static unsigned long long hp[512 * 16];
-                (void)hipMemcpyFromSymbol(hp, HIP_SYMBOL(vt_span6_pstamps), sizeof(hp));
-                double pa[5] = {0};
-                for (int b = 0; b < nb; ++b)
-                    for (int k = 0; k < 5; ++k) pa[k] += (double)(hp[b * 16 + k] - t0) * 0.01 / nb;
-                fprintf(stderr, "[span6 prologue stamps, us from the first workgroup's start, mean over %d WGs] loader: slices issued %.2f piece sources done %.2f | "
-                                "compute wave 0: piece sources done %.2f pieces issued %.2f landed + row table %.2f\n", nb, pa[0], pa[1], pa[2], pa[3], pa[4]);
-            }
             fprintf(stderr, "[span6 stamps] start times (us), sorted, every 32nd WG:");
             for (int b = 0; b < nb; b += 32) fprintf(stderr, " %.1f", st[b]);
             fprintf(stderr, "\n[span6 stamps] loader end times (us), sorted, every 32nd WG:");
