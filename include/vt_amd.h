@@ -116,6 +116,22 @@ int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w, void* y,
                   const float* scale, const float* shift, const void* residual,
                   float* stats, void* stream);
 
+/* A data gradient that also REDUCES the BatchNorm backward of the unit whose output it differentiates (round 6).
+ * `d` describes a convolution run on dz with the re-packed filter (as vt_conv_igemm is called for a data gradient: flags
+ * 0, every pixel of the output tensor produced: oHs = oWs = 1, oH = Ho, oW = Wo); its result dy = d(y) is the gradient of
+ * the output y = act(z * scale + shift) of a ConvNormAct unit (components.py:26-44) that has no other consumer.  Besides
+ * storing dy the call adds that unit's backward sums -- exactly what vt_bn_act_bwd_reduce(dy, z, ...) adds:
+ *   sums[0][c] += sum g,  sums[1][c] += invstd[c] * sum g * (z - mean[c]),   g = dy (as stored) * [z * scale + shift > 0]
+ * (`relu` 0: no mask) -- so that the separate reduction pass, which reads dy and z once more, disappears: where the
+ * two-group persistent 3x3 kernel takes the launch the sums come out of its epilogue (dy in registers, z read like a
+ * residual operand); everywhere else the call is the two launches it replaces.  `sums` is a statistics buffer
+ * (VT_STAT_REPLICAS), fixed point: the result does not depend on the order in which workgroups finish.
+ * Replaces the autograd backward of nn.Conv2d (components.py:26-35) with respect to its input + the reductions of
+ * the autograd backward of nn.BatchNorm2d / nn.ReLU (components.py:36-44) of the unit in front of it. */
+int vt_conv_dgrad_bnred(const vt_conv_desc* d, const void* dz, const void* w, void* dy, const void* z, int32_t ldz,
+                        const float* scale, const float* shift, const float* mean, const float* invstd,
+                        int32_t relu, float* sums, void* stream);
+
 /* Filter gradient: dw[n][t][c] += sum_pixels dz(pix,n) * x_gathered(pix,t,c),
  * fp32 accumulation straight into the (channels_last) .grad of the weight.
  * `d` is the forward descriptor (ldy = pixel stride of dz).  Replaces the
@@ -447,6 +463,7 @@ enum vt_op_kind {
     VT_OP_ALLREDUCE,        /* vt_allreduce_bucket (a gradient bucket, in place) */
     VT_OP_STAT_SYNC,        /* vt_stat_sync (one BatchNorm layer's sums over all ranks) */
     VT_OP_XENT_EVAL,        /* vt_softmax_xent_eval (validation: loss sum, top-1 hits, rows) */
+    VT_OP_CONV_DGRAD_BNRED, /* vt_conv_dgrad_bnred (a data gradient + the BatchNorm-backward sums of the producing unit) */
     VT_OP_KIND_END
 };
 

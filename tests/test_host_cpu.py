@@ -163,7 +163,11 @@ def test_cspdarknet53_program_structure():
     # their filter gradient is formed inside pw_bwd up to 64 x 64; the 128-channel ones (stage 1 pair + out_conv, the 8
     # block units of stage 2: 11 filters) hand dz to the filter-gradient kernel
     assert h["conv_wgrad"] == 66 - pw_units + 11 and h["bn_finalize"] == 67
-    assert h["bn_bwd_apply"] == 66 - pw_units and h["bn_bwd_reduce"] == 66 - pw_units
+    # round 6: where a unit's d(y) comes out of ONE 3x3 stride-1 data-gradient launch (DarknetBlock.conv1 <- conv2) that launch
+    # also forms the unit's backward sums (vt_conv_dgrad_bnred): here the 8 + 4 blocks of stages 3 and 4 (stages 0-2 are
+    # pointwise units under this test's VT_PW_MIN_MB=0; at the production threshold the 8 of stage 2 join: 20 of 57)
+    assert h["conv_dgrad_bnred"] == 12
+    assert h["bn_bwd_apply"] == 66 - pw_units and h["bn_bwd_reduce"] + h["conv_dgrad_bnred"] == 66 - pw_units
     assert h["bn_bwd_finalize"] == 67
     # residual adds are folded into the normalise pass and torch.cat is elided: the ONLY
     # elementwise launches are one bn_act_apply per remaining unit; the only copies are the bf16 weight

@@ -466,6 +466,30 @@ int launch(IgemmArgs& a, hipStream_t st) {
 
 }  // namespace
 
+// the kernel argument block of a validated descriptor
+static void fill_args(IgemmArgs& a, const vt_conv_desc* d, const void* x, const void* w, void* y, const float* scale,
+                      const float* shift, const void* residual, float* stats) {
+    memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.w = w;
+    a.y = y;
+    a.scale = scale;
+    a.shift = shift;
+    a.res = residual;
+    a.stats = stats;
+    a.B = d->B, a.Hi = d->Hi, a.Wi = d->Wi, a.Cin = d->Cin, a.ldx = d->ldx;
+    a.Ho = d->Ho, a.Wo = d->Wo, a.sh = d->sh, a.sw = d->sw, a.h0 = d->h0, a.w0 = d->w0;
+    a.Cout = d->Cout, a.ldy = d->ldy, a.oH = d->oH, a.oW = d->oW;
+    a.oHs = d->oHs, a.oWs = d->oWs, a.oh0 = d->oh0, a.ow0 = d->ow0;
+    a.ldw = d->ldw, a.ldr = d->ldr, a.flags = d->flags, a.ntaps = d->ntaps;
+    a.M = d->B * d->Ho * d->Wo;
+    a.Ktot = d->ntaps * d->Cin;
+    a.dense_out = (d->oHs == 1 && d->oWs == 1 && d->oh0 == 0 && d->ow0 == 0 && d->oH == d->Ho && d->oW == d->Wo);
+    memcpy(a.dh, d->dh, VT_MAX_TAPS);
+    memcpy(a.dw, d->dw, VT_MAX_TAPS);
+
+}
+
 extern "C" int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w, void* y,
                              const float* scale, const float* shift, const void* residual,
                              float* stats, void* stream) {
@@ -474,6 +498,7 @@ extern "C" int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w
                "vt_conv_igemm: NOSTORE is the statistics-only pass");
     VT_REQUIRE(d->dtype == VT_F32 || d->dtype == VT_BF16, VT_ERR_UNSUPPORTED,
                "vt_conv_igemm: dtype %d", d->dtype);
+    VT_REQUIRE(!(d->flags & VT_CONV_BNRED), VT_ERR_INVALID, "vt_conv_igemm: unknown flag bits 0x%x", d->flags);
     const int epc = vt_epc(d->dtype);
     VT_REQUIRE(d->ntaps >= 1 && d->ntaps <= VT_MAX_TAPS, VT_ERR_UNSUPPORTED,
                "vt_conv_igemm: ntaps %d outside [1,%d]", d->ntaps, VT_MAX_TAPS);
@@ -514,24 +539,7 @@ extern "C" int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w
     }
 
     IgemmArgs a;
-    memset(&a, 0, sizeof(a));
-    a.x = x;
-    a.w = w;
-    a.y = y;
-    a.scale = scale;
-    a.shift = shift;
-    a.res = residual;
-    a.stats = stats;
-    a.B = d->B, a.Hi = d->Hi, a.Wi = d->Wi, a.Cin = d->Cin, a.ldx = d->ldx;
-    a.Ho = d->Ho, a.Wo = d->Wo, a.sh = d->sh, a.sw = d->sw, a.h0 = d->h0, a.w0 = d->w0;
-    a.Cout = d->Cout, a.ldy = d->ldy, a.oH = d->oH, a.oW = d->oW;
-    a.oHs = d->oHs, a.oWs = d->oWs, a.oh0 = d->oh0, a.ow0 = d->ow0;
-    a.ldw = d->ldw, a.ldr = d->ldr, a.flags = d->flags, a.ntaps = d->ntaps;
-    a.M = d->B * d->Ho * d->Wo;
-    a.Ktot = d->ntaps * d->Cin;
-    a.dense_out = (d->oHs == 1 && d->oWs == 1 && d->oh0 == 0 && d->ow0 == 0 && d->oH == d->Ho && d->oW == d->Wo);
-    memcpy(a.dh, d->dh, VT_MAX_TAPS);
-    memcpy(a.dw, d->dw, VT_MAX_TAPS);
+    fill_args(a, d, x, w, y, scale, shift, residual, stats);
 
     hipStream_t st = (hipStream_t)stream;
     if (!d2s) {  // (these kernels write dense rows only)
@@ -577,4 +585,36 @@ extern "C" int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w
     }
     if (d->Cout > 32) return launch<float, 128, 64, 2, 2, 2>(a, st);
     return launch<float, 128, 32, 4, 1, 2>(a, st);
+}
+
+// A data gradient that also reduces the BatchNorm backward of the unit whose output it differentiates (round 6): see
+// include/vt_amd.h.  Fused where the two-group persistent kernel takes the launch (its epilogue holds d(y) in registers
+// and reads the unit's z like a residual operand); everywhere else the same two launches as before.
+extern "C" int vt_conv_dgrad_bnred(const vt_conv_desc* d, const void* dz, const void* w, void* dy, const void* z, int32_t ldz,
+                                   const float* scale, const float* shift, const float* mean, const float* invstd,
+                                   int32_t relu, float* sums, void* stream) {
+    VT_REQUIRE(d && dz && w && dy && z && scale && shift && mean && invstd && sums, VT_ERR_INVALID,
+               "vt_conv_dgrad_bnred: null argument");
+    VT_REQUIRE(relu == 0 || relu == 1, VT_ERR_UNSUPPORTED, "vt_conv_dgrad_bnred: activation code %d (none / ReLU only)", relu);
+    VT_REQUIRE(d->flags == 0, VT_ERR_INVALID, "vt_conv_dgrad_bnred: the launch has a plain epilogue (flags 0x%x)", d->flags);
+    const long M = (long)d->B * d->oH * d->oW;
+    const bool whole = d->oHs == 1 && d->oWs == 1 && d->oh0 == 0 && d->ow0 == 0 && d->oH == d->Ho && d->oW == d->Wo;
+    VT_REQUIRE(whole, VT_ERR_INVALID, "vt_conv_dgrad_bnred: the launch must produce every pixel of d(y)");
+    const int epc = vt_epc(d->dtype);
+    VT_REQUIRE(ldz % epc == 0 && ldz >= d->Cout && vt_aligned16(z), VT_ERR_INVALID, "vt_conv_dgrad_bnred: bad z");
+    if (d->dtype == VT_BF16 && VT_KNOB("VT_DGRAD_BNRED", 1) && d->ntaps >= 1 && d->ntaps <= VT_MAX_TAPS && d->Cin % epc == 0 &&
+        d->Cout % epc == 0 && d->ldx % epc == 0 && d->ldy % epc == 0 && d->ldw % epc == 0 && d->ldx >= d->Cin &&
+        d->ldy >= d->Cout && d->ldw >= d->ntaps * d->Cin && vt_aligned16(dz) && vt_aligned16(w) && vt_aligned16(dy) &&
+        (long)d->B * d->Hi * d->Wi * d->ldx < 0x7fffffffL && M * d->ldy < 0x7fffffffL && M * ldz < 0x7fffffffL) {
+        IgemmArgs a;
+        fill_args(a, d, dz, w, dy, scale, shift, z, sums);
+        a.ldr = ldz;
+        a.aux0 = mean, a.aux1 = invstd;
+        a.flags = VT_CONV_BNRED | (relu ? VT_CONV_RELU : 0);
+        const int rc = vt_span6_dispatch(a, d->dtype, stream);
+        if (rc >= 0) return rc;
+    }
+    const int rc = vt_conv_igemm(d, dz, w, dy, nullptr, nullptr, nullptr, nullptr, stream);
+    if (rc != VT_OK) return rc;
+    return vt_bn_act_bwd_reduce(dy, d->ldy, z, ldz, scale, shift, mean, invstd, M, d->Cout, relu, d->dtype, sums, stream);
 }

@@ -2,6 +2,9 @@
 #pragma once
 #include "vt_common.h"
 
+// internal epilogue flag (never in a caller's vt_conv_desc.flags): the launch is vt_conv_dgrad_bnred's fused form
+#define VT_CONV_BNRED 0x1000
+
 struct IgemmArgs {
     const void* x;
     const void* w;
@@ -16,6 +19,9 @@ struct IgemmArgs {
     int fast_dma;  // span kernel: scalar-base LDS-DMA addressing on interior tiles
     int8_t dh[VT_MAX_TAPS];
     int8_t dw[VT_MAX_TAPS];
+    // VT_CONV_BNRED (vt_conv_dgrad_bnred): mean / invstd of the unit whose d(y) this launch produces
+    const float* aux0;
+    const float* aux1;
 };
 
 // element offset of output column n relative to the row's base pixel: n itself, or under VT_CONV_D2S the pixel

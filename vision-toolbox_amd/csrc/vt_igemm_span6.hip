@@ -205,7 +205,7 @@ __device__ __forceinline__ void wg_barrier() {
 //   adds them and runs the epilogue.  Half as many K-steps per launch at twice the MFMAs per tick, and every filter
 //   slice staged once per 224 rows instead of once per 112.  (One tile per workgroup by construction: the hand-over re-uses
 //   the ring and the span slots, which a loader running ahead into a next tile would still be filling.)
-template <int MODE, bool MASKED, bool KSPLIT>  // epilogue: 0 plain (+ residual), 1 BatchNorm statistics, 2 affine (+ ReLU, + residual)
+template <int MODE, bool MASKED, bool KSPLIT>  // epilogue: 0 plain (+ residual), 1 BatchNorm statistics, 2 affine (+ ReLU, + residual), 3 plain + BatchNorm-backward sums
 __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
     const IgemmArgs& p = a.p;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -365,8 +365,12 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
         // have nothing to do before the first tick (compute wave w of group g takes the pieces this loader takes for
         // group g in the loop, below): the first tick waited for ~1250 loader instructions in a row -- 6.0 us before
         // the last prologue LDS-DMA was even issued (profiles/r04_span6_phases.json) -- and now for the longer of a
-        // loader's share (slices, piece sources for the chunks that follow) and a compute wave's (one group's piece
-        // sources, seven LDS-DMAs, a quarter of a row table).  The first wait of the loop is a full one.
+        // loader's share (the slices) and a compute wave's (one group's piece sources, seven LDS-DMAs, a quarter of a row
+        // table).  The piece sources, which this loader needs for the chunks that follow, come from the compute waves too:
+        // compute wave (g, lj) parks them in the four pieces this loader owns of group g's SECOND span slot (64 lanes x
+        // 64 B; the slot is first written by this loader's own LDS-DMAs of step 0, behind the reads below), because the
+        // same ~400 instructions took a loader wave 4 us and a compute wave 1 (stamps, NOTEBOOK R6).  The first wait of
+        // the loop is a full one.
         const long S = (long)ntile * nsteps;  // steps of each group
         int m0c[2] = {VT_TILE_U0(0, 0) * 32, VT_TILE_U0(1, 0) * 32};
         int sic = 0, sT = 0;         // (chunk, tap) of the next slice to issue; slices repeat per tile
@@ -385,9 +389,6 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
         next_slice();
         next_slice();
         VT_S6_PSTAMP(0);
-        tile_bases(m0c[0], ab_cur[0], vm_cur[0]);
-        tile_bases(m0c[1], ab_cur[1], vm_cur[1]);
-        VT_S6_PSTAMP(1);
         if (lj == 0 && lane < 4) ((unsigned*)(smem + L6::kZ))[lane] = 0u;  // the fragment of a tap outside the image
         VT_S6_STAMP(1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // zero block written before barrier 0
@@ -433,6 +434,23 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                             else vmw<0>();  // (the first step: the prologue issued the slices before the spans)
                         }
                         VT_TBAR(lwait);
+                        if constexpr (T == 0) {
+                            if (sleft == S) {  // the first tick: the first tiles' piece sources, parked by the compute waves
+#pragma unroll
+                                for (int g = 0; g < 2; ++g) {
+                                    const char* st = sAb + (g * 2 + 1) * aslot_bytes + lj * 1024 + lane * 16;
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) {
+                                        const uint4 v = *(const uint4*)(st + q * 4096);
+                                        ab_cur[g][2 * q] = ((unsigned long)v.y << 32) | v.x;
+                                        if (q < 3) ab_cur[g][2 * q + 1] = ((unsigned long)v.w << 32) | v.z;
+                                        else vm_cur[g] = v.z;
+                                    }
+                                }
+                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // read before this wave's LDS-DMAs land there
+                                VT_S6_PSTAMP(1);
+                            }
+                        }
                         if constexpr (T < NTP) if (dma) {
                             const unsigned long base = nx ? ab_nxt[0][T] : ab_cur[0][T];
                             const unsigned v = ((nx ? vm_nxt[0] : vm_cur[0]) >> T) & 1u;
@@ -550,6 +568,14 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                 glds_v(ab0[T] + ((grp == 1 && ((vm0 >> T) & 1u)) ? (unsigned long)koff : 0ul));
             }
         if (wave == 0) VT_S6_PSTAMP(3);
+        {  // the piece sources for loader lj (see the loader's prologue): its four first pieces of this group's second span slot
+            char* st = smem + L6::a_off(KSPLIT) + (grp * 2 + 1) * aslot_bytes + lj * 1024 + lane * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned long lo = ab0[2 * q], hi = q < 3 ? ab0[2 * q + 1] : (unsigned long)vm0;
+                *(uint4*)(st + q * 4096) = make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32));
+            }
+        }
         row_tables(grp, 0, m0g);
         vmw<0>();  // landed before this wave's next barrier: group 0 reads the chunk in tick 0, group 1 in tick 1
         set_m0(m0_keep);
@@ -732,8 +758,17 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
             // ---- epilogue: two 16-byte stores per row fragment, straight from the accumulators ----------
             ArgsPtr Q = fresh_args();
             constexpr bool affine = MODE == 2, stats = MODE == 1;
-            const bool relu = MODE == 2 && (Q->p.flags & VT_CONV_RELU);
-            const bool has_res = MODE != 1 && (Q->p.flags & VT_CONV_RESIDUAL) != 0;
+            // MODE 3 (round 6): a data gradient that also REDUCES the BatchNorm backward of the unit whose output it
+            // differentiates -- this launch's result is that unit's d(y); the unit's stored pre-activation z arrives like a
+            // residual operand (p.res / ldr: same pixels, same channels), p.scale / p.shift are the unit's BatchNorm
+            // coefficients (the ReLU mask is z * scale + shift > 0, as in bn_bwd_reduce_kernel / bn_bwd_apply_kernel),
+            // p.aux0 / p.aux1 its mean / invstd, p.stats the unit's backward sums: [0][c] += sum g, [1][c] += invstd *
+            // sum g * (z - mean), g = mask * d(y) AS STORED (bf16).  The separate reduction pass (d(y) and z read once more:
+            // 19.5 us alone at 128 ch @28x28, ~50 us beside the filter-gradient stream) disappears.  VT_CONV_RELU: the unit
+            // has a ReLU (else the mask is all ones).
+            constexpr bool bnred = MODE == 3;
+            const bool relu = (MODE == 2 || MODE == 3) && (Q->p.flags & VT_CONV_RELU);
+            const bool has_res = MODE == 3 || (MODE != 1 && (Q->p.flags & VT_CONV_RESIDUAL) != 0);
             const int Cout_ = Q->p.Cout, ldy_ = Q->p.ldy, ldr_ = Q->p.ldr;
             bf16_t* __restrict__ yg = (bf16_t*)Q->p.y;
             const bf16_t* __restrict__ rg = (const bf16_t*)Q->p.res;
@@ -750,13 +785,14 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                 float s1[8], s2[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s1[e] = 0.f, s2[e] = 0.f;
-                float sc[8], sf[8];
-                if (affine) {
+                float sc[8], sf[8], mu[8];
+                if (affine || bnred) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int ne = min(n + e, Cout_ - 1);
                         sc[e] = scale_ ? scale_[ne] : 1.f;
                         sf[e] = shift_[ne];
+                        if (bnred) mu[e] = Q->p.aux0[ne];
                     }
                 }
                 // the residual rows of this half, all in flight before the first one is used: loaded unconditionally
@@ -784,7 +820,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                     for (int e = 0; e < 8; ++e) {
                         float t = acc[i][2 * h + (e >> 2)][e & 3];
                         if (affine) t = fmaf(t, sc[e], sf[e]);
-                        if (relu) t = fmaxf(t, 0.f);
+                        if (affine && relu) t = fmaxf(t, 0.f);
                         v[e] = t;
                     }
                     uint4 out = VecIO<bf16_t>::pack(v);
@@ -798,7 +834,17 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                                 s2[e] = fmaf(r8[e], r8[e], s2[e]);
                             }
                         }
-                        if (has_res) {
+                        if (bnred) {
+                            float g8[8], z8[8];
+                            VecIO<bf16_t>::unpack(out, g8);
+                            VecIO<bf16_t>::unpack(rres[kPreRes ? i : 0], z8);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float gg = (!relu || fmaf(z8[e], sc[e], sf[e]) > 0.f) ? g8[e] : 0.f;
+                                s1[e] += gg;
+                                s2[e] = fmaf(gg, z8[e] - mu[e], s2[e]);  // invstd applied once, below
+                            }
+                        } else if (has_res) {
                             const uint4 rr = kPreRes ? rres[kPreRes ? i : 0] : *(const uint4*)(rg + (po * ldr_ + n));
                             float fv[8], fr[8];
                             VecIO<bf16_t>::unpack(out, fv);
@@ -810,7 +856,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                         *(uint4*)(yg + (po * ldy_ + n)) = out;
                     }
                 }
-                if (stats) {
+                if (stats || bnred) {
                     // sum over the 16 pixel lanes (same q4 = one DPP row): four row rotations on the vector ALU (no LDS
                     // crossbar round trips), then lanes c16 = 0..7 keep channel e = c16
                     float u = 0.f, v = 0.f;
@@ -821,6 +867,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                         v = c16 == e ? x2 : v;
                     }
                     const int nn = n + c16;
+                    if (bnred && c16 < 8 && nn < Cout_) v *= Q->p.aux1[nn];
                     if (c16 < 8 && nn < Cout_) {
                         vt_stat_add(stats_, ((long)rep * 2 + 0) * Cout_ + nn, u);
                         vt_stat_add(stats_, ((long)rep * 2 + 1) * Cout_ + nn, v);
@@ -962,12 +1009,17 @@ static int span6_run(IgemmArgs& a0, int dtype, void* stream, bool dry) {
     a.s64j = 64 % a.Wp, a.s64i = (64 / a.Wp) % a.Hp, a.s64b = (64 / a.Wp) / a.Hp;
     a.hp_magic = (unsigned)((0x100000000ull + a.Hp - 1) / a.Hp);
     a.wp_magic = (unsigned)((0x100000000ull + a.Wp - 1) / a.Wp);
-    const int mode = (p.flags & VT_CONV_STATS) ? 1 : ((p.flags & VT_CONV_AFFINE) ? 2 : 0);
+    const int mode = (p.flags & VT_CONV_BNRED) ? 3 : ((p.flags & VT_CONV_STATS) ? 1 : ((p.flags & VT_CONV_AFFINE) ? 2 : 0));
     if (mode == 1 && (p.flags & (VT_CONV_AFFINE | VT_CONV_RELU | VT_CONV_RESIDUAL))) return -1;
     if (mode == 0 && (p.flags & VT_CONV_RELU)) return -1;
-    auto kern = ksplit ? (mode == 1 ? span6_kernel<1, true, true> : (mode == 2 ? span6_kernel<2, true, true> : span6_kernel<0, true, true>))
-                : masked ? (mode == 1 ? span6_kernel<1, true, false> : (mode == 2 ? span6_kernel<2, true, false> : span6_kernel<0, true, false>))
-                         : (mode == 1 ? span6_kernel<1, false, false> : (mode == 2 ? span6_kernel<2, false, false> : span6_kernel<0, false, false>));
+    if (mode == 3 && ((p.flags & (VT_CONV_AFFINE | VT_CONV_STATS | VT_CONV_RESIDUAL | VT_CONV_D2S)) || !p.res || !p.shift || !p.aux0 ||
+                      !p.aux1 || !p.stats))
+        return -1;
+#define VT_S6_PICK(KS, MK)                                                                       \
+    (mode == 1 ? span6_kernel<1, MK, KS>                                                         \
+               : (mode == 2 ? span6_kernel<2, MK, KS> : (mode == 3 ? span6_kernel<3, MK, KS> : span6_kernel<0, MK, KS>)))
+    auto kern = ksplit ? VT_S6_PICK(true, true) : (masked ? VT_S6_PICK(false, true) : VT_S6_PICK(false, false));
+#undef VT_S6_PICK
     {
         // (in the dry run too: the only fallible step of a launch, so a caller that splits the columns over two kernels
         //  knows this half cannot fail once the other one has been issued)
@@ -1003,10 +1055,10 @@ static int span6_run(IgemmArgs& a0, int dtype, void* stream, bool dry) {
             {
                 static unsigned long long hp[512 * 16];
                 (void)hipMemcpyFromSymbol(hp, HIP_SYMBOL(vt_span6_pstamps), sizeof(hp));
-                double pa[5] = {0};
+                double pa[6] = {0};
                 for (int b = 0; b < nb; ++b)
-                    for (int k = 0; k < 5; ++k) pa[k] += (double)(hp[b * 16 + k] - t0) * 0.01 / nb;
-                fprintf(stderr, "[span6 prologue stamps, us from the first workgroup's start, mean over %d WGs] loader: slices issued %.2f piece sources done %.2f | "
+                    for (int k = 0; k < 6; ++k) pa[k] += (double)(hp[b * 16 + k] - t0) * 0.01 / nb;
+                fprintf(stderr, "[span6 prologue stamps, us from the first workgroup's start, mean over %d WGs] loader: slices issued %.2f piece sources read back (tick 0) %.2f | "
                                 "compute wave 0: piece sources done %.2f pieces issued %.2f landed + row table %.2f\n", nb, pa[0], pa[1], pa[2], pa[3], pa[4]);
             }
             fprintf(stderr, "[span6 stamps] start times (us), sorted, every 32nd WG:");
@@ -1027,7 +1079,7 @@ int vt_span6_dispatch(IgemmArgs& a0, int dtype, void* stream) {
     // 64 remaining columns (192 @14x14: 60 us whole, 42 + 32 split).  VT_SPAN6_SPLIT=0: never.
     const int rem = a0.Cout % 128;
     const int split = VT_KNOB("VT_SPAN6_SPLIT", 1);
-    if (split && a0.Cout > 128 && rem == 32 && dtype == VT_BF16 && !(a0.flags & (VT_CONV_STATS | VT_CONV_D2S | VT_CONV_NOSTORE))) {
+    if (split && a0.Cout > 128 && rem == 32 && dtype == VT_BF16 && !(a0.flags & (VT_CONV_STATS | VT_CONV_D2S | VT_CONV_NOSTORE | VT_CONV_BNRED))) {
         const int head = a0.Cout - rem;
         IgemmArgs a1 = a0;
         a1.Cout = head;

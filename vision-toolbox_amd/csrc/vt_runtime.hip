@@ -133,6 +133,12 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
             return vt_conv_igemm(&d, P[0], P[1], P[2], (const float*)P[3], (const float*)P[4], P[5],
                                  (float*)P[6], st);
         }
+        case VT_OP_CONV_DGRAD_BNRED: {  // ptr: dz w dy z scale shift mean invstd sums | i: vt_conv_desc image, then ldz, relu
+            vt_conv_desc d;
+            memcpy(&d, I, sizeof(d));
+            return vt_conv_dgrad_bnred(&d, P[0], P[1], P[2], P[3], I[sizeof(d) / 4], (const float*)P[4], (const float*)P[5],
+                                       (const float*)P[6], (const float*)P[7], I[sizeof(d) / 4 + 1], (float*)P[8], st);
+        }
         case VT_OP_CONV_WGRAD: {  // ptr: x dz dw [scratch] | i: vt_conv_desc image, then ldgw, scratch MiB
             vt_conv_desc d;
             memcpy(&d, I, sizeof(d));
@@ -283,7 +289,7 @@ struct Graph {
 
 extern "C" {
 
-int vt_version(void) { return 103; }  // 103: round 6 (vt_debug_hog left the library: tools/diag/vt_diag_hog.hip)
+int vt_version(void) { return 103; }  // 103: round 6 (vt_conv_dgrad_bnred; vt_debug_hog left the library: tools/diag/vt_diag_hog.hip)
 int vt_set_knob(const char* name, int32_t value) {
     VT_REQUIRE(name && strlen(name) < 48, VT_ERR_INVALID, "vt_set_knob: bad name");
     // (a knob set before its first use overrides the environment: the slot exists from here on)

@@ -92,7 +92,8 @@ VT_OP_MAX_PTR, VT_OP_MAX_INT, VT_OP_MAX_FLT, VT_MAX_BASES = 16, 110, 8, 16
     OP_ALLREDUCE,
     OP_STAT_SYNC,
     OP_XENT_EVAL,
-) = range(1, 40)
+    OP_CONV_DGRAD_BNRED,
+) = range(1, 41)
 OP_SIDE_STREAM = 0x10000  # OR-ed into Op.kind: enqueue on the side stream
 
 OP_NAMES = {
@@ -115,6 +116,7 @@ OP_NAMES = {
     OP_COLSUM: "colsum",
     OP_XENT: "xent",
     OP_XENT_EVAL: "xent_eval",
+    OP_CONV_DGRAD_BNRED: "conv_dgrad_bnred",
     OP_SGD: "sgd",
     OP_COPY2D: "copy2d",
     OP_NCHW_TO_NHWC: "nchw_to_nhwc",
@@ -206,6 +208,7 @@ SYMBOLS = {
     "vt_set_knob": (_i32, [C.c_char_p, _i32]),
     "vt_memset": (_i32, [_vp, _i32, _u64, _vp]),
     "vt_conv_igemm": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vt_conv_dgrad_bnred": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "vt_conv_wgrad": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i32, _vp]),
     "vt_pack_dgrad_filter_batch": (_i32, [_vp, _i32, _vp]),
     "vt_bn_eval_coeffs_batch": (_i32, [_vp, _i32, _vp]),

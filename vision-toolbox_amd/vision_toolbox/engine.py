@@ -295,6 +295,13 @@ class Builder:
         # ... on the side stream (0) or in line on the main stream (1): the CU-owning kernel shares nothing with the
         # kernels beside it (12 waves x 168 registers, 104 KiB of LDS), so the side stream buys it no overlap
         self.wgrad_inline = os.environ.get("VT_WGRAD_INLINE", "0") != "0"
+        # Round 6: a 3x3 stride-1 data gradient that is the ONLY contribution to the gradient of a ConvNormAct unit's
+        # output also reduces that unit's BatchNorm backward (vt_conv_dgrad_bnred): the separate reduction pass over
+        # d(y) and z disappears (DarknetBlock.conv1 <- conv2, darknet.py:23-28: 23 units of CSPDarknet-53).  The last
+        # whole-tensor data-gradient op per gradient buffer is remembered here; any other writer forgets it.
+        # VT_FUSE_BNRED=0: the separate passes everywhere.
+        self.fuse_bnred = os.environ.get("VT_FUSE_BNRED", "1") != "0"
+        self._last_dgrad: dict[int, tuple] = {}  # id(gradient Buf) -> (op, c0, c1)
         self._wg_expect: dict[tuple, int] = {}   # shape key -> units seen in forward and not yet released
         self._wg_pending: dict[tuple, list] = {}  # shape key -> [(x addr, dz addr, dw addr, desc, ldw)]
         # SyncBatchNorm (configs/base.yaml:22): the trainer all-reduces every layer's statistics
@@ -411,6 +418,7 @@ class Builder:
 
     def _add_into(self, dst: TRef, src: TRef, accumulate: bool):
         """dst (=|+=) src, elementwise (vt_bn_act_apply with unit scale)."""
+        self._last_dgrad.pop(id(dst.buf), None)
         self.emit(N.OP_BN_ACT_APPLY,
                   [src.addr(), None, None, dst.addr() if accumulate else None, dst.addr()],
                   [src.ld, dst.ld, dst.ld, dst.C, 0, self.dtype], [dst.M])
@@ -455,6 +463,7 @@ class Builder:
         gs = self._gs(t)
         c0, c1 = t.coff, t.coff + t.C
         g = self._gref(t)
+        self._last_dgrad.pop(id(g.buf), None)  # (a writer is coming: whatever wrote the buffer last is no longer the only one)
         if gs.covered(c0, c1):
             self._flush_pending(t)
             return g, g
@@ -494,6 +503,7 @@ class Builder:
             # zero-fill the gaps (only dense full-width buffers can be memset)
             if t.ld == t.C and not gs.touches(c0, c1):
                 g = self._gref(t)
+                self._last_dgrad.pop(id(g.buf), None)
                 self.emit(N.OP_MEMSET, [g.addr()], [0], [t.M * t.C * t.esize])
                 gs.init.append((c0, c1))
             else:
@@ -770,9 +780,22 @@ class Builder:
                     g_ = pool_grad if pool_grad is not None else dy
                     am_ = [self.bp(pool_am)] if pool_grad is not None else []
                     geo = [B, Ho, Wo] if pool_grad is not None else []
-                    self.emit(N.OP_BN_BWD_REDUCE,
-                              [g_.addr(), z.addr(), cp[0], cp[1], cp[2], cp[3], self.bp(sums)] + am_,
-                              [g_.ld, z.ld, Cout, int(relu), dt] + geo, [M])
+                    rec = self._last_dgrad.get(id(dy.buf)) if (self.fuse_bnred and pool_grad is None and dt == N.VT_BF16 and
+                                                                not generic_act and self._cur is self.bwd) else None
+                    if rec is not None and rec[1] == dy.coff and rec[2] == dy.coff + dy.C and any(o is rec[0] for o in self.bwd):
+                        # d(y) came out of ONE data-gradient launch and nothing was added to it since: that launch also forms
+                        # this unit's backward sums (the op is patched in place: ptr dz w dy | z scale shift mean invstd sums)
+                        fop = rec[0]
+                        fop.kind = N.OP_CONV_DGRAD_BNRED | (fop.kind & N.OP_SIDE_STREAM)
+                        for k_, pa in ((3, z.addr()), (4, cp[0]), (5, cp[1]), (6, cp[2]), (7, cp[3]), (8, self.bp(sums))):
+                            fop.ptr[k_].base, fop.ptr[k_].offset = pa
+                        k0 = C.sizeof(N.ConvDesc) // 4
+                        fop.i[k0], fop.i[k0 + 1] = z.ld, int(relu)
+                        self._last_dgrad.pop(id(dy.buf), None)
+                    else:
+                        self.emit(N.OP_BN_BWD_REDUCE,
+                                  [g_.addr(), z.addr(), cp[0], cp[1], cp[2], cp[3], self.bp(sums)] + am_,
+                                  [g_.ld, z.ld, Cout, int(relu), dt] + geo, [M])
                     bcoef = self.f32(3 * Cout, "bwdcoef")
                     self.emit(N.OP_BN_BWD_FINALIZE,
                               [self.bp(sums), cp[0], cp[2], cp[3], self.pgrad(norm.weight), self.pgrad(norm.bias),
@@ -1133,8 +1156,10 @@ class Builder:
                 d.ntaps = nsel
                 for i, (a, b) in enumerate(offs):
                     d.dh[i], d.dw[i] = a, b
-                self.emit(N.OP_CONV_IGEMM, [dz.addr(), self.bp(wd), gx.addr(), None, None,
-                                            res.addr() if res is not None else None, None], desc=d)
+                op = self.emit(N.OP_CONV_IGEMM, [dz.addr(), self.bp(wd), gx.addr(), None, None,
+                                                 res.addr() if res is not None else None, None], desc=d)
+                if s == 1 and res is None and Hc == x.H and Wc == x.W and self._cur is self.bwd:
+                    self._last_dgrad[id(gx.buf)] = (op, gx.coff, gx.coff + gx.C)  # this launch alone forms d(x)
         self.grad_written(x)
 
     def copy(self, x: TRef, dst: TRef) -> TRef:
