@@ -178,7 +178,8 @@ def test_cspdarknet53_program_structure():
     assert h["copy2d"] == 2
     # forward convs + one data-gradient launch per conv; the 5 stride-2 convs take 4 parity-class launches, except the
     # two HBM-bound ones (32 -> 64 and 64 -> 128 channels), whose classes are the column blocks of one depth-to-space launch
-    assert h["conv_igemm"] == (67 - pw_units) + 1 + (66 - 5 - pw_units) + 3 * 4 + 2
+    # (12 of the data-gradient launches are the fused form counted above)
+    assert h["conv_igemm"] + h["conv_dgrad_bnred"] == (67 - pw_units) + 1 + (66 - 5 - pw_units) + 3 * 4 + 2
     assert "maxpool_fwd" not in h
 
 

@@ -88,6 +88,19 @@ def main():
                 ctypes.byref(d), x.data_ptr(), w.data_ptr(), y.data_ptr(), sc.data_ptr() if aff else None,
                 sf.data_ptr() if aff else None, resid.data_ptr() if res else None, None if (aff or res) else stats.data_ptr(), st)))
             line += f" | fwd {ms:7.4f} ms {flops / ms / 1e9:7.1f} TF/s [{N.last_kernel_name()}]"
+        if what == "bnred":  # vt_conv_dgrad_bnred against the two launches it replaces (flags 0 launch + the reduction pass)
+            d0, _ = desc_for(B, Cin, Cout, k, s, H, 0)
+            z = (torch.randn(B, Ho, Ho, Cout, device="cuda") + 0.2).to(torch.bfloat16)
+            mean, istd = torch.randn(Cout, device="cuda") * 0.1 + 0.2, torch.rand(Cout, device="cuda") + 0.5
+            sums = N.stats_buffer(Cout)
+            vp_ = lambda t: ctypes.c_void_p(t.data_ptr())
+            ms_f = timeit(lambda st: N.check(lib.vt_conv_dgrad_bnred(ctypes.byref(d0), vp_(x), vp_(w), vp_(y), vp_(z), Cout, vp_(sc), vp_(sf),
+                                                                     vp_(mean), vp_(istd), 1, vp_(sums), st)))
+            name = N.last_kernel_name()
+            ms_c = timeit(lambda st: N.check(lib.vt_conv_igemm(ctypes.byref(d0), vp_(x), vp_(w), vp_(y), None, None, None, None, st)))
+            ms_r = timeit(lambda st: N.check(lib.vt_bn_act_bwd_reduce(vp_(y), Cout, vp_(z), Cout, vp_(sc), vp_(sf), vp_(mean), vp_(istd),
+                                                                      B * Ho * Ho, Cout, 1, N.VT_BF16, vp_(sums), st)))
+            line += f" | fused {ms_f * 1e3:7.1f} us [{name}] | plain {ms_c * 1e3:7.1f} us + reduce {ms_r * 1e3:6.1f} us"
         if what in ("wgrad", "all"):
             d0, _ = desc_for(B, Cin, Cout, k, s, H, 0)
             ms = timeit(lambda st: N.check(lib.vt_conv_wgrad(ctypes.byref(d0), x.data_ptr(), dz.data_ptr(),

@@ -241,6 +241,10 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
 #define VT_TILE_U0(g, k) (VT_G_U0(g) + (k) * (VT_G_NUN(g) / ntile) + min((k), VT_G_NUN(g) % ntile))
 #define VT_TILE_F(g, k) (VT_G_NUN(g) / ntile + ((k) < VT_G_NUN(g) % ntile ? 1 : 0))
 
+    // Who issues the FIRST chunk's span pieces: the compute waves (padded coordinates) or the loaders (pixel rows: their
+    // piece sources cost no division, and a compute wave still has its tap masks to build before the first tick -- the
+    // compute-wave form measured 1.3 us (256 -> 256 @14x14) to 6 us (K-split 512 -> 512 @7x7) SLOWER there).
+    constexpr bool kCwPro = !MASKED;
     // ---- address arithmetic shared by the loader waves and, in the prologue only, the compute waves ----------------
     const int lj = wave & 3;  // loader index (waves 8..11) / the quarter of the prologue's work a compute wave takes
     const char* xg = (const char*)p.x;
@@ -389,6 +393,20 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
         next_slice();
         next_slice();
         VT_S6_PSTAMP(0);
+        if constexpr (!kCwPro) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                tile_bases(m0c[g], ab_cur[g], vm_cur[g]);
+#pragma unroll
+                for (int T = 0; T < 7; ++T)
+                    if (lj + 4 * T < a.npc) {
+                        set_m0(a_base + (unsigned)((g * 2) * aslot_bytes + (lj + 4 * T) * 1024));
+                        glds_v(ab_cur[g][T] + ((g == 1 && ((vm_cur[g] >> T) & 1u)) ? (unsigned long)koff : 0ul));
+                    }
+            }
+            row_tables(0, 0, m0c[0]);
+            row_tables(1, 0, m0c[1]);
+        }
         if (lj == 0 && lane < 4) ((unsigned*)(smem + L6::kZ))[lane] = 0u;  // the fragment of a tap outside the image
         VT_S6_STAMP(1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // zero block written before barrier 0
@@ -434,7 +452,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                             else vmw<0>();  // (the first step: the prologue issued the slices before the spans)
                         }
                         VT_TBAR(lwait);
-                        if constexpr (T == 0) {
+                        if constexpr (T == 0 && kCwPro) {
                             if (sleft == S) {  // the first tick: the first tiles' piece sources, parked by the compute waves
 #pragma unroll
                                 for (int g = 0; g < 2; ++g) {
@@ -554,7 +572,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
     int bcur = 0, acur = 0;
     unsigned long long cwait = 0, cR = 0, cM = 0;
 
-    {
+    if constexpr (kCwPro) {
         // ---- prologue (round 6): this wave's share of its group's first span chunk and first row table -------------
         const int m0g = VT_TILE_U0(grp, 0) * 32;
         unsigned long ab0[7];
@@ -768,7 +786,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
             // has a ReLU (else the mask is all ones).
             constexpr bool bnred = MODE == 3;
             const bool relu = (MODE == 2 || MODE == 3) && (Q->p.flags & VT_CONV_RELU);
-            const bool has_res = MODE == 3 || (MODE != 1 && (Q->p.flags & VT_CONV_RESIDUAL) != 0);
+            const bool has_res = MODE != 3 && MODE != 1 && (Q->p.flags & VT_CONV_RESIDUAL) != 0;
             const int Cout_ = Q->p.Cout, ldy_ = Q->p.ldy, ldr_ = Q->p.ldr;
             bf16_t* __restrict__ yg = (bf16_t*)Q->p.y;
             const bf16_t* __restrict__ rg = (const bf16_t*)Q->p.res;
@@ -776,6 +794,77 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
             const float* shift_ = Q->p.shift;
             float* stats_ = Q->p.stats;
             const int rep = (int)((m0_cur / 32) % kStatReplicas);
+            if constexpr (bnred) {
+                // Register-lean form (the accumulators fill the file): per half h the two channel QUADS of a lane one
+                // after the other -- z as 8-byte loads (FM rows in flight), scale / shift and the two running sums for four
+                // channels; quad 0's packed results wait for quad 1's so that a row still leaves as ONE 16-byte store.
+                // sum g * (z - mean) is formed as sum g * z - mean * sum g on the wave's partial sums (<= 16 FM rows: the
+                // cancellation costs ~|mean| / std of an f32 rounding), then scaled by invstd and added in fixed point.
+                const float* mean_ = Q->p.aux0;
+                const float* istd_ = Q->p.aux1;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    int n = ch0 + h * 32;
+                    asm volatile("" : "+v"(n));
+                    uint2 pk0[FM];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int nq = n + 4 * q;
+                        float sc[4], sf[4], s1[4], s2[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int ne = min(nq + e, Cout_ - 1);
+                            sc[e] = scale_[ne], sf[e] = shift_[ne];
+                            s1[e] = 0.f, s2[e] = 0.f;
+                        }
+                        uint2 zr[FM];
+#pragma unroll
+                        for (int i = 0; i < FM; ++i) {
+                            const int tr = wrow + i * 16;
+                            const long po = sPo[tbl + tr];
+                            const bool ok = tr < rows_tile && po >= 0 && n < Cout_;
+                            zr[i] = *(const uint2*)(rg + (ok ? po * ldr_ + nq : 0l));
+                        }
+#pragma unroll
+                        for (int i = 0; i < FM; ++i) {
+                            const int tr = wrow + i * 16;
+                            const long po = sPo[tbl + tr];
+                            const bool row_ok = tr < rows_tile && po >= 0 && n < Cout_;
+                            const f32x4 av = acc[i][2 * h + q];
+                            uint2 pk;
+                            pk.x = VecIO<bf16_t>::pack2(av[0], av[1]);
+                            pk.y = VecIO<bf16_t>::pack2(av[2], av[3]);
+                            if (row_ok) {
+                                const float g4[4] = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
+                                                     __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u)};
+                                const float z4[4] = {__uint_as_float(zr[i].x << 16), __uint_as_float(zr[i].x & 0xffff0000u),
+                                                     __uint_as_float(zr[i].y << 16), __uint_as_float(zr[i].y & 0xffff0000u)};
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float gg = (!relu || fmaf(z4[e], sc[e], sf[e]) > 0.f) ? g4[e] : 0.f;
+                                    s1[e] += gg;
+                                    s2[e] = fmaf(gg, z4[e], s2[e]);
+                                }
+                                if (q == 1) *(uint4*)(yg + (po * ldy_ + n)) = make_uint4(pk0[i].x, pk0[i].y, pk.x, pk.y);
+                            }
+                            if (q == 0) pk0[i] = pk;
+                        }
+                        float u = 0.f, v = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float x1 = row_sum16(s1[e]), x2 = row_sum16(s2[e]);
+                            u = c16 == e ? x1 : u;
+                            v = c16 == e ? x2 : v;
+                        }
+                        const int nn = nq + c16;
+                        if (c16 < 4 && nn < Cout_) {
+                            v = (v - mean_[nn] * u) * istd_[nn];
+                            vt_stat_add(stats_, ((long)rep * 2 + 0) * Cout_ + nn, u);
+                            vt_stat_add(stats_, ((long)rep * 2 + 1) * Cout_ + nn, v);
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 // (opaque: keeps the per-lane 64-bit output / statistics addresses from being hoisted out of the tile
@@ -785,14 +874,13 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                 float s1[8], s2[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s1[e] = 0.f, s2[e] = 0.f;
-                float sc[8], sf[8], mu[8];
-                if (affine || bnred) {
+                float sc[8], sf[8];
+                if (affine) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int ne = min(n + e, Cout_ - 1);
                         sc[e] = scale_ ? scale_[ne] : 1.f;
                         sf[e] = shift_[ne];
-                        if (bnred) mu[e] = Q->p.aux0[ne];
                     }
                 }
                 // the residual rows of this half, all in flight before the first one is used: loaded unconditionally
@@ -834,17 +922,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                                 s2[e] = fmaf(r8[e], r8[e], s2[e]);
                             }
                         }
-                        if (bnred) {
-                            float g8[8], z8[8];
-                            VecIO<bf16_t>::unpack(out, g8);
-                            VecIO<bf16_t>::unpack(rres[kPreRes ? i : 0], z8);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                const float gg = (!relu || fmaf(z8[e], sc[e], sf[e]) > 0.f) ? g8[e] : 0.f;
-                                s1[e] += gg;
-                                s2[e] = fmaf(gg, z8[e] - mu[e], s2[e]);  // invstd applied once, below
-                            }
-                        } else if (has_res) {
+                        if (has_res) {
                             const uint4 rr = kPreRes ? rres[kPreRes ? i : 0] : *(const uint4*)(rg + (po * ldr_ + n));
                             float fv[8], fr[8];
                             VecIO<bf16_t>::unpack(out, fv);
@@ -856,7 +934,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                         *(uint4*)(yg + (po * ldy_ + n)) = out;
                     }
                 }
-                if (stats || bnred) {
+                if (stats) {
                     // sum over the 16 pixel lanes (same q4 = one DPP row): four row rotations on the vector ALU (no LDS
                     // crossbar round trips), then lanes c16 = 0..7 keep channel e = c16
                     float u = 0.f, v = 0.f;
@@ -867,7 +945,6 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                         v = c16 == e ? x2 : v;
                     }
                     const int nn = n + c16;
-                    if (bnred && c16 < 8 && nn < Cout_) v *= Q->p.aux1[nn];
                     if (c16 < 8 && nn < Cout_) {
                         vt_stat_add(stats_, ((long)rep * 2 + 0) * Cout_ + nn, u);
                         vt_stat_add(stats_, ((long)rep * 2 + 1) * Cout_ + nn, v);
