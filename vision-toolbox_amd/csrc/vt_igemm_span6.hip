@@ -795,73 +795,76 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
             float* stats_ = Q->p.stats;
             const int rep = (int)((m0_cur / 32) % kStatReplicas);
             if constexpr (bnred) {
-                // Register-lean form (the accumulators fill the file): per half h the two channel QUADS of a lane one
-                // after the other -- z as 8-byte loads (FM rows in flight), scale / shift and the two running sums for four
-                // channels; quad 0's packed results wait for quad 1's so that a row still leaves as ONE 16-byte store.
-                // sum g * (z - mean) is formed as sum g * z - mean * sum g on the wave's partial sums (<= 16 FM rows: the
-                // cancellation costs ~|mean| / std of an f32 rounding), then scaled by invstd and added in fixed point.
+                // Register-lean form (the accumulators fill the file): the four channel QUADS of a lane (half h, quad q)
+                // one after the other -- z as 8-byte loads, the NEXT quad's FM rows in flight while this one is consumed (a
+                // quad's loads cost a round trip to HBM: with one buffer the epilogue was four of them in a row, 12 us per
+                // tile); scale / shift and the two running sums for four channels; 8-byte stores (the two quads of a half
+                // meet again in the L2 line).  sum g * (z - mean) is formed as sum g * z - mean * sum g on the wave's
+                // partial sums (<= 16 FM rows: the cancellation costs ~|mean| / std of an f32 rounding), then scaled by
+                // invstd and added in fixed point.
                 const float* mean_ = Q->p.aux0;
                 const float* istd_ = Q->p.aux1;
+                uint2 zr[2][FM];
+                auto load_quad = [&](int b, uint2 (&dst)[FM]) {
+                    int nq = ch0 + (b >> 1) * 32 + (b & 1) * 4;
+                    asm volatile("" : "+v"(nq));
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    int n = ch0 + h * 32;
-                    asm volatile("" : "+v"(n));
-                    uint2 pk0[FM];
+                    for (int i = 0; i < FM; ++i) {
+                        const int tr = wrow + i * 16;
+                        const long po = sPo[tbl + tr];
+                        const bool ok = tr < rows_tile && po >= 0 && nq < Cout_;
+                        dst[i] = *(const uint2*)(rg + (ok ? po * ldr_ + nq : 0l));
+                    }
+                };
+                load_quad(0, zr[0]);
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int nq = n + 4 * q;
-                        float sc[4], sf[4], s1[4], s2[4];
+                for (int b = 0; b < 4; ++b) {
+                    if (b + 1 < 4) load_quad(b + 1, zr[(b + 1) & 1]);
+                    int nq = ch0 + (b >> 1) * 32 + (b & 1) * 4;
+                    asm volatile("" : "+v"(nq));
+                    float sc[4], sf[4], s1[4], s2[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int ne = min(nq + e, Cout_ - 1);
-                            sc[e] = scale_[ne], sf[e] = shift_[ne];
-                            s1[e] = 0.f, s2[e] = 0.f;
-                        }
-                        uint2 zr[FM];
+                    for (int e = 0; e < 4; ++e) {
+                        const int ne = min(nq + e, Cout_ - 1);
+                        sc[e] = scale_[ne], sf[e] = shift_[ne];
+                        s1[e] = 0.f, s2[e] = 0.f;
+                    }
 #pragma unroll
-                        for (int i = 0; i < FM; ++i) {
-                            const int tr = wrow + i * 16;
-                            const long po = sPo[tbl + tr];
-                            const bool ok = tr < rows_tile && po >= 0 && n < Cout_;
-                            zr[i] = *(const uint2*)(rg + (ok ? po * ldr_ + nq : 0l));
-                        }
+                    for (int i = 0; i < FM; ++i) {
+                        const int tr = wrow + i * 16;
+                        const long po = sPo[tbl + tr];
+                        const bool row_ok = tr < rows_tile && po >= 0 && nq < Cout_;
+                        const f32x4 av = acc[i][b];
+                        uint2 pk;
+                        pk.x = VecIO<bf16_t>::pack2(av[0], av[1]);
+                        pk.y = VecIO<bf16_t>::pack2(av[2], av[3]);
+                        if (row_ok) {
+                            const uint2 zz = zr[b & 1][i];
+                            const float g4[4] = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
+                                                 __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u)};
+                            const float z4[4] = {__uint_as_float(zz.x << 16), __uint_as_float(zz.x & 0xffff0000u),
+                                                 __uint_as_float(zz.y << 16), __uint_as_float(zz.y & 0xffff0000u)};
 #pragma unroll
-                        for (int i = 0; i < FM; ++i) {
-                            const int tr = wrow + i * 16;
-                            const long po = sPo[tbl + tr];
-                            const bool row_ok = tr < rows_tile && po >= 0 && n < Cout_;
-                            const f32x4 av = acc[i][2 * h + q];
-                            uint2 pk;
-                            pk.x = VecIO<bf16_t>::pack2(av[0], av[1]);
-                            pk.y = VecIO<bf16_t>::pack2(av[2], av[3]);
-                            if (row_ok) {
-                                const float g4[4] = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
-                                                     __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u)};
-                                const float z4[4] = {__uint_as_float(zr[i].x << 16), __uint_as_float(zr[i].x & 0xffff0000u),
-                                                     __uint_as_float(zr[i].y << 16), __uint_as_float(zr[i].y & 0xffff0000u)};
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const float gg = (!relu || fmaf(z4[e], sc[e], sf[e]) > 0.f) ? g4[e] : 0.f;
-                                    s1[e] += gg;
-                                    s2[e] = fmaf(gg, z4[e], s2[e]);
-                                }
-                                if (q == 1) *(uint4*)(yg + (po * ldy_ + n)) = make_uint4(pk0[i].x, pk0[i].y, pk.x, pk.y);
+                            for (int e = 0; e < 4; ++e) {
+                                const float gg = (!relu || fmaf(z4[e], sc[e], sf[e]) > 0.f) ? g4[e] : 0.f;
+                                s1[e] += gg;
+                                s2[e] = fmaf(gg, z4[e], s2[e]);
                             }
-                            if (q == 0) pk0[i] = pk;
+                            *(uint2*)(yg + (po * ldy_ + nq)) = pk;
                         }
-                        float u = 0.f, v = 0.f;
+                    }
+                    float u = 0.f, v = 0.f;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float x1 = row_sum16(s1[e]), x2 = row_sum16(s2[e]);
-                            u = c16 == e ? x1 : u;
-                            v = c16 == e ? x2 : v;
-                        }
-                        const int nn = nq + c16;
-                        if (c16 < 4 && nn < Cout_) {
-                            v = (v - mean_[nn] * u) * istd_[nn];
-                            vt_stat_add(stats_, ((long)rep * 2 + 0) * Cout_ + nn, u);
-                            vt_stat_add(stats_, ((long)rep * 2 + 1) * Cout_ + nn, v);
-                        }
+                    for (int e = 0; e < 4; ++e) {
+                        const float x1 = row_sum16(s1[e]), x2 = row_sum16(s2[e]);
+                        u = c16 == e ? x1 : u;
+                        v = c16 == e ? x2 : v;
+                    }
+                    const int nn = nq + c16;
+                    if (c16 < 4 && nn < Cout_) {
+                        v = (v - mean_[nn] * u) * istd_[nn];
+                        vt_stat_add(stats_, ((long)rep * 2 + 0) * Cout_ + nn, u);
+                        vt_stat_add(stats_, ((long)rep * 2 + 1) * Cout_ + nn, v);
                     }
                 }
             } else
