@@ -227,6 +227,21 @@ int vt_bn_act_bwd_apply(const void* dy, int32_t lddy, const void* z, int32_t ldz
                         void* dz, int32_t lddz, int64_t M, int32_t C, int32_t relu,
                         int32_t dtype, void* stream);
 
+/* The three calls above in ONE launch where the operands fit the register file (round 6, vt_bn_bwd_fused.hip): every
+ * thread keeps its rows of dy and z packed in registers between the reduction and the apply pass, two device-scope grid
+ * barriers (at most one workgroup per CU: all resident) separate reduce | finalize | apply -- dy and z are read once instead
+ * of twice and two launches disappear.  bf16, activation code 0 / 1, C <= 4096, up to 13 x 16 bytes per thread and tensor
+ * (256 channels @14x14 and smaller at batch 256); any other call runs vt_bn_act_bwd_reduce, vt_bn_bwd_finalize and
+ * vt_bn_act_bwd_apply, with identical arguments and results that differ by the order of the f32 partial sums only.
+ * `sums`: a zeroed statistics buffer; `sync`: 16 zeroed bytes (two barrier counters, one error flag).  A barrier that does not
+ * complete within ~4 ms of wall clock gives up (no hang) and is counted: vt_bn_bwd_fused_timeouts must read 0.
+ * Replaces the autograd backward of nn.BatchNorm2d + nn.ReLU (components.py:36-44). */
+int vt_bn_act_bwd_fused(const void* dy, int32_t lddy, const void* z, int32_t ldz, const float* scale, const float* shift,
+                        const float* mean, const float* invstd, int64_t M, int32_t C, int32_t relu, int32_t dtype,
+                        double count, double pscale, int32_t train, float* sums, void* sync, float* dgamma, float* dbeta,
+                        float* coef, void* dz, int32_t lddz, void* stream);
+int vt_bn_bwd_fused_timeouts(uint32_t* count);
+
 /* Backward of the stem unit Conv3x3(3 -> C, s1, pad 1) -> BatchNorm2d -> ReLU in one streaming pass
  * (darknet.py:75 `ConvNormAct(3, 32, 3, 1)`; autograd backward of components.py:26-44 with respect to the
  * conv weight and the BatchNorm parameters -- the unit's input is the image, no data gradient exists).
@@ -464,6 +479,7 @@ enum vt_op_kind {
     VT_OP_STAT_SYNC,        /* vt_stat_sync (one BatchNorm layer's sums over all ranks) */
     VT_OP_XENT_EVAL,        /* vt_softmax_xent_eval (validation: loss sum, top-1 hits, rows) */
     VT_OP_CONV_DGRAD_BNRED, /* vt_conv_dgrad_bnred (a data gradient + the BatchNorm-backward sums of the producing unit) */
+    VT_OP_BN_BWD_FUSED,     /* vt_bn_act_bwd_fused (BatchNorm backward of a unit: reduce, finalize, apply in one launch) */
     VT_OP_KIND_END
 };
 

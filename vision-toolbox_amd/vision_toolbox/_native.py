@@ -93,7 +93,8 @@ VT_OP_MAX_PTR, VT_OP_MAX_INT, VT_OP_MAX_FLT, VT_MAX_BASES = 16, 110, 8, 16
     OP_STAT_SYNC,
     OP_XENT_EVAL,
     OP_CONV_DGRAD_BNRED,
-) = range(1, 41)
+    OP_BN_BWD_FUSED,
+) = range(1, 42)
 OP_SIDE_STREAM = 0x10000  # OR-ed into Op.kind: enqueue on the side stream
 
 OP_NAMES = {
@@ -117,6 +118,7 @@ OP_NAMES = {
     OP_XENT: "xent",
     OP_XENT_EVAL: "xent_eval",
     OP_CONV_DGRAD_BNRED: "conv_dgrad_bnred",
+    OP_BN_BWD_FUSED: "bn_bwd_fused",
     OP_SGD: "sgd",
     OP_COPY2D: "copy2d",
     OP_NCHW_TO_NHWC: "nchw_to_nhwc",
@@ -210,6 +212,9 @@ SYMBOLS = {
     "vt_conv_igemm": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vt_conv_dgrad_bnred": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "vt_conv_wgrad": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i32, _vp]),
+    "vt_bn_act_bwd_fused": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, C.c_int64, _i32, _i32, _i32, _f64, _f64, _i32, _vp, _vp,
+                                   _vp, _vp, _vp, _vp, _i32, _vp]),
+    "vt_bn_bwd_fused_timeouts": (_i32, [C.POINTER(C.c_uint32)]),
     "vt_pack_dgrad_filter_batch": (_i32, [_vp, _i32, _vp]),
     "vt_bn_eval_coeffs_batch": (_i32, [_vp, _i32, _vp]),
     "vt_pack_dgrad_filter": (_i32, [_vp, _i32, _i32, _vp, _i32, C.POINTER(_i32), _i32, _i32, _i32, _i32, _vp]),

@@ -300,7 +300,13 @@ class Builder:
         # d(y) and z disappears (DarknetBlock.conv1 <- conv2, darknet.py:23-28: 23 units of CSPDarknet-53).  The last
         # whole-tensor data-gradient op per gradient buffer is remembered here; any other writer forgets it.
         # VT_FUSE_BNRED=0: the separate passes everywhere.
-        self.fuse_bnred = os.environ.get("VT_FUSE_BNRED", "1") != "0"
+        # (off by default: the fused epilogue waits for z four times per tile -- 91 us against 66 + 19.5 for the two launches
+        #  at 128 channels @28x28, step +0.10 ms; NOTEBOOK R6.4.  VT_FUSE_BNRED=1 turns it on.)
+        self.fuse_bnred = os.environ.get("VT_FUSE_BNRED", "0") != "0"
+        # BatchNorm backward of a unit as ONE launch (vt_bn_act_bwd_fused: the operands stay in registers between the
+        # reduction and the apply pass; the library falls back to the three launches where they do not fit).  Not with
+        # SyncBatchNorm (the sums are exchanged between the passes).  VT_BN_BWD_FUSED=0: the three launches everywhere.
+        self.bn_bwd_fused = os.environ.get("VT_BN_BWD_FUSED", "1") != "0"
         self._last_dgrad: dict[int, tuple] = {}  # id(gradient Buf) -> (op, c0, c1)
         self._wg_expect: dict[tuple, int] = {}   # shape key -> units seen in forward and not yet released
         self._wg_pending: dict[tuple, list] = {}  # shape key -> [(x addr, dz addr, dw addr, desc, ldw)]
@@ -782,28 +788,38 @@ class Builder:
                     geo = [B, Ho, Wo] if pool_grad is not None else []
                     rec = self._last_dgrad.get(id(dy.buf)) if (self.fuse_bnred and pool_grad is None and dt == N.VT_BF16 and
                                                                 not generic_act and self._cur is self.bwd) else None
-                    if rec is not None and rec[1] == dy.coff and rec[2] == dy.coff + dy.C and any(o is rec[0] for o in self.bwd):
-                        # d(y) came out of ONE data-gradient launch and nothing was added to it since: that launch also forms
-                        # this unit's backward sums (the op is patched in place: ptr dz w dy | z scale shift mean invstd sums)
-                        fop = rec[0]
-                        fop.kind = N.OP_CONV_DGRAD_BNRED | (fop.kind & N.OP_SIDE_STREAM)
-                        for k_, pa in ((3, z.addr()), (4, cp[0]), (5, cp[1]), (6, cp[2]), (7, cp[3]), (8, self.bp(sums))):
-                            fop.ptr[k_].base, fop.ptr[k_].offset = pa
-                        k0 = C.sizeof(N.ConvDesc) // 4
-                        fop.i[k0], fop.i[k0 + 1] = z.ld, int(relu)
-                        self._last_dgrad.pop(id(dy.buf), None)
-                    else:
-                        self.emit(N.OP_BN_BWD_REDUCE,
-                                  [g_.addr(), z.addr(), cp[0], cp[1], cp[2], cp[3], self.bp(sums)] + am_,
-                                  [g_.ld, z.ld, Cout, int(relu), dt] + geo, [M])
+                    fused_red = rec is not None and rec[1] == dy.coff and rec[2] == dy.coff + dy.C and any(o is rec[0] for o in self.bwd)
+                    one_launch = (self.bn_bwd_fused and not fused_red and pool_grad is None and dt == N.VT_BF16 and
+                                  not generic_act and self.bn_world == 1)
                     bcoef = self.f32(3 * Cout, "bwdcoef")
-                    self.emit(N.OP_BN_BWD_FINALIZE,
-                              [self.bp(sums), cp[0], cp[2], cp[3], self.pgrad(norm.weight), self.pgrad(norm.bias),
-                               self.bp(bcoef)], [Cout, int(training)], [M * self.bn_world, 1.0 / self.bn_world])
                     dz = self.act(B, Ho, Wo, Cout, name + ".dz")
-                    self.emit(N.OP_BN_BWD_APPLY,
-                              [g_.addr(), z.addr(), cp[0], cp[1], self.bp(bcoef), dz.addr()] + am_,
-                              [g_.ld, z.ld, dz.ld, Cout, int(relu), dt] + geo, [M])
+                    if one_launch:
+                        sync = self.zeroed_f32(4, "bwdsync")
+                        self.emit(N.OP_BN_BWD_FUSED,
+                                  [dy.addr(), z.addr(), cp[0], cp[1], cp[2], cp[3], self.bp(sums), self.bp(sync),
+                                   self.pgrad(norm.weight), self.pgrad(norm.bias), self.bp(bcoef), dz.addr()],
+                                  [dy.ld, z.ld, dz.ld, Cout, int(relu), dt, int(training)], [M, M * self.bn_world, 1.0 / self.bn_world])
+                    else:
+                        if fused_red:
+                            # d(y) came out of ONE data-gradient launch and nothing was added to it since: that launch also forms
+                            # this unit's backward sums (the op is patched in place: ptr dz w dy | z scale shift mean invstd sums)
+                            fop = rec[0]
+                            fop.kind = N.OP_CONV_DGRAD_BNRED | (fop.kind & N.OP_SIDE_STREAM)
+                            for k_, pa in ((3, z.addr()), (4, cp[0]), (5, cp[1]), (6, cp[2]), (7, cp[3]), (8, self.bp(sums))):
+                                fop.ptr[k_].base, fop.ptr[k_].offset = pa
+                            k0 = C.sizeof(N.ConvDesc) // 4
+                            fop.i[k0], fop.i[k0 + 1] = z.ld, int(relu)
+                            self._last_dgrad.pop(id(dy.buf), None)
+                        else:
+                            self.emit(N.OP_BN_BWD_REDUCE,
+                                      [g_.addr(), z.addr(), cp[0], cp[1], cp[2], cp[3], self.bp(sums)] + am_,
+                                      [g_.ld, z.ld, Cout, int(relu), dt] + geo, [M])
+                        self.emit(N.OP_BN_BWD_FINALIZE,
+                                  [self.bp(sums), cp[0], cp[2], cp[3], self.pgrad(norm.weight), self.pgrad(norm.bias),
+                                   self.bp(bcoef)], [Cout, int(training)], [M * self.bn_world, 1.0 / self.bn_world])
+                        self.emit(N.OP_BN_BWD_APPLY,
+                                  [g_.addr(), z.addr(), cp[0], cp[1], self.bp(bcoef), dz.addr()] + am_,
+                                  [g_.ld, z.ld, dz.ld, Cout, int(relu), dt] + geo, [M])
                 else:
                     dz = dy
                     if relu:  # dz = dy * act'(z)
