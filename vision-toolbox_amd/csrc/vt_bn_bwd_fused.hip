@@ -53,13 +53,15 @@ __device__ __forceinline__ uint4 ldg16(const bf16_t* p) { return *(const uint4*)
 // barriers that ran into their wall-clock bound since the library was loaded (vt_bn_bwd_fused_timeouts): must stay 0
 __device__ unsigned vt_bn_fused_timeouts;
 
-// A value another workgroup (another XCD: another L2) has written in THIS launch, read where the device's atomics are
-// performed -- a read-modify-write with 0 (a plain or sc1 load may be served from a line this XCD's L2 still holds).
+// A value another workgroup (another XCD: another L2) has written in THIS launch: a device-scope load behind the
+// barrier's acquire fence.  (First version: read-modify-writes with 0, which are performed where the atomics are whatever
+// a cache holds -- correct, and 100 us per launch: 242 workgroups each polling one counter and fetching 768 coefficients
+// serialise on the addresses they share.)
 __device__ __forceinline__ unsigned long long coherent_u64(const void* p) {
-    return __hip_atomic_fetch_add((unsigned long long*)p, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load((unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ float coherent_f32(const float* p) {
-    return __uint_as_float(__hip_atomic_fetch_add((unsigned*)p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return __hip_atomic_load((float*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // every workgroup of the grid arrives, then leaves; false (and the error flag set) when the others did not arrive within ~4 ms
@@ -69,9 +71,12 @@ __device__ __forceinline__ void grid_barrier(unsigned* cnt, unsigned n, unsigned
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long t0 = wall_clock64();  // 100 MHz
-        // (polled with a read-modify-write: performed where the arrivals are, whatever XCD's L2 this CU sits behind)
-        while (__hip_atomic_fetch_add(cnt, 0u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n) {
-            __builtin_amdgcn_s_sleep(8);
+        // Polled with device-scope acquire LOADS (readers do not serialise); every 32nd poll is a read-modify-write with 0,
+        // performed where the arrivals are whatever a cache holds, so that a stale line cannot hold a workgroup back.
+        unsigned polls = 0;
+        while (((++polls & 31u) ? __hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
+                                : __hip_atomic_fetch_add(cnt, 0u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < n) {
+            __builtin_amdgcn_s_sleep(2);
             if (wall_clock64() - t0 > 400000ull) {
                 __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_fetch_add(&vt_bn_fused_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -217,13 +222,15 @@ __global__ void __launch_bounds__(kT) bn_bwd_fused_kernel(const FArgs a) {
     }
     grid_barrier(a.sync + 1, a.nwg, a.sync + 2);
     // ---- pass 2 from the registers ------------------------------------------------------------------------
-    // the coefficients were written behind other XCDs' L2s: fetched coherently once per workgroup, then from LDS
-    for (int i = t; i < 3 * a.C; i += kT) sred[i] = coherent_f32(a.coef + i);
-    __syncthreads();
     if (!active) return;
+    // (the coefficients were written behind other XCDs' L2s: device-scope loads behind the barrier's acquire fence)
     float ca[EPC], cb[EPC], cd[EPC];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) ca[e] = sred[c0 + e], cb[e] = sred[a.C + c0 + e], cd[e] = sred[2 * a.C + c0 + e];
+    for (int e = 0; e < EPC; ++e) {
+        ca[e] = coherent_f32(a.coef + c0 + e);
+        cb[e] = coherent_f32(a.coef + a.C + c0 + e);
+        cd[e] = coherent_f32(a.coef + 2 * a.C + c0 + e);
+    }
     long rowp = row0;
     asm volatile("" : "+v"(rowp));  // (the store addresses are formed here, not kept from the loads)
 #pragma unroll
@@ -291,8 +298,7 @@ extern "C" int vt_bn_act_bwd_fused(const void* dy, int32_t lddy, const void* z, 
                 a.lddy = lddy, a.ldz = ldz, a.lddz = lddz, a.C = C, a.relu = relu, a.train = train;
                 a.nwg = nwg;
                 const bool inwave = a.CT < 64 && (a.CT & (a.CT - 1)) == 0;
-                int smem = (inwave ? kT / 64 : a.RT) * 2 * a.CT * 8 * (int)sizeof(float);
-                if (smem < 3 * C * (int)sizeof(float)) smem = 3 * C * (int)sizeof(float);
+                const int smem = (inwave ? kT / 64 : a.RT) * 2 * a.CT * 8 * (int)sizeof(float);
                 vt_note_kernel("bn_bwd_fused_kernel<NV%d>", pick);
                 switch (pick) {
                     case 4: return launch_fused<4>(a, smem, (hipStream_t)stream);
