@@ -64,18 +64,22 @@ __device__ __forceinline__ float coherent_f32(const float* p) {
     return __hip_atomic_load((float*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// every workgroup of the grid arrives, then leaves; false (and the error flag set) when the others did not arrive within ~4 ms
+// Every workgroup of the grid arrives, then leaves.  No fences: everything one workgroup reads of another's inside this
+// launch is written with device-scope atomics or sc1 stores and read with device-scope (sc1) loads, so all a thread owes
+// the barrier is that its own requests have been performed (s_waitcnt).  (First versions: a __threadfence() per thread and
+// acquire polls -- an L2 write-back / invalidate per thread and per poll: 100 us per launch.)  The arrival is a relaxed
+// increment; the poll a relaxed device-scope load, every 32nd one a read-modify-write with 0 so that a stale line cannot hold
+// a workgroup back; a wall-clock bound (~4 ms) turns a barrier that does not complete into an error flag and a counted
+// timeout instead of a hang.
 __device__ __forceinline__ void grid_barrier(unsigned* cnt, unsigned n, unsigned* err) {
-    __threadfence();  // every thread's atomics and stores are performed / written back before its workgroup arrives
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long t0 = wall_clock64();  // 100 MHz
-        // Polled with device-scope acquire LOADS (readers do not serialise); every 32nd poll is a read-modify-write with 0,
-        // performed where the arrivals are whatever a cache holds, so that a stale line cannot hold a workgroup back.
         unsigned polls = 0;
-        while (((++polls & 31u) ? __hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
-                                : __hip_atomic_fetch_add(cnt, 0u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < n) {
+        while (((++polls & 31u) ? __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                : __hip_atomic_fetch_add(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < n) {
             __builtin_amdgcn_s_sleep(2);
             if (wall_clock64() - t0 > 400000ull) {
                 __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -85,7 +89,6 @@ __device__ __forceinline__ void grid_barrier(unsigned* cnt, unsigned n, unsigned
         }
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing read before the barrier is reused behind it
 }
 
 template <int NV>
