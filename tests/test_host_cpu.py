@@ -163,13 +163,11 @@ def test_cspdarknet53_program_structure():
     # their filter gradient is formed inside pw_bwd up to 64 x 64; the 128-channel ones (stage 1 pair + out_conv, the 8
     # block units of stage 2: 11 filters) hand dz to the filter-gradient kernel
     assert h["conv_wgrad"] == 66 - pw_units + 11 and h["bn_finalize"] == 67
-    # round 6: the BatchNorm backward of a unit is ONE op (vt_bn_act_bwd_fused: reduce, finalize and apply in one launch
-    # where the operands fit the register file, the three launches elsewhere -- the library decides); the stem and the
-    # pointwise units keep their own finalize op.  (VT_FUSE_BNRED=1, off by default, would move 12 of the reductions of
-    # this program into the data-gradient launches in front of them.)
-    assert h["bn_bwd_fused"] == 66 - pw_units and "bn_bwd_apply" not in h and "bn_bwd_reduce" not in h
-    assert "conv_dgrad_bnred" not in h
-    assert h["bn_bwd_finalize"] == 67 - (66 - pw_units)
+    # (round 6: two fused forms exist and are off by default, each measured slower in the step -- VT_FUSE_BNRED=1 moves the
+    #  reduction of DarknetBlock.conv1's backward into conv2's data-gradient launch, VT_BN_BWD_FUSED=1 makes the whole
+    #  BatchNorm backward of a unit one launch; test_fused_backward_forms_change_the_program_as_documented)
+    assert h["bn_bwd_apply"] == 66 - pw_units and h["bn_bwd_reduce"] == 66 - pw_units
+    assert h["bn_bwd_finalize"] == 67
     # residual adds are folded into the normalise pass and torch.cat is elided: the ONLY
     # elementwise launches are one bn_act_apply per remaining unit; the only copies are the bf16 weight
     # mirror and the 3->8 channel stem filter pad
@@ -181,6 +179,18 @@ def test_cspdarknet53_program_structure():
     # two HBM-bound ones (32 -> 64 and 64 -> 128 channels), whose classes are the column blocks of one depth-to-space launch
     assert h["conv_igemm"] == (67 - pw_units) + 1 + (66 - 5 - pw_units) + 3 * 4 + 2
     assert "maxpool_fwd" not in h
+
+
+def test_fused_backward_forms_change_the_program_as_documented(monkeypatch):
+    monkeypatch.setenv("VT_FUSE_BNRED", "1")
+    h = _dry_program("cspdarknet53", N.VT_BF16, True, True).kind_histogram
+    # the 8 + 4 DarknetBlock.conv1 units of stages 3 and 4 (stages 0-2 are pointwise units under this file's VT_PW_MIN_MB=0)
+    assert h["conv_dgrad_bnred"] == 12 and h["bn_bwd_reduce"] == 66 - 17 - 12 and h["bn_bwd_apply"] == 66 - 17
+    monkeypatch.setenv("VT_FUSE_BNRED", "0")
+    monkeypatch.setenv("VT_BN_BWD_FUSED", "1")
+    h = _dry_program("cspdarknet53", N.VT_BF16, True, True).kind_histogram
+    assert h["bn_bwd_fused"] == 66 - 17 and "bn_bwd_apply" not in h and "bn_bwd_reduce" not in h
+    assert h["bn_bwd_finalize"] == 67 - (66 - 17)  # the stem and the pointwise units keep their own
 
 
 def test_inference_program_is_fully_fused():

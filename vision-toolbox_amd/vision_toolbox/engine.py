@@ -305,8 +305,11 @@ class Builder:
         self.fuse_bnred = os.environ.get("VT_FUSE_BNRED", "0") != "0"
         # BatchNorm backward of a unit as ONE launch (vt_bn_act_bwd_fused: the operands stay in registers between the
         # reduction and the apply pass; the library falls back to the three launches where they do not fit).  Not with
-        # SyncBatchNorm (the sums are exchanged between the passes).  VT_BN_BWD_FUSED=0: the three launches everywhere.
-        self.bn_bwd_fused = os.environ.get("VT_BN_BWD_FUSED", "1") != "0"
+        # SyncBatchNorm (the sums are exchanged between the passes).  OFF by default: alone it equals the three launches
+        # (32.5 against 30.8 us at 256 channels @14x14: two grid barriers of ~5 us each eat what the second read costs) and
+        # in the step it is 0.3 ms SLOWER -- a launch that owns every CU's register file shares nothing with the
+        # filter-gradient stream beside it (NOTEBOOK R6.5).  VT_BN_BWD_FUSED=1 turns it on.
+        self.bn_bwd_fused = os.environ.get("VT_BN_BWD_FUSED", "0") != "0"
         self._last_dgrad: dict[int, tuple] = {}  # id(gradient Buf) -> (op, c0, c1)
         self._wg_expect: dict[tuple, int] = {}   # shape key -> units seen in forward and not yet released
         self._wg_pending: dict[tuple, list] = {}  # shape key -> [(x addr, dz addr, dw addr, desc, ldw)]
