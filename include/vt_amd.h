@@ -241,6 +241,21 @@ int vt_bn_act_bwd_fused(const void* dy, int32_t lddy, const void* z, int32_t ldz
                         double count, double pscale, int32_t train, float* sums, void* sync, float* dgamma, float* dbeta,
                         float* coef, void* dz, int32_t lddz, void* stream);
 int vt_bn_bwd_fused_timeouts(uint32_t* count);
+/* vt_bn_finalize + vt_bn_act_apply, and vt_bn_bwd_finalize + vt_bn_act_bwd_apply, as ONE launch each (round 6): the first
+ * workgroups of the streaming launch finalize 16 channels each (the same arithmetic, bit for bit), publish the coefficients
+ * with device-scope stores and count themselves ready in `ready` (4 zeroed bytes); every workgroup polls that counter once.
+ * The 134 single-workgroup finalize launches of a CSPDarknet-53 step leave the critical path.  Same arguments, same results
+ * (bit-identical) as the two calls each replaces; activation codes >= 2 run those two calls.  A hand-off that does not
+ * complete within ~4 ms gives up and is counted in vt_bn_bwd_fused_timeouts. */
+int vt_bn_finalize_apply(const float* stats, int32_t C, double count, const float* gamma, const float* beta, float eps,
+                         float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* scale,
+                         float* shift, float* mean, float* invstd, void* ready, const void* z, int32_t ldz,
+                         const void* residual, int32_t ldr, void* y, int32_t ldy, int64_t M, int32_t relu, int32_t dtype,
+                         void* stream);
+int vt_bn_bwd_finalize_apply(const float* sums, int32_t C, double count, double pscale, const float* scale,
+                             const float* shift, const float* mean, const float* invstd, int32_t train, float* dgamma,
+                             float* dbeta, float* coef, void* ready, const void* dy, int32_t lddy, const void* z, int32_t ldz,
+                             void* dz, int32_t lddz, int64_t M, int32_t relu, int32_t dtype, void* stream);
 
 /* Backward of the stem unit Conv3x3(3 -> C, s1, pad 1) -> BatchNorm2d -> ReLU in one streaming pass
  * (darknet.py:75 `ConvNormAct(3, 32, 3, 1)`; autograd backward of components.py:26-44 with respect to the
@@ -480,6 +495,8 @@ enum vt_op_kind {
     VT_OP_XENT_EVAL,        /* vt_softmax_xent_eval (validation: loss sum, top-1 hits, rows) */
     VT_OP_CONV_DGRAD_BNRED, /* vt_conv_dgrad_bnred (a data gradient + the BatchNorm-backward sums of the producing unit) */
     VT_OP_BN_BWD_FUSED,     /* vt_bn_act_bwd_fused (BatchNorm backward of a unit: reduce, finalize, apply in one launch) */
+    VT_OP_BN_FIN_APPLY,     /* vt_bn_finalize_apply */
+    VT_OP_BN_BWD_FIN_APPLY, /* vt_bn_bwd_finalize_apply */
     VT_OP_KIND_END
 };
 

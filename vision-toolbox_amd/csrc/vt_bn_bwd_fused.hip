@@ -319,7 +319,9 @@ extern "C" int vt_bn_act_bwd_fused(const void* dy, int32_t lddy, const void* z, 
     return vt_bn_act_bwd_apply(dy, lddy, z, ldz, scale, shift, coef, dz, lddz, M, C, relu, dtype, stream);
 }
 
-// barriers of vt_bn_act_bwd_fused launches that gave up waiting (synchronises the device); anything but 0 means wrong results
+extern "C" unsigned vt_fin_timeouts_host();  // vt_elementwise.hip: the hand-offs of vt_bn_finalize_apply / vt_bn_bwd_finalize_apply
+
+// barriers of vt_bn_act_bwd_fused launches (and hand-offs of vt_bn_finalize_apply / vt_bn_bwd_finalize_apply) that gave up waiting (synchronises the device); anything but 0 means wrong results
 extern "C" int vt_bn_bwd_fused_timeouts(uint32_t* count) {
     VT_REQUIRE(count, VT_ERR_INVALID, "vt_bn_bwd_fused_timeouts: null");
     unsigned v = 0;
@@ -328,6 +330,6 @@ extern "C" int vt_bn_bwd_fused_timeouts(uint32_t* count) {
         vt_set_error("vt_bn_bwd_fused_timeouts: %s", hipGetErrorString(e));
         return VT_ERR_HIP;
     }
-    *count = v;
+    *count = v + vt_fin_timeouts_host();
     return VT_OK;
 }

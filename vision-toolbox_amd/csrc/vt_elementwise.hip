@@ -470,6 +470,251 @@ bn_act_apply_pool_kernel(const T* __restrict__ z, int ldz, const float* __restri
 }
 
 // ---------------------------------------------------------------------------------
+// Finalize INSIDE the consuming launch (round 6).  The 134 single-workgroup finalize launches of a CSPDarknet-53 step sit on
+// the critical path between a producer of statistics and the streaming pass that needs the coefficients (0.71 ms in situ).
+// Here the first workgroups of the streaming launch do that work -- 16 channels per workgroup, 16 lanes per channel (one per
+// statistics replica: exact integer sums, then the arithmetic of bn_finalize_kernel / bn_bwd_finalize_kernel, bit for bit) --
+// publish the coefficients with device-scope (sc1) stores and count themselves ready; every workgroup polls that counter
+// once (device-scope loads; every 32nd poll a read-modify-write with 0, so that a stale cache line cannot hold it back) and
+// then reads the coefficients with device-scope loads.  The finalizing workgroups are the lowest-numbered ones: dispatched
+// first, never waiting for anything, so the hand-off cannot deadlock however many workgroups of the grid are resident.
+// (Round 3 tried this with agent-scope fences and plain polls: some workgroups never saw the flag.  What one workgroup reads
+// of another inside a launch here is written and read with sc1 accesses only; no fence is involved.)
+// A poll that does not complete within ~4 ms of wall clock gives up and is counted (vt_bn_bwd_fused_timeouts): never a hang.
+__device__ unsigned vt_fin_timeouts;
+
+__device__ __forceinline__ float ld_sc1(const float* p) {
+    return __hip_atomic_load((float*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// exact integer sums over the 16 replicas of statistics entries `c` and `C + c`, one replica per lane of a 16-lane group;
+// returned (as vt_stat_sum returns them) in every lane of the group
+__device__ __forceinline__ void stat_sum16(const float* stats, int c, int C, int rp, double& s0, double& s1) {
+    const long long* q = (const long long*)stats;
+    long long hi[2], lo[2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const long idx = (long)w * C + c + (long)rp * 2 * C;
+        hi[w] = q[2 * idx], lo[w] = q[2 * idx + 1];
+    }
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            hi[w] += __shfl_xor(hi[w], off, 64);
+            lo[w] += __shfl_xor(lo[w], off, 64);
+        }
+    }
+    auto nat = [](long long h, long long l) -> double {
+        if (h >= (kStatPoison >> 2) || h <= -(kStatPoison >> 2)) return __longlong_as_double(0x7ff8000000000000LL);  // poisoned
+        return (double)h * 4096.0 + (double)l * (1.0 / 8589934592.0);
+    };
+    s0 = nat(hi[0], lo[0]), s1 = nat(hi[1], lo[1]);
+}
+// the finalizing workgroups count themselves ready; every workgroup waits for all of them
+__device__ __forceinline__ void fin_publish_and_wait(unsigned* ready, bool finalizer, unsigned nfin) {
+    if (finalizer) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's coefficient stores are performed
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = wall_clock64();  // 100 MHz
+        unsigned polls = 0;
+        while (((++polls & 31u) ? __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                : __hip_atomic_fetch_add(ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < nfin) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > 400000ull) {
+                __hip_atomic_fetch_add(&vt_fin_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+struct FinFwd {
+    const float* stats;
+    const float *gamma, *beta;
+    float *running_mean, *running_var;
+    int64_t* nbt;
+    float *scale, *shift, *mean, *invstd;
+    unsigned* ready;
+    double inv_count, unbias;
+    float eps, momentum;
+    int C;
+};
+
+// y = [relu](z*scale + shift) [+ residual] with scale / shift finalized by this launch's first workgroups
+template <typename T, bool kRes>
+__global__ void __launch_bounds__(kThreads)
+bn_fin_apply_kernel(const FinFwd f, const T* __restrict__ z, int ldz, const T* __restrict__ res, int ldr, T* __restrict__ y,
+                    int ldy, long M, RowMap rm, int relu) {
+    constexpr int EPC = VecIO<T>::EPC;
+    const int t = threadIdx.x;
+    const int nfb = (f.C + 15) / 16, nfin = min((int)gridDim.x, nfb);
+    const bool finalizer = (int)blockIdx.x < nfin;
+    if (finalizer) {
+        if (blockIdx.x == 0 && t == 0 && f.nbt) f.nbt[0] += 1;
+        for (int cb = blockIdx.x; cb < nfb; cb += nfin) {
+            const int c = cb * 16 + (t >> 4), rp = t & 15;
+            if (c >= f.C) continue;  // (whole 16-lane groups)
+            double s, ss;
+            stat_sum16(f.stats, c, f.C, rp, s, ss);
+            if (rp == 0) {  // bn_finalize_kernel, bit for bit
+                const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+                const double mu = s * f.inv_count;
+                double var = ss * f.inv_count - mu * mu;
+                if (var < 0.0) var = 0.0;
+                const float istd = 1.0f / sqrtf((float)(var + (double)f.eps));
+                const float sc = g * istd;
+                st_sc1(f.scale + c, sc);
+                st_sc1(f.shift + c, b - (float)mu * sc);
+                f.mean[c] = (float)mu;
+                f.invstd[c] = istd;
+                if (f.running_mean) {
+                    f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mu;
+                    f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)(var * f.unbias);
+                }
+            }
+        }
+    }
+    fin_publish_and_wait(f.ready, finalizer, (unsigned)nfin);
+    const int r = t / rm.CT;
+    if (r >= rm.RT) return;
+    const long row0 = (long)(rm.rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * rm.RT * rm.iters + r;
+    for (int col = t % rm.CT; col < rm.CPR; col += rm.CT) {
+        float sc[EPC], sf[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) sc[e] = ld_sc1(f.scale + col * EPC + e), sf[e] = ld_sc1(f.shift + col * EPC + e);
+        const T* pz = z + row0 * ldz + col * EPC;
+        const T* pr = kRes ? res + row0 * ldr + col * EPC : nullptr;
+        T* py = y + row0 * ldy + col * EPC;
+        const long sz = (long)rm.RT * ldz, sr = (long)rm.RT * ldr, sy = (long)rm.RT * ldy;
+        for (int it = 0; it < rm.iters; it += kUnroll) {
+            uint4 vz[kUnroll], vr[kUnroll];
+            bool ok[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                ok[u] = (it + u < rm.iters) && (row0 + (long)(it + u) * rm.RT < M);
+                vz[u] = vr[u] = make_uint4(0, 0, 0, 0);
+                if (ok[u]) {
+                    vz[u] = ld16(pz + (it + u) * sz);
+                    if (kRes) vr[u] = ld16(pr + (it + u) * sr);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                float v[EPC];
+                VecIO<T>::unpack(vz[u], v);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    v[e] = fmaf(v[e], sc[e], sf[e]);
+                    v[e] = relu ? fmaxf(v[e], 0.f) : v[e];
+                }
+                if (kRes) {
+                    float rr[EPC];
+                    VecIO<T>::unpack(vr[u], rr);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[e] += rr[e];
+                }
+                if (ok[u]) st16(py + (it + u) * sy, VecIO<T>::pack(v));
+            }
+        }
+    }
+}
+
+struct FinBwd {
+    const float* sums;
+    const float *scale, *mean, *invstd;
+    float *dgamma, *dbeta, *coef;
+    unsigned* ready;
+    double inv_count, pscale;
+    int C, train;
+};
+
+// dz = a*g - b*z + d with (a, b, d) finalized by this launch's first workgroups
+template <typename T>
+__global__ void __launch_bounds__(kThreads)
+bn_bwd_fin_apply_kernel(const FinBwd f, const T* __restrict__ dy, int lddy, const T* __restrict__ z, int ldz,
+                        const float* __restrict__ scale, const float* __restrict__ shift, T* __restrict__ dz, int lddz, long M,
+                        RowMap rm, int relu) {
+    constexpr int EPC = VecIO<T>::EPC;
+    const int t = threadIdx.x, C = f.C;
+    const int nfb = (C + 15) / 16, nfin = min((int)gridDim.x, nfb);
+    const bool finalizer = (int)blockIdx.x < nfin;
+    if (finalizer) {
+        for (int cb = blockIdx.x; cb < nfb; cb += nfin) {
+            const int c = cb * 16 + (t >> 4), rp = t & 15;
+            if (c >= C) continue;
+            double s1, s2;
+            stat_sum16(f.sums, c, C, rp, s1, s2);
+            if (rp == 0) {  // bn_bwd_finalize_kernel, bit for bit
+                const float a = f.scale[c], mu = f.mean[c], istd = f.invstd[c];
+                if (f.dgamma) f.dgamma[c] += (float)(s2 * f.pscale);
+                if (f.dbeta) f.dbeta[c] += (float)(s1 * f.pscale);
+                float b = 0.f, d = 0.f;
+                if (f.train) {
+                    const double c1 = s1 * f.inv_count, c2 = s2 * f.inv_count;
+                    const double bb = (double)a * c2 * (double)istd;
+                    b = (float)bb;
+                    d = (float)(bb * (double)mu - (double)a * c1);
+                }
+                st_sc1(f.coef + c, a);
+                st_sc1(f.coef + C + c, b);
+                st_sc1(f.coef + 2 * C + c, d);
+            }
+        }
+    }
+    fin_publish_and_wait(f.ready, finalizer, (unsigned)nfin);
+    const int r = t / rm.CT;
+    if (r >= rm.RT) return;
+    const long row0 = (long)(rm.rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * rm.RT * rm.iters + r;
+    for (int col = t % rm.CT; col < rm.CPR; col += rm.CT) {
+        float sc[EPC], sf[EPC], ca[EPC], cb[EPC], cd[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const int c = col * EPC + e;
+            sc[e] = scale[c];
+            sf[e] = shift[c];
+            ca[e] = ld_sc1(f.coef + c);
+            cb[e] = ld_sc1(f.coef + C + c);
+            cd[e] = ld_sc1(f.coef + 2 * C + c);
+        }
+        for (int it = 0; it < rm.iters; it += kUnroll) {
+            uint4 vg[kUnroll], vz[kUnroll];
+            bool ok[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const long row = row0 + (long)(it + u) * rm.RT;
+                ok[u] = (it + u < rm.iters) && row < M;
+                vg[u] = vz[u] = make_uint4(0, 0, 0, 0);
+                if (ok[u]) {
+                    vg[u] = ld16(dy + row * lddy + col * EPC);
+                    vz[u] = ld16(z + row * ldz + col * EPC);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                if (!ok[u]) continue;
+                const long row = row0 + (long)(it + u) * rm.RT;
+                float g[EPC], zz[EPC];
+                VecIO<T>::unpack(vg[u], g);
+                VecIO<T>::unpack(vz[u], zz);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float gg = (!relu || fmaf(zz[e], sc[e], sf[e]) > 0.f) ? g[e] : 0.f;
+                    g[e] = fmaf(ca[e], gg, fmaf(-cb[e], zz[e], cd[e]));
+                }
+                st16(dz + row * lddz + col * EPC, VecIO<T>::pack(g));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // BN backward, pass 1: per-channel sum(g) and sum(g*xhat), g = dy * [z*scale+shift > 0]
 // ---------------------------------------------------------------------------------
 template <typename T, bool GEN = false>
@@ -1537,6 +1782,82 @@ int vt_bn_act_apply(const void* z, int32_t ldz, const float* scale, const float*
     }
     VT_CHECK_LAUNCH("vt_bn_act_apply");
     return VT_OK;
+}
+
+// vt_bn_finalize + vt_bn_act_apply in one launch (see bn_fin_apply_kernel); activation codes >= 2 and VT_BN_FIN_APPLY=0:
+// the two launches.  `ready`: 4 zeroed bytes.
+int vt_bn_finalize_apply(const float* stats, int32_t C, double count, const float* gamma, const float* beta, float eps,
+                         float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* scale,
+                         float* shift, float* mean, float* invstd, void* ready, const void* z, int32_t ldz,
+                         const void* residual, int32_t ldr, void* y, int32_t ldy, int64_t M, int32_t relu, int32_t dtype,
+                         void* stream) {
+    VT_REQUIRE(stats && scale && shift && mean && invstd && ready && C > 0 && count > 0 && M > 0, VT_ERR_INVALID,
+               "vt_bn_finalize_apply: bad argument");
+    VT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), VT_ERR_INVALID,
+               "vt_bn_finalize_apply: running_mean/var must both be given or both NULL");
+    VT_REQUIRE(relu >= 0 && relu <= 4, VT_ERR_INVALID, "vt_bn_finalize_apply: activation code %d", relu);
+    if (relu >= 2 || !VT_KNOB("VT_BN_FIN_APPLY", 1)) {
+        const int rc = vt_bn_finalize(stats, C, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked,
+                                      scale, shift, mean, invstd, stream);
+        if (rc != VT_OK) return rc;
+        return vt_bn_act_apply(z, ldz, scale, shift, residual, ldr, y, ldy, M, C, relu, dtype, stream);
+    }
+    VT_TRY(check_mat("vt_bn_finalize_apply(z)", z, ldz, C, dtype));
+    VT_TRY(check_mat("vt_bn_finalize_apply(y)", y, ldy, C, dtype));
+    if (residual) VT_TRY(check_mat("vt_bn_finalize_apply(residual)", residual, ldr, C, dtype));
+    RowMap rm = RowMap::make(C, vt_epc(dtype), M);
+    rm.rev = (vt_bn_order() >> 0) & 1;
+    FinFwd f;
+    f.stats = stats, f.gamma = gamma, f.beta = beta, f.running_mean = running_mean, f.running_var = running_var;
+    f.nbt = num_batches_tracked, f.scale = scale, f.shift = shift, f.mean = mean, f.invstd = invstd;
+    f.ready = (unsigned*)ready, f.inv_count = 1.0 / count, f.unbias = count > 1.0 ? count / (count - 1.0) : 1.0;
+    f.eps = eps, f.momentum = momentum, f.C = C;
+    if (residual) {
+        VT_DISPATCH_T(dtype, "vt_bn_finalize_apply",
+                      VT_LAUNCH_STOP((bn_fin_apply_kernel<T, true>), dim3(rm.blocks(M)), dim3(kThreads), 0, (hipStream_t)stream, f,
+                                     (const T*)z, ldz, (const T*)residual, ldr, (T*)y, ldy, (long)M, rm, relu));
+    } else {
+        VT_DISPATCH_T(dtype, "vt_bn_finalize_apply",
+                      VT_LAUNCH_STOP((bn_fin_apply_kernel<T, false>), dim3(rm.blocks(M)), dim3(kThreads), 0, (hipStream_t)stream, f,
+                                     (const T*)z, ldz, (const T*)residual, ldr, (T*)y, ldy, (long)M, rm, relu));
+    }
+    VT_CHECK_LAUNCH("vt_bn_finalize_apply");
+    return VT_OK;
+}
+
+// vt_bn_bwd_finalize + vt_bn_act_bwd_apply in one launch (see bn_bwd_fin_apply_kernel)
+int vt_bn_bwd_finalize_apply(const float* sums, int32_t C, double count, double pscale, const float* scale,
+                             const float* shift, const float* mean, const float* invstd, int32_t train, float* dgamma,
+                             float* dbeta, float* coef, void* ready, const void* dy, int32_t lddy, const void* z, int32_t ldz,
+                             void* dz, int32_t lddz, int64_t M, int32_t relu, int32_t dtype, void* stream) {
+    VT_REQUIRE(sums && scale && shift && mean && invstd && coef && ready && C > 0 && count > 0 && M > 0, VT_ERR_INVALID,
+               "vt_bn_bwd_finalize_apply: bad argument");
+    VT_REQUIRE(relu >= 0 && relu <= 4, VT_ERR_INVALID, "vt_bn_bwd_finalize_apply: activation code %d", relu);
+    if (relu >= 2 || !VT_KNOB("VT_BN_FIN_APPLY", 1)) {
+        const int rc = vt_bn_bwd_finalize(sums, C, count, pscale, scale, mean, invstd, train, dgamma, dbeta, coef, stream);
+        if (rc != VT_OK) return rc;
+        return vt_bn_act_bwd_apply(dy, lddy, z, ldz, scale, shift, coef, dz, lddz, M, C, relu, dtype, stream);
+    }
+    VT_TRY(check_mat("vt_bn_bwd_finalize_apply(dy)", dy, lddy, C, dtype));
+    VT_TRY(check_mat("vt_bn_bwd_finalize_apply(z)", z, ldz, C, dtype));
+    VT_TRY(check_mat("vt_bn_bwd_finalize_apply(dz)", dz, lddz, C, dtype));
+    RowMap rm = RowMap::make(C, vt_epc(dtype), M);
+    rm.rev = (vt_bn_order() >> 2) & 1;
+    FinBwd f;
+    f.sums = sums, f.scale = scale, f.mean = mean, f.invstd = invstd, f.dgamma = dgamma, f.dbeta = dbeta, f.coef = coef;
+    f.ready = (unsigned*)ready, f.inv_count = 1.0 / count, f.pscale = pscale, f.C = C, f.train = train;
+    VT_DISPATCH_T(dtype, "vt_bn_bwd_finalize_apply",
+                  VT_LAUNCH_STOP(bn_bwd_fin_apply_kernel<T>, dim3(rm.blocks(M)), dim3(kThreads), 0, (hipStream_t)stream, f,
+                                 (const T*)dy, lddy, (const T*)z, ldz, scale, shift, (T*)dz, lddz, (long)M, rm, relu));
+    VT_CHECK_LAUNCH("vt_bn_bwd_finalize_apply");
+    return VT_OK;
+}
+
+// hand-offs of the two launches above that gave up waiting (added to vt_bn_bwd_fused_timeouts' count)
+unsigned vt_fin_timeouts_host() {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(vt_fin_timeouts), sizeof(v)) != hipSuccess) return 0xffffffffu;
+    return v;
 }
 
 int vt_bn_act_bwd_reduce(const void* dy, int32_t lddy, const void* z, int32_t ldz, const float* scale,

@@ -174,6 +174,15 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
         case VT_OP_BN_BWD_FINALIZE:  // ptr: sums scale mean invstd dgamma dbeta coef | i: C train | f: count pscale(0 = 1)
             return vt_bn_bwd_finalize((const float*)P[0], I[0], F[0], F[1] == 0.0 ? 1.0 : F[1], (const float*)P[1], (const float*)P[2],
                                       (const float*)P[3], I[1], (float*)P[4], (float*)P[5], (float*)P[6], st);
+        case VT_OP_BN_FIN_APPLY:  // ptr: stats gamma beta rm rv nbt scale shift mean invstd ready z residual y | i: C ldz ldr ldy relu dtype | f: count eps momentum M
+            return vt_bn_finalize_apply((const float*)P[0], I[0], F[0], (const float*)P[1], (const float*)P[2], (float)F[1], (float)F[2],
+                                        (float*)P[3], (float*)P[4], (int64_t*)P[5], (float*)P[6], (float*)P[7], (float*)P[8],
+                                        (float*)P[9], P[10], P[11], I[1], P[12], I[2], P[13], I[3], (int64_t)F[3], I[4], I[5], st);
+        case VT_OP_BN_BWD_FIN_APPLY:  // ptr: sums scale shift mean invstd dgamma dbeta coef ready dy z dz | i: C train lddy ldz lddz relu dtype | f: count pscale(0 = 1) M
+            return vt_bn_bwd_finalize_apply((const float*)P[0], I[0], F[0], F[1] == 0.0 ? 1.0 : F[1], (const float*)P[1],
+                                            (const float*)P[2], (const float*)P[3], (const float*)P[4], I[1], (float*)P[5],
+                                            (float*)P[6], (float*)P[7], P[8], P[9], I[2], P[10], I[3], P[11], I[4], (int64_t)F[2],
+                                            I[5], I[6], st);
         case VT_OP_BN_BWD_FUSED:  // ptr: dy z scale shift mean invstd sums sync dgamma dbeta coef dz | i: lddy ldz lddz C relu dtype train | f: M count pscale(0 = 1)
             return vt_bn_act_bwd_fused(P[0], I[0], P[1], I[1], (const float*)P[2], (const float*)P[3], (const float*)P[4],
                                        (const float*)P[5], (int64_t)F[0], I[3], I[4], I[5], F[1], F[2] == 0.0 ? 1.0 : F[2], I[6],
@@ -413,7 +422,7 @@ static int run_ops_impl(const vt_op* ops, int32_t n, void* const* bases, int32_t
             fork_ev = nullptr;
         } else if (stop_events && two && !bag && !on_side && i + 1 < n && ops[i + 1].kind == VT_OP_FORK &&
                    (op.kind == VT_OP_BN_BWD_APPLY || op.kind == VT_OP_BN_ACT_APPLY || op.kind == VT_OP_PW_BWD ||
-                    op.kind == VT_OP_BN_BWD_FUSED)) {
+                    op.kind == VT_OP_BN_BWD_FUSED || op.kind == VT_OP_BN_FIN_APPLY || op.kind == VT_OP_BN_BWD_FIN_APPLY)) {
             // (single-launch ops only: the event must belong to the LAST kernel of the op)
             hipError_t e = hipSuccess;
             hipEvent_t ev = take_event(nullptr, &e);

@@ -94,7 +94,9 @@ VT_OP_MAX_PTR, VT_OP_MAX_INT, VT_OP_MAX_FLT, VT_MAX_BASES = 16, 110, 8, 16
     OP_XENT_EVAL,
     OP_CONV_DGRAD_BNRED,
     OP_BN_BWD_FUSED,
-) = range(1, 42)
+    OP_BN_FIN_APPLY,
+    OP_BN_BWD_FIN_APPLY,
+) = range(1, 44)
 OP_SIDE_STREAM = 0x10000  # OR-ed into Op.kind: enqueue on the side stream
 
 OP_NAMES = {
@@ -119,6 +121,8 @@ OP_NAMES = {
     OP_XENT_EVAL: "xent_eval",
     OP_CONV_DGRAD_BNRED: "conv_dgrad_bnred",
     OP_BN_BWD_FUSED: "bn_bwd_fused",
+    OP_BN_FIN_APPLY: "bn_fin_apply",
+    OP_BN_BWD_FIN_APPLY: "bn_bwd_fin_apply",
     OP_SGD: "sgd",
     OP_COPY2D: "copy2d",
     OP_NCHW_TO_NHWC: "nchw_to_nhwc",
@@ -215,6 +219,10 @@ SYMBOLS = {
     "vt_bn_act_bwd_fused": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, C.c_int64, _i32, _i32, _i32, _f64, _f64, _i32, _vp, _vp,
                                    _vp, _vp, _vp, _vp, _i32, _vp]),
     "vt_bn_bwd_fused_timeouts": (_i32, [C.POINTER(C.c_uint32)]),
+    "vt_bn_finalize_apply": (_i32, [_vp, _i32, _f64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32,
+                                    _vp, _i32, _i64, _i32, _i32, _vp]),
+    "vt_bn_bwd_finalize_apply": (_i32, [_vp, _i32, _f64, _f64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp,
+                                        _i32, _i64, _i32, _i32, _vp]),
     "vt_pack_dgrad_filter_batch": (_i32, [_vp, _i32, _vp]),
     "vt_bn_eval_coeffs_batch": (_i32, [_vp, _i32, _vp]),
     "vt_pack_dgrad_filter": (_i32, [_vp, _i32, _i32, _vp, _i32, C.POINTER(_i32), _i32, _i32, _i32, _i32, _vp]),

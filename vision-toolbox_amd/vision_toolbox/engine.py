@@ -311,6 +311,10 @@ class Builder:
         # filter-gradient stream beside it (NOTEBOOK R6.5).  VT_BN_BWD_FUSED=1 turns it on.
         self.bn_bwd_fused = os.environ.get("VT_BN_BWD_FUSED", "0") != "0"
         self._last_dgrad: dict[int, tuple] = {}  # id(gradient Buf) -> (op, c0, c1)
+        # The finalize launches folded into the streaming launches that consume their coefficients (vt_bn_finalize_apply,
+        # vt_bn_bwd_finalize_apply: the first workgroups finalize and publish, every workgroup polls once).  Not with
+        # SyncBatchNorm (the statistics are exchanged in front of the finalize).  VT_BN_FIN_APPLY=0: separate launches.
+        self.bn_fin_apply = os.environ.get("VT_BN_FIN_APPLY", "1") != "0"
         self._wg_expect: dict[tuple, int] = {}   # shape key -> units seen in forward and not yet released
         self._wg_pending: dict[tuple, list] = {}  # shape key -> [(x addr, dz addr, dw addr, desc, ldw)]
         # SyncBatchNorm (configs/base.yaml:22): the trainer all-reduces every layer's statistics
@@ -682,10 +686,14 @@ class Builder:
                 stats = self.zeroed_f32(N.stat_floats(Cout), "stats")
                 d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, z.ld, ldw, N.VT_CONV_STATS, dil=dil)
                 self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, z.addr(), None, None, None, self.bp(stats)], desc=d)
-                self.emit(N.OP_BN_FINALIZE,
-                          [self.bp(stats), g, b_, rm, rv, nbt, *cp],
-                          [Cout], [M * self.bn_world, norm.eps, norm.momentum])
+                fin_fwd = (self.bn_fin_apply and self.bn_world == 1 and not generic_act and
+                           not (pool_out is not None and not generic_act))
+                if not fin_fwd:
+                    self.emit(N.OP_BN_FINALIZE,
+                              [self.bp(stats), g, b_, rm, rv, nbt, *cp],
+                              [Cout], [M * self.bn_world, norm.eps, norm.momentum])
             else:
+                fin_fwd = False
                 d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, z.ld, ldw, 0, dil=dil)
                 self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, z.addr(), None, None, None, None], desc=d)
                 self.emit(N.OP_BN_EVAL_COEFFS, [g, b_, rm, rv, *cp], [Cout], [norm.eps])
@@ -697,6 +705,13 @@ class Builder:
                           [z.addr(), cp[0], cp[1], residual.addr() if residual else None, y.addr(), pool_out.addr(),
                            self.bp(pool_am)],
                           [z.ld, residual.ld if residual else 0, y.ld, Cout, int(relu), dt, pool_out.ld, B, Ho, Wo], [M])
+            elif fin_fwd:
+                ready = self.zeroed_f32(4, "finready")
+                self.emit(N.OP_BN_FIN_APPLY,
+                          [self.bp(stats), g, b_, rm, rv, nbt, *cp, self.bp(ready), z.addr(),
+                           residual.addr() if residual else None, y.addr()],
+                          [Cout, z.ld, residual.ld if residual else 0, y.ld, int(relu), dt],
+                          [M * self.bn_world, norm.eps, norm.momentum, M])
             else:
                 self.emit(N.OP_BN_ACT_APPLY,
                           [z.addr(), cp[0], cp[1], residual.addr() if residual else None, y.addr()],
@@ -817,12 +832,20 @@ class Builder:
                             self.emit(N.OP_BN_BWD_REDUCE,
                                       [g_.addr(), z.addr(), cp[0], cp[1], cp[2], cp[3], self.bp(sums)] + am_,
                                       [g_.ld, z.ld, Cout, int(relu), dt] + geo, [M])
-                        self.emit(N.OP_BN_BWD_FINALIZE,
-                                  [self.bp(sums), cp[0], cp[2], cp[3], self.pgrad(norm.weight), self.pgrad(norm.bias),
-                                   self.bp(bcoef)], [Cout, int(training)], [M * self.bn_world, 1.0 / self.bn_world])
-                        self.emit(N.OP_BN_BWD_APPLY,
-                                  [g_.addr(), z.addr(), cp[0], cp[1], self.bp(bcoef), dz.addr()] + am_,
-                                  [g_.ld, z.ld, dz.ld, Cout, int(relu), dt] + geo, [M])
+                        if self.bn_fin_apply and self.bn_world == 1 and pool_grad is None and not generic_act:
+                            ready = self.zeroed_f32(4, "finready")
+                            self.emit(N.OP_BN_BWD_FIN_APPLY,
+                                      [self.bp(sums), cp[0], cp[1], cp[2], cp[3], self.pgrad(norm.weight), self.pgrad(norm.bias),
+                                       self.bp(bcoef), self.bp(ready), g_.addr(), z.addr(), dz.addr()],
+                                      [Cout, int(training), g_.ld, z.ld, dz.ld, int(relu), dt],
+                                      [M * self.bn_world, 1.0 / self.bn_world, M])
+                        else:
+                            self.emit(N.OP_BN_BWD_FINALIZE,
+                                      [self.bp(sums), cp[0], cp[2], cp[3], self.pgrad(norm.weight), self.pgrad(norm.bias),
+                                       self.bp(bcoef)], [Cout, int(training)], [M * self.bn_world, 1.0 / self.bn_world])
+                            self.emit(N.OP_BN_BWD_APPLY,
+                                      [g_.addr(), z.addr(), cp[0], cp[1], self.bp(bcoef), dz.addr()] + am_,
+                                      [g_.ld, z.ld, dz.ld, Cout, int(relu), dt] + geo, [M])
                 else:
                     dz = dy
                     if relu:  # dz = dy * act'(z)
@@ -1382,7 +1405,7 @@ class Builder:
             # host ~0.5 ms, during which the main stream must already have work (measured: it sat idle
             # for exactly that long at the head of every step when the packs came first).
             body, self.fwd = self.fwd, []
-            cut = next((i + 1 for i, op in enumerate(body) if (op.kind & 0xFFFF) == N.OP_BN_ACT_APPLY), 0)
+            cut = next((i + 1 for i, op in enumerate(body) if (op.kind & 0xFFFF) in (N.OP_BN_ACT_APPLY, N.OP_BN_FIN_APPLY)), 0)
             self._cur = self.fwd
             self.fwd.extend(body[:cut])
             self.emit(N.OP_FORK)
