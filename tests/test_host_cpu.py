@@ -191,6 +191,11 @@ def test_fused_backward_forms_change_the_program_as_documented(monkeypatch):
     h = _dry_program("cspdarknet53", N.VT_BF16, True, True).kind_histogram
     assert h["bn_bwd_fused"] == 66 - 17 and "bn_bwd_apply" not in h and "bn_bwd_reduce" not in h
     assert h["bn_bwd_finalize"] == 67 - (66 - 17)  # the stem and the pointwise units keep their own
+    monkeypatch.setenv("VT_BN_BWD_FUSED", "0")
+    monkeypatch.setenv("VT_BN_FIN_APPLY", "1")  # the finalize step inside the launch that consumes its coefficients
+    h = _dry_program("cspdarknet53", N.VT_BF16, True, True).kind_histogram
+    assert h["bn_fin_apply"] == 66 - 17 and h["bn_bwd_fin_apply"] == 66 - 17
+    assert "bn_act_apply" not in h and "bn_bwd_apply" not in h and h["bn_finalize"] == 67 - (66 - 17) == h["bn_bwd_finalize"]
 
 
 def test_inference_program_is_fully_fused():

@@ -313,8 +313,11 @@ class Builder:
         self._last_dgrad: dict[int, tuple] = {}  # id(gradient Buf) -> (op, c0, c1)
         # The finalize launches folded into the streaming launches that consume their coefficients (vt_bn_finalize_apply,
         # vt_bn_bwd_finalize_apply: the first workgroups finalize and publish, every workgroup polls once).  Not with
-        # SyncBatchNorm (the statistics are exchanged in front of the finalize).  VT_BN_FIN_APPLY=0: separate launches.
-        self.bn_fin_apply = os.environ.get("VT_BN_FIN_APPLY", "1") != "0"
+        # SyncBatchNorm (the statistics are exchanged in front of the finalize).  OFF by default: bit-identical, and 2.3 ms
+        # SLOWER in the step -- the coefficients reach every one of up to 4096 workgroups through device-scope (cache-bypassing)
+        # loads behind a polled counter, two dependent round trips at the head of every workgroup, against one ~5 us launch
+        # (NOTEBOOK R6.6).  VT_BN_FIN_APPLY=1 turns it on.
+        self.bn_fin_apply = os.environ.get("VT_BN_FIN_APPLY", "0") != "0"
         self._wg_expect: dict[tuple, int] = {}   # shape key -> units seen in forward and not yet released
         self._wg_pending: dict[tuple, list] = {}  # shape key -> [(x addr, dz addr, dw addr, desc, ldw)]
         # SyncBatchNorm (configs/base.yaml:22): the trainer all-reduces every layer's statistics
