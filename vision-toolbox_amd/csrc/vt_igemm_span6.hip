@@ -334,6 +334,9 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
     if (wave >= 8) {
         // =========================== loader waves ==================================================
         VT_S6_STAMP(0);
+#if defined(VT_SPAN6_SETPRIO) && (VT_SPAN6_SETPRIO & 2)
+        __builtin_amdgcn_s_setprio(2);  // (experiment: the loader wave above both compute waves of its SIMD)
+#endif
         const char* wg = (const char*)p.w;
         const unsigned b_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)(smem + L6::kB);
         const int cin2 = p.Cin * 2;
@@ -717,6 +720,9 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"                                          \
                      : "+v"(acc[i][j])                                                                  \
                      : "v"(__builtin_bit_cast(bf16x8, bfrag)), "v"(__builtin_bit_cast(bf16x8, af[i])))
+#if defined(VT_SPAN6_SETPRIO) && (VT_SPAN6_SETPRIO & 1)
+                    __builtin_amdgcn_s_setprio(1);  // (experiment: the MFMA-issuing wave wins the SIMD's issue arbitration)
+#endif
                     VT_MMA_COL(bf0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     bf0 = *(const uint4*)(Bt + 2304);
@@ -730,6 +736,9 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     VT_MMA_COL(bf0, 3);
+#if defined(VT_SPAN6_SETPRIO) && (VT_SPAN6_SETPRIO & 1)
+                    __builtin_amdgcn_s_setprio(0);
+#endif
 #undef VT_MMA_COL
                     if (VT_DBG(16)) {
                         asm volatile("s_nop 0" ::"v"(acc[FM - 1][3][0]));  // (the last MFMA's result: its issue has happened)
