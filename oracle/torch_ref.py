@@ -298,9 +298,10 @@ def weight_decay_group(key: str, wd: float, norm_wd: float, bias_wd: float) -> f
 
 
 # ---- necks: FPN / PAN, necks.py:45-120 ---------------------------------
-def neck_spec(kind: str, in_channels, out_channels: int) -> "OrderedDict[str, tuple]":
-    """state_dict key -> shape of FPN(in_channels, out_channels) / PAN(...) with the defaults
-    (fuse 'sum', ConvNormAct blocks); a lateral conv exists only where in != out (necks.py:60-65)."""
+def neck_spec(kind: str, in_channels, out_channels: int, fuse: str = "sum") -> "OrderedDict[str, tuple]":
+    """state_dict key -> shape of FPN(in_channels, out_channels) / PAN(...) with ConvNormAct blocks; a lateral conv
+    exists only where in != out (necks.py:60-65); fuse 'concat': the output convs take 2 x out_channels (necks.py:66)."""
+    fin = out_channels if fuse == "sum" else 2 * out_channels
 
     def fpn_spec(out, p, ins):
         for i, c in enumerate(ins):
@@ -308,7 +309,7 @@ def neck_spec(kind: str, in_channels, out_channels: int) -> "OrderedDict[str, tu
                 out[f"{p}lateral_convs.{i}.weight"] = (out_channels, c, 1, 1)
                 out[f"{p}lateral_convs.{i}.bias"] = (out_channels,)
         for i in range(len(ins) - 1):
-            _cna_spec(out, f"{p}output_convs.{i}.", out_channels, out_channels, 3)
+            _cna_spec(out, f"{p}output_convs.{i}.", fin, out_channels, 3)
 
     out = OrderedDict()
     if kind == "fpn":
@@ -321,9 +322,11 @@ def neck_spec(kind: str, in_channels, out_channels: int) -> "OrderedDict[str, tu
     return out
 
 
-def fpn(sd, p, xs, top_down: bool, training: bool):
+def fpn(sd, p, xs, top_down: bool, training: bool, fuse: str = "sum"):
     """FPN.forward (necks.py:83-88): lateral 1x1 convs (biased, no norm), then level by level
-    `fuse([x_dst, upsample(x_src)])` = x_dst + nearest-resampled x_src, then the output ConvNormAct."""
+    `fuse([x_dst, upsample(x_src)])` = x_dst + nearest-resampled x_src (or their channel concatenation, necks.py:14-15),
+    then the output ConvNormAct."""
+    join = (lambda a, b: a + b) if fuse == "sum" else (lambda a, b: torch.cat([a, b], dim=1))
     outs = []
     for i, x in enumerate(xs):
         k = f"{p}lateral_convs.{i}.weight"
@@ -332,18 +335,18 @@ def fpn(sd, p, xs, top_down: bool, training: bool):
     for i in range(n - 1):
         if top_down:  # necks.py:70-73
             d, s = n - 2 - i, n - 1 - i
-            fused = outs[d] + F.interpolate(outs[s], scale_factor=2.0, mode="nearest")
+            fused = join(outs[d], F.interpolate(outs[s], scale_factor=2.0, mode="nearest"))
         else:  # necks.py:76-79
             d, s = i + 1, i
-            fused = outs[d] + F.interpolate(outs[s], scale_factor=0.5, mode="nearest")
+            fused = join(outs[d], F.interpolate(outs[s], scale_factor=0.5, mode="nearest"))
         outs[d] = cna(sd, f"{p}output_convs.{i}.", fused, 1, training)
     return outs
 
 
-def pan(sd, p, xs, training: bool):
+def pan(sd, p, xs, training: bool, fuse: str = "sum"):
     """PAN.forward (necks.py:117-120).  NOTE the reference builds `bottom_up` with FPN's default
     top_down=True (necks.py:109-115), so both passes run top-down; restated as written."""
-    return fpn(sd, p + "bottom_up.", fpn(sd, p + "top_down.", xs, True, training), True, training)
+    return fpn(sd, p + "bottom_up.", fpn(sd, p + "top_down.", xs, True, training, fuse), True, training, fuse)
 
 
 # ---- MixUp / CutMix of the training step (SURVEY 8(f) rank 3): extras.py:14-109, classifier.py:86-92 ----

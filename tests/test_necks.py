@@ -18,7 +18,16 @@ CASES = {  # must match tools/gen_golden_necks.py
     "fpn_td": ("fpn", (16, 32, 64), 32, True, (16, 8, 4), 2),
     "fpn_bu": ("fpn", (16, 32, 64), 32, False, (16, 8, 4), 2),
     "pan": ("pan", (16, 24, 40), 16, True, (16, 8, 4), 2),
+    # round 6: fuse_fn="concat" (necks.py:14-15, 66)
+    "fpn_td_cat": ("fpn", (16, 32, 64), 32, True, (16, 8, 4), 2, "concat"),
+    "fpn_bu_cat": ("fpn", (16, 32, 64), 32, False, (16, 8, 4), 2, "concat"),
+    "pan_cat": ("pan", (16, 24, 40), 16, True, (16, 8, 4), 2, "concat"),
 }
+
+
+def _case(name):
+    c = CASES[name]
+    return c[:6] + ((c[6] if len(c) > 6 else "sum"),)
 
 
 @pytest.fixture(scope="module")
@@ -43,8 +52,8 @@ def _loss(name, ys):
 @pytest.mark.parametrize("name", list(CASES))
 @pytest.mark.parametrize("mode", ["train", "eval"])
 def test_oracle_necks_match_reference_fixtures(gold, name, mode):
-    kind, ins, outc, td, sizes, B = CASES[name]
-    spec = R.neck_spec(kind, ins, outc)
+    kind, ins, outc, td, sizes, B, fuse = _case(name)
+    spec = R.neck_spec(kind, ins, outc, fuse)
     assert list(spec.keys()) == list(gold[f"{name}/keys"])
     assert [str(tuple(s)) for s in spec.values()] == list(gold[f"{name}/shapes"])
     sd = {k: filler.fill_tensor(f"{name}.{k}", torch.zeros(s, dtype=torch.int64 if k.endswith("tracked") else torch.float32))
@@ -52,7 +61,7 @@ def test_oracle_necks_match_reference_fixtures(gold, name, mode):
     params = {k: v.requires_grad_(True) for k, v in sd.items()
               if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))}
     xs = _inputs(name, ins, sizes, B)
-    ys = R.fpn(sd, "", xs, td, mode == "train") if kind == "fpn" else R.pan(sd, "", xs, mode == "train")
+    ys = R.fpn(sd, "", xs, td, mode == "train", fuse) if kind == "fpn" else R.pan(sd, "", xs, mode == "train", fuse)
     _loss(name, ys).backward()
     for i, y in enumerate(ys):
         assert rel(y.detach(), gold[f"{name}/{mode}/y{i}"]) < 1e-6
@@ -70,8 +79,8 @@ def test_oracle_necks_match_reference_fixtures(gold, name, mode):
 def test_neck_modules_keep_the_reference_state_dict(gold, name):
     from vision_toolbox import necks
 
-    kind, ins, outc, td, sizes, B = CASES[name]
-    m = necks.FPN(list(ins), outc, top_down=td) if kind == "fpn" else necks.PAN(list(ins), outc)
+    kind, ins, outc, td, sizes, B, fuse = _case(name)
+    m = necks.FPN(list(ins), outc, fuse_fn=fuse, top_down=td) if kind == "fpn" else necks.PAN(list(ins), outc, fuse_fn=fuse)
     sd = m.state_dict()
     assert list(sd.keys()) == list(gold[f"{name}/keys"])
     assert [str(tuple(v.shape)) for v in sd.values()] == list(gold[f"{name}/shapes"])
@@ -87,8 +96,8 @@ def test_neck_modules_match_reference_fixtures_on_gpu(gold, name, mode, dtype):
     from vision_toolbox import _native as N
     from vision_toolbox import necks
 
-    kind, ins, outc, td, sizes, B = CASES[name]
-    m = necks.FPN(list(ins), outc, top_down=td) if kind == "fpn" else necks.PAN(list(ins), outc)
+    kind, ins, outc, td, sizes, B, fuse = _case(name)
+    m = necks.FPN(list(ins), outc, fuse_fn=fuse, top_down=td) if kind == "fpn" else necks.PAN(list(ins), outc, fuse_fn=fuse)
     filler.fill_module(m, f"{name}.")
     m = m.cuda().train(mode == "train")
     xs = _inputs(name, ins, sizes, B, "cuda", dtype)

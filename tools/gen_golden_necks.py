@@ -21,10 +21,14 @@ from oracle import filler  # noqa: E402
 necks = gen_golden.ref_import("vision_toolbox.necks")
 GOLDEN = ROOT / "tests" / "golden"
 
-CASES = {  # name -> (kind, in_channels, out_channels, top_down, sizes(bottom first), batch)
+CASES = {  # name -> (kind, in_channels, out_channels, top_down, sizes(bottom first), batch[, fuse_fn])
     "fpn_td": ("fpn", (16, 32, 64), 32, True, (16, 8, 4), 2),
     "fpn_bu": ("fpn", (16, 32, 64), 32, False, (16, 8, 4), 2),
     "pan": ("pan", (16, 24, 40), 16, True, (16, 8, 4), 2),
+    # round 6: fuse_fn="concat" (necks.py:14-15, 66: the output conv takes 2 x out_channels)
+    "fpn_td_cat": ("fpn", (16, 32, 64), 32, True, (16, 8, 4), 2, "concat"),
+    "fpn_bu_cat": ("fpn", (16, 32, 64), 32, False, (16, 8, 4), 2, "concat"),
+    "pan_cat": ("pan", (16, 24, 40), 16, True, (16, 8, 4), 2, "concat"),
 }
 
 
@@ -34,9 +38,11 @@ def np_(t):
 
 def main():
     out = {}
-    for name, (kind, ins, outc, td, sizes, B) in CASES.items():
+    for name, case in CASES.items():
+        kind, ins, outc, td, sizes, B = case[:6]
+        fuse = case[6] if len(case) > 6 else "sum"
         torch.manual_seed(0)
-        m = necks.FPN(list(ins), outc, top_down=td) if kind == "fpn" else necks.PAN(list(ins), outc)
+        m = necks.FPN(list(ins), outc, fuse_fn=fuse, top_down=td) if kind == "fpn" else necks.PAN(list(ins), outc, fuse_fn=fuse)
         filler.fill_module(m, f"{name}.")
         out[f"{name}/keys"] = np.array(list(m.state_dict().keys()))
         out[f"{name}/shapes"] = np.array([str(tuple(v.shape)) for v in m.state_dict().values()])

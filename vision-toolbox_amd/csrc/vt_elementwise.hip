@@ -1113,12 +1113,16 @@ template <typename T>
 __global__ void __launch_bounds__(kThreads)
 resample_fwd_kernel(const T* __restrict__ src, int lds, const T* __restrict__ other, int ldo, T* __restrict__ dst,
                     int ldd, int Hd, int Wd, long M, RowMap rm, int mode) {
+    // mode 0 / 1: nearest x2 / x0.5; mode 2 / 3: bilinear x2 / x0.5 (nn.Upsample(mode="bilinear"), align_corners False: a
+    // destination index d reads source coordinate (d + 0.5) / scale - 0.5 -- x2: taps (k - 1, k) with weights (0.25, 0.75)
+    // for d = 2k, (k, k + 1) with (0.75, 0.25) for d = 2k + 1, indices clamped to the map; x0.5: the mean of 2 x 2 pixels)
     constexpr int EPC = VecIO<T>::EPC;
     const int t = threadIdx.x;
     const int r = t / rm.CT;
     if (r >= rm.RT) return;
     const long row0 = (long)blockIdx.x * rm.RT * rm.iters + r;
-    const int Hs = mode ? 2 * Hd : Hd / 2, Ws = mode ? 2 * Wd : Wd / 2;
+    const bool down = mode & 1;
+    const int Hs = down ? 2 * Hd : Hd / 2, Ws = down ? 2 * Wd : Wd / 2;
     for (int col = t % rm.CT; col < rm.CPR; col += rm.CT) {
         for (int it = 0; it < rm.iters; ++it) {
             const long row = row0 + (long)it * rm.RT;
@@ -1126,10 +1130,30 @@ resample_fwd_kernel(const T* __restrict__ src, int lds, const T* __restrict__ ot
             const long b = row / ((long)Hd * Wd);
             const int rem = (int)(row - b * Hd * Wd);
             const int i = rem / Wd, j = rem - i * Wd;
-            const int si = mode ? 2 * i : i >> 1, sj = mode ? 2 * j : j >> 1;
-            const long srow = (b * Hs + si) * Ws + sj;
             float v[EPC];
-            VecIO<T>::unpack(ld16(src + srow * lds + col * EPC), v);
+            if (mode < 2) {
+                const int si = down ? 2 * i : i >> 1, sj = down ? 2 * j : j >> 1;
+                const long srow = (b * Hs + si) * Ws + sj;
+                VecIO<T>::unpack(ld16(src + srow * lds + col * EPC), v);
+            } else {
+                int i0, i1, j0, j1;
+                float wi0, wj0;  // weight of tap 0 (tap 1: 1 - that)
+                if (down) {
+                    i0 = 2 * i, i1 = 2 * i + 1, j0 = 2 * j, j1 = 2 * j + 1, wi0 = 0.5f, wj0 = 0.5f;
+                } else {
+                    const int ki = i >> 1, kj = j >> 1;
+                    i0 = (i & 1) ? ki : max(ki - 1, 0), i1 = (i & 1) ? min(ki + 1, Hs - 1) : ki, wi0 = (i & 1) ? 0.75f : 0.25f;
+                    j0 = (j & 1) ? kj : max(kj - 1, 0), j1 = (j & 1) ? min(kj + 1, Ws - 1) : kj, wj0 = (j & 1) ? 0.75f : 0.25f;
+                }
+                float a[EPC], c[EPC], d[EPC], e4[EPC];
+                VecIO<T>::unpack(ld16(src + ((b * Hs + i0) * Ws + j0) * lds + col * EPC), a);
+                VecIO<T>::unpack(ld16(src + ((b * Hs + i0) * Ws + j1) * lds + col * EPC), c);
+                VecIO<T>::unpack(ld16(src + ((b * Hs + i1) * Ws + j0) * lds + col * EPC), d);
+                VecIO<T>::unpack(ld16(src + ((b * Hs + i1) * Ws + j1) * lds + col * EPC), e4);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e)
+                    v[e] = wi0 * (wj0 * a[e] + (1.f - wj0) * c[e]) + (1.f - wi0) * (wj0 * d[e] + (1.f - wj0) * e4[e]);
+            }
             if (other) {
                 float o[EPC];
                 VecIO<T>::unpack(ld16(other + row * ldo + col * EPC), o);
@@ -1151,7 +1175,15 @@ resample_bwd_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dsrc, in
     const int r = t / rm.CT;
     if (r >= rm.RT) return;
     const long row0 = (long)blockIdx.x * rm.RT * rm.iters + r;
-    const int Hs = mode ? 2 * Hd : Hd / 2, Ws = mode ? 2 * Wd : Wd / 2;
+    const bool down = mode & 1;
+    const int Hs = down ? 2 * Hd : Hd / 2, Ws = down ? 2 * Wd : Wd / 2;
+    // bilinear x2: the weight source index s carries in destination index d (the two taps of d, clamped, that land on s)
+    auto wup = [](int d, int s, int n) -> float {
+        const int k = d >> 1;
+        const int t0 = (d & 1) ? k : max(k - 1, 0), t1 = (d & 1) ? min(k + 1, n - 1) : k;
+        const float w0 = (d & 1) ? 0.75f : 0.25f;
+        return (t0 == s ? w0 : 0.f) + (t1 == s ? 1.f - w0 : 0.f);
+    };
     for (int col = t % rm.CT; col < rm.CPR; col += rm.CT) {
         for (int it = 0; it < rm.iters; ++it) {
             const long row = row0 + (long)it * rm.RT;
@@ -1174,12 +1206,32 @@ resample_bwd_kernel(const T* __restrict__ dy, int lddy, T* __restrict__ dsrc, in
 #pragma unroll
                         for (int e = 0; e < EPC; ++e) a[e] += g[e];
                     }
-            } else if (!(i & 1) && !(j & 1)) {
-                float g[EPC];
-                const long drow = (b * Hd + (i >> 1)) * Wd + (j >> 1);
-                VecIO<T>::unpack(ld16(dy + drow * lddy + col * EPC), g);
+            } else if (mode == 1) {
+                if (!(i & 1) && !(j & 1)) {
+                    float g[EPC];
+                    const long drow = (b * Hd + (i >> 1)) * Wd + (j >> 1);
+                    VecIO<T>::unpack(ld16(dy + drow * lddy + col * EPC), g);
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) a[e] += g[e];
+                    for (int e = 0; e < EPC; ++e) a[e] += g[e];
+                }
+            } else if (mode == 2) {  // destination rows 2i-1 .. 2i+2 (columns alike) may read this source pixel
+                for (int di = max(2 * i - 1, 0); di <= min(2 * i + 2, Hd - 1); ++di) {
+                    const float wi = wup(di, i, Hs);
+                    if (wi == 0.f) continue;
+                    for (int dj = max(2 * j - 1, 0); dj <= min(2 * j + 2, Wd - 1); ++dj) {
+                        const float w = wi * wup(dj, j, Ws);
+                        if (w == 0.f) continue;
+                        float g[EPC];
+                        VecIO<T>::unpack(ld16(dy + ((b * Hd + di) * Wd + dj) * lddy + col * EPC), g);
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) a[e] = fmaf(w, g[e], a[e]);
+                    }
+                }
+            } else if ((i >> 1) < Hd && (j >> 1) < Wd) {  // x0.5 bilinear: a quarter of the destination pixel's gradient
+                float g[EPC];
+                VecIO<T>::unpack(ld16(dy + ((b * Hd + (i >> 1)) * Wd + (j >> 1)) * lddy + col * EPC), g);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) a[e] = fmaf(0.25f, g[e], a[e]);
             }
             st16(dsrc + row * lds + col * EPC, VecIO<T>::pack(a));
         }
@@ -2075,9 +2127,9 @@ int vt_global_avgpool_bwd(const void* dy, int32_t lddy, void* dx, int32_t lddx, 
 
 int vt_resample2x_add_fwd(const void* src, int32_t lds, const void* other, int32_t ldo, void* dst, int32_t ldd,
                           int32_t B, int32_t Hd, int32_t Wd, int32_t C, int32_t mode, int32_t dtype, void* stream) {
-    VT_REQUIRE(B > 0 && Hd > 0 && Wd > 0 && (mode == 0 || mode == 1), VT_ERR_INVALID,
+    VT_REQUIRE(B > 0 && Hd > 0 && Wd > 0 && mode >= 0 && mode <= 3, VT_ERR_INVALID,
                "vt_resample2x_add_fwd: bad argument");
-    VT_REQUIRE(mode == 1 || (Hd % 2 == 0 && Wd % 2 == 0), VT_ERR_UNSUPPORTED,
+    VT_REQUIRE((mode & 1) || (Hd % 2 == 0 && Wd % 2 == 0), VT_ERR_UNSUPPORTED,
                "vt_resample2x_add_fwd: x2 upsampling needs an even destination (%dx%d)", Hd, Wd);
     VT_TRY(check_mat("vt_resample2x_add_fwd(src)", src, lds, C, dtype));
     VT_TRY(check_mat("vt_resample2x_add_fwd(dst)", dst, ldd, C, dtype));
@@ -2094,13 +2146,13 @@ int vt_resample2x_add_fwd(const void* src, int32_t lds, const void* other, int32
 
 int vt_resample2x_bwd(const void* dy, int32_t lddy, void* dsrc, int32_t lds, int32_t B, int32_t Hd, int32_t Wd,
                       int32_t C, int32_t mode, int32_t accumulate, int32_t dtype, void* stream) {
-    VT_REQUIRE(B > 0 && Hd > 0 && Wd > 0 && (mode == 0 || mode == 1), VT_ERR_INVALID,
+    VT_REQUIRE(B > 0 && Hd > 0 && Wd > 0 && mode >= 0 && mode <= 3, VT_ERR_INVALID,
                "vt_resample2x_bwd: bad argument");
-    VT_REQUIRE(mode == 1 || (Hd % 2 == 0 && Wd % 2 == 0), VT_ERR_UNSUPPORTED,
+    VT_REQUIRE((mode & 1) || (Hd % 2 == 0 && Wd % 2 == 0), VT_ERR_UNSUPPORTED,
                "vt_resample2x_bwd: x2 upsampling needs an even destination (%dx%d)", Hd, Wd);
     VT_TRY(check_mat("vt_resample2x_bwd(dy)", dy, lddy, C, dtype));
     VT_TRY(check_mat("vt_resample2x_bwd(dsrc)", dsrc, lds, C, dtype));
-    const int Hs = mode ? 2 * Hd : Hd / 2, Ws = mode ? 2 * Wd : Wd / 2;
+    const int Hs = (mode & 1) ? 2 * Hd : Hd / 2, Ws = (mode & 1) ? 2 * Wd : Wd / 2;
     const long Ms = (long)B * Hs * Ws;
     const RowMap rm = RowMap::make(C, vt_epc(dtype), Ms);
     VT_DISPATCH_T(dtype, "vt_resample2x_bwd",

@@ -37,6 +37,9 @@
 #ifndef VT_SPAN6_FMX
 #define VT_SPAN6_FMX 7
 #endif
+#ifndef VT_SPAN6_SETPRIO
+#define VT_SPAN6_SETPRIO 1  // bit 0: s_setprio(1) around the MFMA tick; bit 1: the loader waves at priority 2 (measured: nothing)
+#endif
 
 namespace {
 
@@ -334,7 +337,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
     if (wave >= 8) {
         // =========================== loader waves ==================================================
         VT_S6_STAMP(0);
-#if defined(VT_SPAN6_SETPRIO) && (VT_SPAN6_SETPRIO & 2)
+#if VT_SPAN6_SETPRIO & 2
         __builtin_amdgcn_s_setprio(2);  // (experiment: the loader wave above both compute waves of its SIMD)
 #endif
         const char* wg = (const char*)p.w;
@@ -720,8 +723,11 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"                                          \
                      : "+v"(acc[i][j])                                                                  \
                      : "v"(__builtin_bit_cast(bf16x8, bfrag)), "v"(__builtin_bit_cast(bf16x8, af[i])))
-#if defined(VT_SPAN6_SETPRIO) && (VT_SPAN6_SETPRIO & 1)
-                    __builtin_amdgcn_s_setprio(1);  // (experiment: the MFMA-issuing wave wins the SIMD's issue arbitration)
+#if VT_SPAN6_SETPRIO & 1
+                    // the MFMA-issuing wave wins its SIMD's issue arbitration against the wave that reads fragments and the
+                    // loader (the guide's T2): 128 -> 128 @28x28 65.7 -> 63.2 us alone, 128 @56x56 260 -> 257, the other shapes
+                    // and the step unchanged (N R6.8); the loaders raised instead, or as well: nothing
+                    __builtin_amdgcn_s_setprio(1);
 #endif
                     VT_MMA_COL(bf0, 0);
                     __builtin_amdgcn_sched_barrier(0);
@@ -736,7 +742,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     VT_MMA_COL(bf0, 3);
-#if defined(VT_SPAN6_SETPRIO) && (VT_SPAN6_SETPRIO & 1)
+#if VT_SPAN6_SETPRIO & 1
                     __builtin_amdgcn_s_setprio(0);
 #endif
 #undef VT_MMA_COL

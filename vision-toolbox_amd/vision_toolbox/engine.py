@@ -1237,8 +1237,9 @@ class Builder:
             self.nodes.append(bwd)
         return t
 
-    def resample_add(self, src: TRef, other: Optional[TRef], mode: int, name="resample") -> TRef:
-        """nearest x2 (mode 0) / x0.5 (mode 1) resampling of `src` plus `other` (necks.py:66-81)."""
+    def resample_add(self, src: TRef, other: Optional[TRef], mode: int, name="resample", out: Optional[TRef] = None) -> TRef:
+        """nearest x2 (mode 0) / x0.5 (mode 1) resampling of `src` plus `other` (necks.py:66-81); `out`: write into this
+        tensor (a channel slice of a concat buffer: fuse_fn="concat") instead of a fresh one."""
         self.tag += 1
         if mode == 0:
             Hd, Wd = src.H * 2, src.W * 2
@@ -1248,7 +1249,8 @@ class Builder:
             Hd, Wd = src.H // 2, src.W // 2
         if other is not None:
             assert (other.B, other.H, other.W, other.C) == (src.B, Hd, Wd, src.C), "fuse operands differ in shape"
-        y = self.act(src.B, Hd, Wd, src.C, name)
+        y = out if out is not None else self.act(src.B, Hd, Wd, src.C, name)
+        assert (y.B, y.H, y.W, y.C) == (src.B, Hd, Wd, src.C)
         self.emit(N.OP_RESAMPLE_FWD, [src.addr(), other.addr() if other is not None else None, y.addr()],
                   [src.ld, other.ld if other is not None else 0, y.ld, src.B, Hd, Wd, src.C, mode, self.dtype])
         if self.need_grad and (src.needs_grad or (other is not None and other.needs_grad)):

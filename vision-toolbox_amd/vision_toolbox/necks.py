@@ -187,8 +187,10 @@ class FPN(_NeckBase):
         self.output_convs = nn.ModuleList([block(in_c, out_channels) for _ in range(len(in_channels_list) - 1)])
 
     def _vt_emit_list(self, b, xs, name: str = "fpn"):
-        if self.fuse_fn != "sum" or self.interpolation_mode != "nearest":
-            raise NotImplementedError("the MI355X neck implements the reference defaults: fuse_fn='sum', nearest")
+        if self.fuse_fn not in ("sum", "concat") or self.interpolation_mode != "nearest":
+            # ('avg' / 'max' cannot run in the reference either: its output convs are built for 2 x out_channels whenever
+            #  fuse_fn != 'sum', necks.py:66, while those two fuse functions return out_channels)
+            raise NotImplementedError("the MI355X neck implements fuse_fn 'sum' / 'concat' with nearest resampling")
         assert len(xs) == len(self.lateral_convs)
         outs = []
         for i, (lat, x) in enumerate(zip(self.lateral_convs, xs)):
@@ -200,25 +202,31 @@ class FPN(_NeckBase):
         for i, oc in enumerate(self.output_convs):
             if not isinstance(oc, ConvNormAct):
                 raise NotImplementedError("neck blocks other than ConvNormAct are outside the hot path")
-            if self.top_down:  # levels n-2, ..., 0 receive the level above, upsampled (necks.py:70-73)
-                dst, src = n - 2 - i, n - 1 - i
-                fused = b.resample_add(outs[src], outs[dst], 0, name=f"{name}.fuse.{dst}")
-            else:  # levels 1, ..., n-1 receive the level below, subsampled (necks.py:76-79)
-                dst, src = i + 1, i
-                fused = b.resample_add(outs[src], outs[dst], 1, name=f"{name}.fuse.{dst}")
+            # top-down: levels n-2, ..., 0 receive the level above, upsampled (necks.py:70-73); bottom-up: levels 1, ..., n-1
+            # the level below, subsampled (necks.py:76-79)
+            dst, src = (n - 2 - i, n - 1 - i) if self.top_down else (i + 1, i)
+            mode = 0 if self.top_down else 1
+            if self.fuse_fn == "sum":
+                fused = b.resample_add(outs[src], outs[dst], mode, name=f"{name}.fuse.{dst}")
+            else:  # torch.cat([x_dst, resample(x_src)], dim=1) (necks.py:14-15): two channel slices of one buffer
+                d = outs[dst]
+                fused = b.act(d.B, d.H, d.W, 2 * d.C, f"{name}.cat.{dst}")
+                b.copy(d, fused.sl(0, d.C))
+                b.resample_add(outs[src], None, mode, name=f"{name}.fuse.{dst}", out=fused.sl(d.C, d.C))
             outs[dst] = oc._vt_emit(b, fused, name=f"{name}.output_convs.{i}")
         return outs
 
     def _eager_list(self, xs):
         """CPU tensors: the same wiring with torch ops over this module's children."""
-        if self.fuse_fn != "sum":
-            raise NotImplementedError("fuse_fn other than 'sum' is outside the hot path")
+        if self.fuse_fn not in ("sum", "concat"):
+            raise NotImplementedError("fuse_fn 'sum' / 'concat' (the reference's 'avg' / 'max' cannot run there either)")
         assert len(xs) == len(self.lateral_convs)
         outs = [lat(x) for lat, x in zip(self.lateral_convs, xs)]
         n = len(outs)
         for i, oc in enumerate(self.output_convs):
             dst, src = (n - 2 - i, n - 1 - i) if self.top_down else (i + 1, i)
-            outs[dst] = oc(outs[dst] + self.upsample(outs[src]))
+            up = self.upsample(outs[src])
+            outs[dst] = oc(outs[dst] + up if self.fuse_fn == "sum" else torch.cat([outs[dst], up], dim=1))
         return outs
 
 
