@@ -365,13 +365,18 @@ int vt_global_avgpool_bwd(const void* dy, int32_t lddy, void* dx, int32_t lddx, 
  * that follows it (`aggregate_sum`, necks.py:19-23):
  *   mode 0 (top-down):  dst[b][i][j] = src[b][i/2][j/2] (+ other[b][i][j]);  src is [B][Hd/2][Wd/2][C]
  *   mode 1 (bottom-up): dst[b][i][j] = src[b][2i][2j]   (+ other[b][i][j]);  src is [B][2Hd][2Wd][C]
- * dst / other are [B][Hd][Wd][C]; `other` may be NULL. */
+ * dst / other are [B][Hd][Wd][C]; `other` may be NULL.
+ * Round 6: `mode="bilinear"` (align_corners False, what nn.Upsample computes):
+ *   mode 2 (x2):   destination index d reads source coordinate d/2 - 1/4: taps (k-1, k) with weights (1/4, 3/4) for d = 2k,
+ *                  (k, k+1) with (3/4, 1/4) for d = 2k+1, indices clamped to the map, rows and columns alike
+ *   mode 3 (x0.5): dst[b][i][j] = mean of src[b][2i..2i+1][2j..2j+1] */
 int vt_resample2x_add_fwd(const void* src, int32_t lds, const void* other, int32_t ldo, void* dst,
                           int32_t ldd, int32_t B, int32_t Hd, int32_t Wd, int32_t C, int32_t mode,
                           int32_t dtype, void* stream);
 /* gradient w.r.t. src of the above (the `other` branch is the identity):
  *   mode 0: dsrc[b][i][j] (+)= sum of the 2x2 block dy[b][2i..2i+1][2j..2j+1]
  *   mode 1: dsrc[b][i][j] (+)= (i, j both even) ? dy[b][i/2][j/2] : 0
+ *   mode 2 / 3: the transposes of the bilinear maps above (mode 3: a quarter of dy[b][i/2][j/2])
  * dy is [B][Hd][Wd][C]. */
 int vt_resample2x_bwd(const void* dy, int32_t lddy, void* dsrc, int32_t lds, int32_t B, int32_t Hd,
                       int32_t Wd, int32_t C, int32_t mode, int32_t accumulate, int32_t dtype,

@@ -322,7 +322,7 @@ def neck_spec(kind: str, in_channels, out_channels: int, fuse: str = "sum") -> "
     return out
 
 
-def fpn(sd, p, xs, top_down: bool, training: bool, fuse: str = "sum"):
+def fpn(sd, p, xs, top_down: bool, training: bool, fuse: str = "sum", interp: str = "nearest"):
     """FPN.forward (necks.py:83-88): lateral 1x1 convs (biased, no norm), then level by level
     `fuse([x_dst, upsample(x_src)])` = x_dst + nearest-resampled x_src (or their channel concatenation, necks.py:14-15),
     then the output ConvNormAct."""
@@ -335,18 +335,18 @@ def fpn(sd, p, xs, top_down: bool, training: bool, fuse: str = "sum"):
     for i in range(n - 1):
         if top_down:  # necks.py:70-73
             d, s = n - 2 - i, n - 1 - i
-            fused = join(outs[d], F.interpolate(outs[s], scale_factor=2.0, mode="nearest"))
+            fused = join(outs[d], F.interpolate(outs[s], scale_factor=2.0, mode=interp))
         else:  # necks.py:76-79
             d, s = i + 1, i
-            fused = join(outs[d], F.interpolate(outs[s], scale_factor=0.5, mode="nearest"))
+            fused = join(outs[d], F.interpolate(outs[s], scale_factor=0.5, mode=interp))
         outs[d] = cna(sd, f"{p}output_convs.{i}.", fused, 1, training)
     return outs
 
 
-def pan(sd, p, xs, training: bool, fuse: str = "sum"):
+def pan(sd, p, xs, training: bool, fuse: str = "sum", interp: str = "nearest"):
     """PAN.forward (necks.py:117-120).  NOTE the reference builds `bottom_up` with FPN's default
     top_down=True (necks.py:109-115), so both passes run top-down; restated as written."""
-    return fpn(sd, p + "bottom_up.", fpn(sd, p + "top_down.", xs, True, training, fuse), True, training, fuse)
+    return fpn(sd, p + "bottom_up.", fpn(sd, p + "top_down.", xs, True, training, fuse, interp), True, training, fuse, interp)
 
 
 # ---- MixUp / CutMix of the training step (SURVEY 8(f) rank 3): extras.py:14-109, classifier.py:86-92 ----

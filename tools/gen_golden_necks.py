@@ -29,6 +29,10 @@ CASES = {  # name -> (kind, in_channels, out_channels, top_down, sizes(bottom fi
     "fpn_td_cat": ("fpn", (16, 32, 64), 32, True, (16, 8, 4), 2, "concat"),
     "fpn_bu_cat": ("fpn", (16, 32, 64), 32, False, (16, 8, 4), 2, "concat"),
     "pan_cat": ("pan", (16, 24, 40), 16, True, (16, 8, 4), 2, "concat"),
+    # interpolation_mode="bilinear" (nn.Upsample, necks.py:65), both directions
+    "fpn_td_bil": ("fpn", (16, 32, 64), 32, True, (16, 8, 4), 2, "sum", "bilinear"),
+    "fpn_bu_bil": ("fpn", (16, 32, 64), 32, False, (16, 8, 4), 2, "sum", "bilinear"),
+    "pan_cat_bil": ("pan", (16, 24, 40), 16, True, (16, 8, 4), 2, "concat", "bilinear"),
 }
 
 
@@ -41,8 +45,10 @@ def main():
     for name, case in CASES.items():
         kind, ins, outc, td, sizes, B = case[:6]
         fuse = case[6] if len(case) > 6 else "sum"
+        interp = case[7] if len(case) > 7 else "nearest"
         torch.manual_seed(0)
-        m = necks.FPN(list(ins), outc, fuse_fn=fuse, top_down=td) if kind == "fpn" else necks.PAN(list(ins), outc, fuse_fn=fuse)
+        m = (necks.FPN(list(ins), outc, fuse_fn=fuse, interpolation_mode=interp, top_down=td) if kind == "fpn"
+             else necks.PAN(list(ins), outc, fuse_fn=fuse, interpolation_mode=interp))
         filler.fill_module(m, f"{name}.")
         out[f"{name}/keys"] = np.array(list(m.state_dict().keys()))
         out[f"{name}/shapes"] = np.array([str(tuple(v.shape)) for v in m.state_dict().values()])

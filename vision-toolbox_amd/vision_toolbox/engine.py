@@ -1238,14 +1238,15 @@ class Builder:
         return t
 
     def resample_add(self, src: TRef, other: Optional[TRef], mode: int, name="resample", out: Optional[TRef] = None) -> TRef:
-        """nearest x2 (mode 0) / x0.5 (mode 1) resampling of `src` plus `other` (necks.py:66-81); `out`: write into this
-        tensor (a channel slice of a concat buffer: fuse_fn="concat") instead of a fresh one."""
+        """nearest x2 (mode 0) / x0.5 (mode 1) or bilinear x2 (mode 2) / x0.5 (mode 3) resampling of `src` plus `other`
+        (necks.py:66-81); `out`: write into this tensor (a channel slice of a concat buffer: fuse_fn="concat") instead of
+        a fresh one."""
         self.tag += 1
-        if mode == 0:
+        if mode in (0, 2):
             Hd, Wd = src.H * 2, src.W * 2
         else:
             if src.H % 2 or src.W % 2:
-                raise NotImplementedError("x0.5 nearest resampling of an odd-sized map")
+                raise NotImplementedError("x0.5 resampling of an odd-sized map")
             Hd, Wd = src.H // 2, src.W // 2
         if other is not None:
             assert (other.B, other.H, other.W, other.C) == (src.B, Hd, Wd, src.C), "fuse operands differ in shape"

@@ -187,10 +187,10 @@ class FPN(_NeckBase):
         self.output_convs = nn.ModuleList([block(in_c, out_channels) for _ in range(len(in_channels_list) - 1)])
 
     def _vt_emit_list(self, b, xs, name: str = "fpn"):
-        if self.fuse_fn not in ("sum", "concat") or self.interpolation_mode != "nearest":
+        if self.fuse_fn not in ("sum", "concat") or self.interpolation_mode not in ("nearest", "bilinear"):
             # ('avg' / 'max' cannot run in the reference either: its output convs are built for 2 x out_channels whenever
             #  fuse_fn != 'sum', necks.py:66, while those two fuse functions return out_channels)
-            raise NotImplementedError("the MI355X neck implements fuse_fn 'sum' / 'concat' with nearest resampling")
+            raise NotImplementedError("the MI355X neck implements fuse_fn 'sum' / 'concat' with nearest / bilinear resampling")
         assert len(xs) == len(self.lateral_convs)
         outs = []
         for i, (lat, x) in enumerate(zip(self.lateral_convs, xs)):
@@ -205,7 +205,7 @@ class FPN(_NeckBase):
             # top-down: levels n-2, ..., 0 receive the level above, upsampled (necks.py:70-73); bottom-up: levels 1, ..., n-1
             # the level below, subsampled (necks.py:76-79)
             dst, src = (n - 2 - i, n - 1 - i) if self.top_down else (i + 1, i)
-            mode = 0 if self.top_down else 1
+            mode = (0 if self.top_down else 1) + (2 if self.interpolation_mode == "bilinear" else 0)
             if self.fuse_fn == "sum":
                 fused = b.resample_add(outs[src], outs[dst], mode, name=f"{name}.fuse.{dst}")
             else:  # torch.cat([x_dst, resample(x_src)], dim=1) (necks.py:14-15): two channel slices of one buffer
