@@ -132,6 +132,23 @@ int vt_conv_dgrad_bnred(const vt_conv_desc* d, const void* dz, const void* w, vo
                         const float* scale, const float* shift, const float* mean, const float* invstd,
                         int32_t relu, float* sums, void* stream);
 
+/* Depthwise convolution (round 6): nn.Conv2d(C, C, k, stride s, padding pad, dilation dil, groups=C, bias=False) inside a
+ * ConvNormAct (components.py:26-35 with `groups = in_channels`) -- forward, data gradient, filter gradient.  x / dx are
+ * [B][Hi][Wi][C], z / dz [B][Ho][Wo][C] with Ho = (Hi + 2 pad - dil (k-1) - 1) / s + 1; `w` / `dw` are the f32 [C][k*k]
+ * image of the torch [C, 1, k, k] weight (bf16 launches round the filter as the convolution kernels' bf16 mirror does).
+ *   vt_dwconv_fwd:   z = conv(x, w); `stats` non-NULL: also the per-channel sum / sum of squares of the STORED z (a
+ *                    statistics buffer, VT_STAT_REPLICAS: the contract of vt_conv_igemm's VT_CONV_STATS)
+ *   vt_dwconv_dgrad: dx = conv_transpose(dz, w) (+ residual, which may alias dx)
+ *   vt_dwconv_wgrad: dw[c][t] += sum_pixels dz * x_shifted  (f32 atomics)
+ * C a multiple of 8 (bf16) / 4 (f32), k <= 7.  Off the Darknet / VoVNet path; streaming kernels, no matrix pipe. */
+int vt_dwconv_fwd(const void* x, int32_t ldx, const float* w, void* z, int32_t ldz, float* stats, int32_t B, int32_t Hi,
+                  int32_t Wi, int32_t C, int32_t k, int32_t s, int32_t pad, int32_t dil, int32_t dtype, void* stream);
+int vt_dwconv_dgrad(const void* dz, int32_t lddz, const float* w, void* dx, int32_t lddx, const void* residual, int32_t ldr,
+                    int32_t B, int32_t Hi, int32_t Wi, int32_t C, int32_t k, int32_t s, int32_t pad, int32_t dil,
+                    int32_t dtype, void* stream);
+int vt_dwconv_wgrad(const void* x, int32_t ldx, const void* dz, int32_t lddz, float* dw, int32_t B, int32_t Hi, int32_t Wi,
+                    int32_t C, int32_t k, int32_t s, int32_t pad, int32_t dil, int32_t dtype, void* stream);
+
 /* Filter gradient: dw[n][t][c] += sum_pixels dz(pix,n) * x_gathered(pix,t,c),
  * fp32 accumulation straight into the (channels_last) .grad of the weight.
  * `d` is the forward descriptor (ldy = pixel stride of dz).  Replaces the
@@ -502,6 +519,9 @@ enum vt_op_kind {
     VT_OP_BN_BWD_FUSED,     /* vt_bn_act_bwd_fused (BatchNorm backward of a unit: reduce, finalize, apply in one launch) */
     VT_OP_BN_FIN_APPLY,     /* vt_bn_finalize_apply */
     VT_OP_BN_BWD_FIN_APPLY, /* vt_bn_bwd_finalize_apply */
+    VT_OP_DWCONV_FWD,       /* vt_dwconv_fwd */
+    VT_OP_DWCONV_DGRAD,     /* vt_dwconv_dgrad */
+    VT_OP_DWCONV_WGRAD,     /* vt_dwconv_wgrad */
     VT_OP_KIND_END
 };
 

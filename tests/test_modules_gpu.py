@@ -561,6 +561,12 @@ VARIANTS = [  # Cin, Cout, k, s, kwargs
     (16, 24, 3, 1, dict(norm="none", act="none")),
     (32, 32, 3, 1, dict(groups=2, dilation=2, norm="none", act="silu")),
     (32, 32, 3, 2, dict(groups=2, dilation=2, act="leaky_relu")),
+    # round 6: depthwise (groups = in_channels = out_channels; vt_dwconv.hip)
+    (16, 16, 3, 1, dict(groups=16)),
+    (24, 24, 3, 2, dict(groups=24)),
+    (16, 16, 5, 1, dict(groups=16, dilation=2, act="silu")),
+    (32, 32, 3, 2, dict(groups=32, norm="none", act="relu")),
+    (16, 16, 1, 1, dict(groups=16, norm="none", act="none")),
 ]
 
 

@@ -174,6 +174,15 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
         case VT_OP_BN_BWD_FINALIZE:  // ptr: sums scale mean invstd dgamma dbeta coef | i: C train | f: count pscale(0 = 1)
             return vt_bn_bwd_finalize((const float*)P[0], I[0], F[0], F[1] == 0.0 ? 1.0 : F[1], (const float*)P[1], (const float*)P[2],
                                       (const float*)P[3], I[1], (float*)P[4], (float*)P[5], (float*)P[6], st);
+        // depthwise convolution: i: ld0 ld1 [ldr] B Hi Wi C k s pad dil dtype
+        case VT_OP_DWCONV_FWD:  // ptr: x w z stats | i: ldx ldz _ B Hi Wi C k s pad dil dtype
+            return vt_dwconv_fwd(P[0], I[0], (const float*)P[1], P[2], I[1], (float*)P[3], I[3], I[4], I[5], I[6], I[7], I[8], I[9],
+                                 I[10], I[11], st);
+        case VT_OP_DWCONV_DGRAD:  // ptr: dz w dx residual | i: lddz lddx ldr B Hi Wi C k s pad dil dtype
+            return vt_dwconv_dgrad(P[0], I[0], (const float*)P[1], P[2], I[1], P[3], I[2], I[3], I[4], I[5], I[6], I[7], I[8], I[9],
+                                   I[10], I[11], st);
+        case VT_OP_DWCONV_WGRAD:  // ptr: x dz dw | i: ldx lddz _ B Hi Wi C k s pad dil dtype
+            return vt_dwconv_wgrad(P[0], I[0], P[1], I[1], (float*)P[2], I[3], I[4], I[5], I[6], I[7], I[8], I[9], I[10], I[11], st);
         case VT_OP_BN_FIN_APPLY:  // ptr: stats gamma beta rm rv nbt scale shift mean invstd ready z residual y | i: C ldz ldr ldy relu dtype | f: count eps momentum M
             return vt_bn_finalize_apply((const float*)P[0], I[0], F[0], (const float*)P[1], (const float*)P[2], (float)F[1], (float)F[2],
                                         (float*)P[3], (float*)P[4], (int64_t*)P[5], (float*)P[6], (float*)P[7], (float*)P[8],

@@ -96,7 +96,10 @@ VT_OP_MAX_PTR, VT_OP_MAX_INT, VT_OP_MAX_FLT, VT_MAX_BASES = 16, 110, 8, 16
     OP_BN_BWD_FUSED,
     OP_BN_FIN_APPLY,
     OP_BN_BWD_FIN_APPLY,
-) = range(1, 44)
+    OP_DWCONV_FWD,
+    OP_DWCONV_DGRAD,
+    OP_DWCONV_WGRAD,
+) = range(1, 47)
 OP_SIDE_STREAM = 0x10000  # OR-ed into Op.kind: enqueue on the side stream
 
 OP_NAMES = {
@@ -123,6 +126,9 @@ OP_NAMES = {
     OP_BN_BWD_FUSED: "bn_bwd_fused",
     OP_BN_FIN_APPLY: "bn_fin_apply",
     OP_BN_BWD_FIN_APPLY: "bn_bwd_fin_apply",
+    OP_DWCONV_FWD: "dwconv_fwd",
+    OP_DWCONV_DGRAD: "dwconv_dgrad",
+    OP_DWCONV_WGRAD: "dwconv_wgrad",
     OP_SGD: "sgd",
     OP_COPY2D: "copy2d",
     OP_NCHW_TO_NHWC: "nchw_to_nhwc",
@@ -216,6 +222,9 @@ SYMBOLS = {
     "vt_conv_igemm": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vt_conv_dgrad_bnred": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "vt_conv_wgrad": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i32, _vp]),
+    "vt_dwconv_fwd": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp] + [_i32] * 9 + [_vp]),
+    "vt_dwconv_dgrad": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32] + [_i32] * 9 + [_vp]),
+    "vt_dwconv_wgrad": (_i32, [_vp, _i32, _vp, _i32, _vp] + [_i32] * 9 + [_vp]),
     "vt_bn_act_bwd_fused": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, C.c_int64, _i32, _i32, _i32, _f64, _f64, _i32, _vp, _vp,
                                    _vp, _vp, _vp, _vp, _i32, _vp]),
     "vt_bn_bwd_fused_timeouts": (_i32, [C.POINTER(C.c_uint32)]),

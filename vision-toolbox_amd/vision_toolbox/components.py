@@ -11,7 +11,7 @@ CPU tensors run the children with plain torch ops (`_eager_maps`), as in the ref
 
 Every constructor argument of the reference unit runs on the GPU: the Darknet / VoVNet configuration (bn + relu, groups
 = dilation = 1) on the fused kernels; other activations, `groups` (>= one 16-byte channel chunk per group), `dilation`
-and norm="none" on the general kernels (engine.Builder.conv_unit / _grouped_unit).  Depthwise groups raise.
+and norm="none" on the general kernels (engine.Builder.conv_unit / _grouped_unit).  Depthwise units (groups = in_channels = out_channels) run on the streaming kernels of vt_dwconv.hip (round 6); other groups narrower than a 16-byte channel slice raise.
 """
 from __future__ import annotations
 

@@ -916,10 +916,13 @@ class Builder:
         epc = _EPC[self.dtype]
         if getattr(x, "logical_C", x.C) != Cin or x.C != Cin:
             raise ValueError(f"conv expects {Cin} (unpadded) input channels, got {getattr(x, 'logical_C', x.C)}")
+        if ci == 1 and co == 1 and Cin % epc == 0:
+            return self._depthwise_unit(x, conv, norm, relu, residual, out, name, pool_out)
         if ci % epc or co % epc:
             raise NotImplementedError(
                 f"groups={G} with {ci} -> {co} channels per group: channel slices are addressed in 16-byte chunks "
-                f"({epc} elements); depthwise / narrow groups are outside the hot path")
+                f"({epc} elements); narrow groups other than depthwise (groups = in_channels = out_channels) are outside the "
+                "hot path")
         k, s, pad, dil = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0]
         Ho = (x.H + 2 * pad - dil * (k - 1) - 1) // s + 1
         Wo = (x.W + 2 * pad - dil * (k - 1) - 1) // s + 1
@@ -946,6 +949,103 @@ class Builder:
                            out=y.sl(g * co, co), name=f"{name}.g{g}")
         if pool_out is not None:
             self.maxpool3x3s2(y, out=pool_out, name=name + ".max_pool")
+        return y
+
+    def _depthwise_unit(self, x: TRef, conv, norm, relu, residual, out, name, pool_out) -> TRef:
+        """nn.Conv2d(C, C, k, groups=C) inside a ConvNormAct (reference components.py:26-44 with `groups = in_channels`):
+        vt_dwconv_fwd (+ batch statistics) -> the ordinary BatchNorm finalize / normalise passes; backward: the ordinary
+        BatchNorm backward -> vt_dwconv_wgrad (side stream) and vt_dwconv_dgrad.  Streaming kernels (round 6): off the
+        Darknet / VoVNet path, present so that every `groups` the constructor accepts runs on the GPU."""
+        Cc = conv.in_channels
+        k, s, pad, dil = conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0]
+        B = x.B
+        Ho = (x.H + 2 * pad - dil * (k - 1) - 1) // s + 1
+        Wo = (x.W + 2 * pad - dil * (k - 1) - 1) // s + 1
+        M, dt = B * Ho * Wo, self.dtype
+        if self.deterministic:
+            raise NotImplementedError("depthwise filter gradients use f32 atomics: not available in deterministic mode")
+        y = out if out is not None else self.act(B, Ho, Wo, Cc, name + ".y")
+        assert (y.B, y.H, y.W, y.C) == (B, Ho, Wo, Cc), "out geometry mismatch"
+        has_bn = isinstance(norm, nn.BatchNorm2d)
+        # (the unit follows ITS BatchNorm's flag, as conv_unit does)
+        training = bool(norm.training) if has_bn else self.training
+        track = self.need_grad
+        self.tag += 1
+        self.n_units += 1
+        w = conv.weight
+        wptr = self.pref(w)  # the f32 master [C][k*k] (the kernels round it for bf16 launches)
+        geo = [B, x.H, x.W, Cc, k, s, pad, dil, dt]
+        z = self.act(B, Ho, Wo, Cc, name + ".z") if (has_bn or relu) else y
+        cp = None
+        if has_bn:
+            coef = self.f32(4 * Cc, "bncoef")
+            cp = [self.bp(coef, i * Cc * 4) for i in range(4)]
+            g, b_, rm, rv = (self.pref(norm.weight), self.pref(norm.bias), self.pref(norm.running_mean),
+                             self.pref(norm.running_var))
+            nbt = self.pref(norm.num_batches_tracked) if norm.num_batches_tracked is not None else None
+            if training:
+                stats = self.zeroed_f32(N.stat_floats(Cc), "stats")
+                self.emit(N.OP_DWCONV_FWD, [x.addr(), wptr, z.addr(), self.bp(stats)], [x.ld, z.ld, 0] + geo)
+                self.emit(N.OP_BN_FINALIZE, [self.bp(stats), g, b_, rm, rv, nbt, *cp], [Cc],
+                          [M * self.bn_world, norm.eps, norm.momentum])
+            else:
+                self.emit(N.OP_DWCONV_FWD, [x.addr(), wptr, z.addr(), None], [x.ld, z.ld, 0] + geo)
+                self.emit(N.OP_BN_EVAL_COEFFS, [g, b_, rm, rv, *cp], [Cc], [norm.eps])
+            self.emit(N.OP_BN_ACT_APPLY, [z.addr(), cp[0], cp[1], residual.addr() if residual else None, y.addr()],
+                      [z.ld, residual.ld if residual else 0, y.ld, Cc, int(relu), dt], [M])
+        else:
+            self.emit(N.OP_DWCONV_FWD, [x.addr(), wptr, z.addr(), None], [x.ld, z.ld, 0] + geo)
+            bias = self.pref(conv.bias) if conv.bias is not None else None
+            if z is not y or bias is not None or residual is not None:
+                # (biased conv -> activation: the unit-scale form of the normalise pass, shift = the bias)
+                self.emit(N.OP_BN_ACT_APPLY, [z.addr(), None, bias, residual.addr() if residual else None, y.addr()],
+                          [z.ld, residual.ld if residual else 0, y.ld, Cc, int(relu), dt], [M])
+        if pool_out is not None:
+            self.maxpool3x3s2(y, out=pool_out, name=name + ".max_pool")
+        if track:
+            tag = self.tag
+
+            def bwd():
+                self.tag = tag
+                dy = self.grad_read(y)
+                if dy is None:
+                    return
+                if residual is not None:
+                    self.grad_add(residual, dy)
+                if has_bn:
+                    sums = self.zeroed_f32(N.stat_floats(Cc), "bwdsums")
+                    self.emit(N.OP_BN_BWD_REDUCE, [dy.addr(), z.addr(), cp[0], cp[1], cp[2], cp[3], self.bp(sums)],
+                              [dy.ld, z.ld, Cc, int(relu), dt], [M])
+                    bcoef = self.f32(3 * Cc, "bwdcoef")
+                    self.emit(N.OP_BN_BWD_FINALIZE,
+                              [self.bp(sums), cp[0], cp[2], cp[3], self.pgrad(norm.weight), self.pgrad(norm.bias), self.bp(bcoef)],
+                              [Cc, int(training)], [M * self.bn_world, 1.0 / self.bn_world])
+                    dz = self.act(B, Ho, Wo, Cc, name + ".dz")
+                    self.emit(N.OP_BN_BWD_APPLY, [dy.addr(), z.addr(), cp[0], cp[1], self.bp(bcoef), dz.addr()],
+                              [dy.ld, z.ld, dz.ld, Cc, int(relu), dt], [M])
+                else:
+                    dz = dy
+                    if relu:  # dz = dy * act'(z + bias): the coefficient-free form reads the pre-activation it is given
+                        zb = z
+                        if conv.bias is not None:  # act' is taken at z + bias: form it once
+                            zb = self.act(B, Ho, Wo, Cc, name + ".zb")
+                            self.emit(N.OP_BN_ACT_APPLY, [z.addr(), None, self.pref(conv.bias), None, zb.addr()],
+                                      [z.ld, 0, zb.ld, Cc, 0, dt], [M])
+                        dz = self.act(B, Ho, Wo, Cc, name + ".dz")
+                        self.emit(N.OP_BN_BWD_APPLY, [dy.addr(), zb.addr(), None, None, None, dz.addr()],
+                                  [dy.ld, zb.ld, dz.ld, Cc, int(relu), dt], [M])
+                    if conv.bias is not None and conv.bias.requires_grad:
+                        self.emit(N.OP_COLSUM, [dz.addr(), self.pgrad(conv.bias)], [dz.ld, Cc, dt], [M])
+                if w.requires_grad:
+                    self.emit(N.OP_FORK)
+                    self.emit(N.OP_DWCONV_WGRAD, [x.addr(), dz.addr(), self.pgrad(w)], [x.ld, dz.ld, 0] + geo, side=True)
+                if x.needs_grad:
+                    gx, res = self.grad_target(x)
+                    self.emit(N.OP_DWCONV_DGRAD, [dz.addr(), wptr, gx.addr(), res.addr() if res is not None else None],
+                              [dz.ld, gx.ld, res.ld if res is not None else 0] + geo)
+                    self.grad_written(x)
+
+            self.nodes.append(bwd)
         return y
 
     # -- pointwise (1x1) units without stored pre-activations (vt_pointwise.hip) ------------------------------------
