@@ -509,7 +509,7 @@ def test_conv_norm_act_other_activations_forward_backward(act, k, s, dtype):
         m = dev.cpu()
 
 
-def _variant_check(m, ref, x, dtype, fwd_ref, params):
+def _variant_check(m, ref, x, dtype, fwd_ref, params, bf16_slack=1.0):
     """one train and one eval pass of HipModule `m` on the GPU against the float64 `ref` (same parameters) on the CPU"""
     f32 = dtype == torch.float32
     for training in (True, False):
@@ -518,7 +518,7 @@ def _variant_check(m, ref, x, dtype, fwd_ref, params):
         #  terms by percents; with the same operands what remains is the rounding of the stored activations: 2e-3 to 1.7e-2, 3e-2 allowed.
         #  In train mode BatchNorm backward subtracts the gradient's per-channel projections (most of it, at ~500 samples per
         #  channel) and so amplifies that rounding (module docstring): 1.7-3.9e-2 measured, 8e-2 allowed; f32 is the strict run.
-        gtol = 1e-4 if f32 else (8e-2 if training else 3e-2)
+        gtol = 1e-4 if f32 else (8e-2 if training else 3e-2) * bf16_slack
         m.train(training), ref.train(training)
         xr = x.double().requires_grad_(True)
         yr = fwd_ref(ref, xr)
@@ -595,7 +595,11 @@ def test_conv_norm_act_groups_dilation_and_no_norm(case, dtype):
         with torch.no_grad():
             ref.conv.weight.copy_(m.conv.weight.bfloat16().double())
     names = {"conv.weight", "conv.bias", "norm.weight", "norm.bias"}
-    _variant_check(m, ref, x, dtype, lambda r, xr: r.act(r.norm(r.conv(xr))), names)
+    # (depthwise, bf16: a filter-gradient entry is a sum over the 572 pixels of ONE channel -- nothing averages a flipped ReLU
+    #  mask element or a rounded dz out over input channels; measured 3.3e-2 in eval mode where dense units stay under
+    #  1.7e-2.  The f32 run of the same case carries the 1e-4 bound.)
+    depthwise = kw.get("groups", 1) == Cin == Cout
+    _variant_check(m, ref, x, dtype, lambda r, xr: r.act(r.norm(r.conv(xr))), names, bf16_slack=2.0 if depthwise else 1.0)
 
 
 def test_grouped_unit_inside_a_chain_with_a_shortcut():
