@@ -370,6 +370,46 @@ def test_captured_data_parallel_segments_equal_the_eager_schedule(bucket_mb):
     N.check(N.lib().vt_memset(buf.data_ptr(), 0, 64, int(torch.cuda.current_stream().cuda_stream)))
 
 
+@pytest.mark.parametrize("flag", ["VT_FUSE_BNRED", "VT_BN_BWD_FUSED", "VT_BN_FIN_APPLY"])
+def test_fused_batchnorm_forms_leave_the_step_alone(flag, monkeypatch):
+    """Round 6 built three launch fusions of the BatchNorm passes that are OFF by default (each measured slower in the step,
+    NOTEBOOK R6.4-R6.6): the backward reduction inside the data-gradient launch in front of it (VT_FUSE_BNRED), the whole
+    backward of a unit as one launch with grid barriers (VT_BN_BWD_FUSED), the finalize step inside the launch that consumes
+    its coefficients (VT_BN_FIN_APPLY).  Their kernels have parity tests of their own; this is the ENGINE side: with a flag on,
+    the program really contains the fused ops, and loss, every parameter gradient and the running statistics of a bf16 train
+    step equal the default program's (the sums are the same terms in another order; VT_BN_FIN_APPLY is bit-identical)."""
+    import ctypes
+
+    ncls, B, S = 16, 8, 96
+    x, y = filler.images(B, S), filler.labels(B, ncls)
+    want = {"VT_FUSE_BNRED": N.OP_CONV_DGRAD_BNRED, "VT_BN_BWD_FUSED": N.OP_BN_BWD_FUSED, "VT_BN_FIN_APPLY": N.OP_BN_BWD_FIN_APPLY}[flag]
+
+    def run(on):
+        for k in ("VT_FUSE_BNRED", "VT_BN_BWD_FUSED", "VT_BN_FIN_APPLY"):
+            monkeypatch.setenv(k, "1" if (on and k == flag) else "0")
+        ts = TrainStep(backbones.cspdarknet53(), ncls, B, S, torch.bfloat16, lr=0.0, momentum=0.0, weight_decay=0.0,
+                       label_smoothing=0.1, device="cuda")
+        filler.fill_module(ts.model, "fus.")
+        ts.weights_changed()
+        ts.step(x.cuda(), y.cuda())
+        torch.cuda.synchronize()
+        kinds = [ts.prog.bwd_ops[i].kind & 0xFFFF for i in range(ts.prog.n_bwd)]
+        rv = {k: v.detach().clone().cpu() for k, v in ts.model.state_dict().items() if k.endswith("running_var")}
+        return _device_grads(ts), ts.loss(), kinds.count(want), rv
+
+    g0, l0, n0, rv0 = run(False)
+    g1, l1, n1, rv1 = run(True)
+    assert n0 == 0 and n1 >= 8, (n0, n1)
+    assert abs(l1 - l0) <= 1e-6 * abs(l0)
+    for k in g0:
+        assert rel_err(g1[k], g0[k]) < (1e-6 if flag == "VT_BN_FIN_APPLY" else 2e-3), k
+    for k in rv0:
+        assert torch.equal(rv0[k], rv1[k]), k
+    n = ctypes.c_uint32(0)
+    N.check(N.lib().vt_bn_bwd_fused_timeouts(ctypes.byref(n)))
+    assert n.value == 0
+
+
 def test_grouped_filter_gradients_equal_the_ungrouped_ones(monkeypatch):
     """The engine holds the filter gradients of same-shape 3x3 layers back and releases them as one grouped launch
     (VT_WGRAD_GROUP, default 8; vt_conv_wgrad_group): every parameter gradient of a bf16 train step must equal the ungrouped
