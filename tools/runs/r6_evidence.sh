@@ -6,7 +6,7 @@
 #   3. span6's phase stamps (tools/span6_phases.sh)
 #   4. the full default bench line (what the driver runs)
 set -u
-TAG=${1:-r06_a}
+TAG=${1:-r06_b}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
