@@ -27,6 +27,10 @@
 
 #include "vt_common.h"
 
+#ifndef VT_W6_SETPRIO
+#define VT_W6_SETPRIO 0  // 1: s_setprio(1) around a compute wave's MFMA tick (measured: see NOTEBOOK R6.8)
+#endif
+
 // ablations exist only in -DVT_W6_ABL=<bits> builds (results wrong by construction, only the time is read):
 //   1 no LDS-DMA inside the loop, 2 no MFMAs, 4 no fragment reads, 8 no flush
 #ifndef VT_W6_ABL
@@ -327,6 +331,9 @@ __global__ void __launch_bounds__(768, 3) wgrad6_kernel(const W6Args p) {
                 // ---- MFMA tick (the other group reads meanwhile) ---------------------------------------------
                 VT_W6_BAR(cwait);
                 VT_W6_T(const unsigned long long m0_ = clock64();)
+#if VT_W6_SETPRIO
+                __builtin_amdgcn_s_setprio(1);  // (as span6: the MFMA-issuing wave wins its SIMD's issue arbitration)
+#endif
                 bf16x8 af[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -370,6 +377,9 @@ __global__ void __launch_bounds__(768, 3) wgrad6_kernel(const W6Args p) {
                     }
                 }
                 VT_W6_T(asm volatile("s_nop 0" ::"v"(acc[NB - 1][3][0])); cM += clock64() - m0_;)
+#if VT_W6_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 zs = (zs + 1 == NS) ? 0 : zs + 1;
             }
 #ifdef VT_W6_DIAG
