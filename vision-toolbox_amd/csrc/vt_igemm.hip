@@ -314,10 +314,16 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(const IgemmArgs p) 
             for (int i = 0; i < FM; ++i) af[i] = A[i * 64];
 #pragma unroll
             for (int j = 0; j < FN; ++j) bf[j] = Bt[j * 64];
+#if VT_MFMA_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) mma<T>(af[i], bf[j], acc[i][j]);
+#if VT_MFMA_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
         cur = (cur + 1 == NS) ? 0 : cur + 1;
         nxt = (nxt + 1 == NS) ? 0 : nxt + 1;

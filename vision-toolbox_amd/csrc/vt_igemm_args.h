@@ -5,6 +5,10 @@
 // internal epilogue flag (never in a caller's vt_conv_desc.flags): the launch is vt_conv_dgrad_bnred's fused form
 #define VT_CONV_BNRED 0x1000
 
+#ifndef VT_MFMA_SETPRIO
+#define VT_MFMA_SETPRIO 0  // 1: s_setprio(1) around the MFMA cluster of a main-loop step (vt_igemm / vt_igemm_span / vt_igemm_pspan)
+#endif
+
 struct IgemmArgs {
     const void* x;
     const void* w;

@@ -545,7 +545,13 @@ __global__ void __launch_bounds__(768, 3) pspan_kernel(const PsArgs a) {
                         constexpr int T = decltype(Tc)::value;
                         if constexpr (T + D < NT) load_step(std::integral_constant<int, (T + D < NT ? T + D : 0)>{});
                         __builtin_amdgcn_sched_barrier(0);
+#if VT_MFMA_SETPRIO
+                        __builtin_amdgcn_s_setprio(1);
+#endif
                         mma_step(Tc);
+#if VT_MFMA_SETPRIO
+                        __builtin_amdgcn_s_setprio(0);
+#endif
                         __builtin_amdgcn_sched_barrier(0);
                     };
                     auto pre = [&](auto Tc) {

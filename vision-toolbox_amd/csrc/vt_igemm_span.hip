@@ -426,10 +426,16 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) span_kernel(const IgemmArgs p
                     af[i] = src[i * 64];
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#if VT_MFMA_SETPRIO
+                __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < FN; ++j) mma<T>(af[i], bf[j], acc[i][j]);
+#if VT_MFMA_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
             }
             if (++it == p.ntaps) it = 0, ++ic;
             bcur = (bcur + 1 == NSB) ? 0 : bcur + 1;
@@ -488,10 +494,16 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) span_kernel(const IgemmArgs p
             // all fragment reads are issued before the first MFMA (the scheduler otherwise funnels
             // the A fragments through one register quad: read, wait lgkmcnt(0), 4 MFMAs, read, ...)
             __builtin_amdgcn_sched_barrier(0);
+#if VT_MFMA_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) mma<T>(af[i], bf[j], acc[i][j]);
+#if VT_MFMA_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
         if (++it == p.ntaps) it = 0, ++ic;
         bcur = (bcur + 1 == NSB) ? 0 : bcur + 1;

@@ -28,7 +28,7 @@
 #include "vt_common.h"
 
 #ifndef VT_W6_SETPRIO
-#define VT_W6_SETPRIO 0  // 1: s_setprio(1) around a compute wave's MFMA tick (measured: see NOTEBOOK R6.8)
+#define VT_W6_SETPRIO 1  // 1: s_setprio(1) around a compute wave's MFMA tick (measured: see NOTEBOOK R6.8)
 #endif
 
 // ablations exist only in -DVT_W6_ABL=<bits> builds (results wrong by construction, only the time is read):
