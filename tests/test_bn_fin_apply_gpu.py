@@ -56,11 +56,10 @@ def test_forward_finalize_inside_the_normalise_launch_is_bit_identical(shape, dt
         coef = torch.zeros(4, Cc, device="cuda")
         yb = torch.full((M, ld), float("nan"), device="cuda", dtype=td)
         y = yb[:, 8:8 + Cc] if slices else yb
-        ready = torch.zeros(1, dtype=torch.int32, device="cuda")
         before = N.launch_count()
         if fused:
             N.check(lib.vt_bn_finalize_apply(vp(st), Cc, float(M), vp(gamma), vp(beta), 1e-5, 0.1, vp(rm), vp(rv), vp(nbt), vp(coef[0]),
-                                             vp(coef[1]), vp(coef[2]), vp(coef[3]), vp(ready), vp(z), ld, vp(res), Cc, vp(y), ld, M, 1,
+                                             vp(coef[1]), vp(coef[2]), vp(coef[3]), vp(z), ld, vp(res), Cc, vp(y), ld, M, 1,
                                              dtype, stream()))
         else:
             N.check(lib.vt_bn_finalize(vp(st), Cc, float(M), vp(gamma), vp(beta), 1e-5, 0.1, vp(rm), vp(rv), vp(nbt), vp(coef[0]),
@@ -99,10 +98,9 @@ def test_backward_finalize_inside_the_apply_launch_is_bit_identical(shape, dtype
         dg, db = torch.full((Cc,), 0.25, device="cuda"), torch.full((Cc,), -0.5, device="cuda")
         coef = torch.zeros(3, Cc, device="cuda")
         dz = torch.full((M, Cc), float("nan"), device="cuda", dtype=td)
-        ready = torch.zeros(1, dtype=torch.int32, device="cuda")
         if fused:
             N.check(lib.vt_bn_bwd_finalize_apply(vp(sums), Cc, float(M), 1.0, vp(scale), vp(shift), vp(mean), vp(invstd), train, vp(dg),
-                                                 vp(db), vp(coef), vp(ready), vp(dy), Cc, vp(z), Cc, vp(dz), Cc, M, 1, dtype, stream()))
+                                                 vp(db), vp(coef), vp(dy), Cc, vp(z), Cc, vp(dz), Cc, M, 1, dtype, stream()))
         else:
             N.check(lib.vt_bn_bwd_finalize(vp(sums), Cc, float(M), 1.0, vp(scale), vp(mean), vp(invstd), train, vp(dg), vp(db), vp(coef),
                                            stream()))

@@ -162,18 +162,22 @@ def test_cspdarknet53_program_structure():
     assert h["pw_stats"] == h["pw_apply"] == h["pw_reduce"] == h["pw_bwd"] == pw_launches
     # their filter gradient is formed inside pw_bwd up to 64 x 64; the 128-channel ones (stage 1 pair + out_conv, the 8
     # block units of stage 2: 11 filters) hand dz to the filter-gradient kernel
-    assert h["conv_wgrad"] == 66 - pw_units + 11 and h["bn_finalize"] == 67
-    # (round 6: two fused forms exist and are off by default, each measured slower in the step -- VT_FUSE_BNRED=1 moves the
-    #  reduction of DarknetBlock.conv1's backward into conv2's data-gradient launch, VT_BN_BWD_FUSED=1 makes the whole
-    #  BatchNorm backward of a unit one launch; test_fused_backward_forms_change_the_program_as_documented)
-    assert h["bn_bwd_apply"] == 66 - pw_units and h["bn_bwd_reduce"] == 66 - pw_units
-    assert h["bn_bwd_finalize"] == 67
+    assert h["conv_wgrad"] == 66 - pw_units + 11
+    # round 6: the finalize step of the 49 units whose normalise / backward-apply passes are the streaming kernels runs
+    # inside those passes (every workgroup finalizes its own channel group: vt_bn_finalize_apply / vt_bn_bwd_finalize_apply);
+    # the stem and the pointwise units keep a finalize launch of their own
+    assert h["bn_fin_apply"] == h["bn_bwd_fin_apply"] == 66 - pw_units and "bn_act_apply" not in h and "bn_bwd_apply" not in h
+    assert h["bn_finalize"] == h["bn_bwd_finalize"] == 67 - (66 - pw_units)
+    # (three other fused forms exist and are off by default, each measured no faster in the step -- VT_FUSE_BNRED=1 moves
+    #  the reduction of DarknetBlock.conv1's backward into conv2's data-gradient launch, VT_BN_BWD_FUSED=1 makes the whole
+    #  BatchNorm backward of a unit one launch, VT_FIN_TAIL=1 finalizes in the tail of the launch that produces the sums;
+    #  test_fused_backward_forms_change_the_program_as_documented)
+    assert h["bn_bwd_reduce"] == 66 - pw_units
     # residual adds are folded into the normalise pass and torch.cat is elided: the ONLY
-    # elementwise launches are one bn_act_apply per remaining unit; the only copies are the bf16 weight
+    # elementwise launches are one normalise pass (bn_fin_apply) per remaining unit; the only copies are the bf16 weight
     # mirror and the 3->8 channel stem filter pad
     # (the stem unit has none: its conv runs twice, statistics only and then with the normalise + ReLU epilogue, and
     # its pre-activation is never stored)
-    assert h["bn_act_apply"] == 67 - pw_units - 1
     assert h["copy2d"] == 2
     # forward convs + one data-gradient launch per conv; the 5 stride-2 convs take 4 parity-class launches, except the
     # two HBM-bound ones (32 -> 64 and 64 -> 128 channels), whose classes are the column blocks of one depth-to-space launch
@@ -185,17 +189,21 @@ def test_fused_backward_forms_change_the_program_as_documented(monkeypatch):
     monkeypatch.setenv("VT_FUSE_BNRED", "1")
     h = _dry_program("cspdarknet53", N.VT_BF16, True, True).kind_histogram
     # the 8 + 4 DarknetBlock.conv1 units of stages 3 and 4 (stages 0-2 are pointwise units under this file's VT_PW_MIN_MB=0)
-    assert h["conv_dgrad_bnred"] == 12 and h["bn_bwd_reduce"] == 66 - 17 - 12 and h["bn_bwd_apply"] == 66 - 17
+    assert h["conv_dgrad_bnred"] == 12 and h["bn_bwd_reduce"] == 66 - 17 - 12 and h["bn_bwd_fin_apply"] == 66 - 17
     monkeypatch.setenv("VT_FUSE_BNRED", "0")
     monkeypatch.setenv("VT_BN_BWD_FUSED", "1")
     h = _dry_program("cspdarknet53", N.VT_BF16, True, True).kind_histogram
-    assert h["bn_bwd_fused"] == 66 - 17 and "bn_bwd_apply" not in h and "bn_bwd_reduce" not in h
+    assert h["bn_bwd_fused"] == 66 - 17 and "bn_bwd_fin_apply" not in h and "bn_bwd_reduce" not in h
     assert h["bn_bwd_finalize"] == 67 - (66 - 17)  # the stem and the pointwise units keep their own
     monkeypatch.setenv("VT_BN_BWD_FUSED", "0")
-    monkeypatch.setenv("VT_BN_FIN_APPLY", "1")  # the finalize step inside the launch that consumes its coefficients
+    monkeypatch.setenv("VT_BN_FIN_APPLY", "0")  # finalize launches of their own (rounds 1-5)
     h = _dry_program("cspdarknet53", N.VT_BF16, True, True).kind_histogram
-    assert h["bn_fin_apply"] == 66 - 17 and h["bn_bwd_fin_apply"] == 66 - 17
-    assert "bn_act_apply" not in h and "bn_bwd_apply" not in h and h["bn_finalize"] == 67 - (66 - 17) == h["bn_bwd_finalize"]
+    assert h["bn_act_apply"] == h["bn_bwd_apply"] == h["bn_bwd_reduce"] == 66 - 17 and h["bn_finalize"] == h["bn_bwd_finalize"] == 67
+    assert "bn_fin_apply" not in h and "bn_bwd_fin_apply" not in h
+    monkeypatch.setenv("VT_FIN_TAIL", "1")  # ... or the finalize step in the tail of the launch that produces the sums
+    h = _dry_program("cspdarknet53", N.VT_BF16, True, True).kind_histogram
+    assert h["bn_bwd_reduce_fin"] == 66 - 17 and "bn_bwd_reduce" not in h and h["bn_bwd_finalize"] == 67 - (66 - 17)
+    assert h["conv_igemm_fin"] == 66 - 17 and h["bn_finalize"] == 67 - (66 - 17) and h["bn_act_apply"] == h["bn_bwd_apply"] == 66 - 17
 
 
 def test_inference_program_is_fully_fused():
@@ -250,11 +258,18 @@ def test_unsupported_variants_raise_not_fallback():
     descs = [N.ConvDesc.from_buffer_copy(bytes(op.i)[: ctypes.sizeof(N.ConvDesc)]) for op in convs]
     assert [(d.Cin, d.ldx, d.Cout, d.ldy, d.ldw) for d in descs] == [(4, 8, 4, 8, 36)] * 2
     assert convs[1].ptr[1].offset - convs[0].ptr[1].offset == 4 * 36 * 4  # the second group's filter rows
-    # ... but not below one 16-byte chunk per group (depthwise): raises, no fallback
-    g = ConvNormAct(8, 8, groups=8)
+    # ... depthwise (groups == channels, round 6): one launch of the depthwise kernel, no per-group units ...
+    g = ConvNormAct(8, 8, groups=8).eval()
     b = E.Builder(E.ParamStore(g), N.VT_F32, False, False)
     b.store.ensure(torch.device("cpu"))
-    with pytest.raises(NotImplementedError, match="depthwise"):
+    g._vt_emit(b, b.act(1, 4, 4, 8))
+    kinds = [op.kind & 0xFFFF for op in b.fwd]
+    assert kinds.count(N.OP_DWCONV_FWD) == 1 and N.OP_CONV_IGEMM not in kinds
+    # ... but not a group below one 16-byte chunk that is not depthwise: raises, no fallback
+    g = ConvNormAct(8, 8, groups=4)
+    b = E.Builder(E.ParamStore(g), N.VT_F32, False, False)
+    b.store.ensure(torch.device("cpu"))
+    with pytest.raises(NotImplementedError, match="16-byte chunk"):
         g._vt_emit(b, b.act(1, 4, 4, 8))
     # dilation: the taps move apart, the padding stays ceil((k - s) / 2) (components.py:31), so the map shrinks
     dl = ConvNormAct(8, 8, dilation=2).eval()

@@ -11,6 +11,7 @@
 #include <hip/hip_ext.h>
 
 #include "vt_common.h"
+#include "vt_fin_tail.h"
 
 namespace {
 
@@ -59,36 +60,17 @@ __device__ __forceinline__ void st16(T* p, const uint4& v) { *(uint4*)p = v; }
 // ---------------------------------------------------------------------------------
 // BatchNorm finalize (training): stats -> mean / invstd / scale / shift + running stats
 // ---------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, int C, double inv_count, double unbias,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float eps, float momentum, float* running_mean, float* running_var,
-                                   int64_t* nbt, float* scale, float* shift, float* mean, float* invstd) {
-    // One single-block launch per BatchNorm, 134 of them on the critical path of a step: what it costs is latency,
-    // not work.  The replica sums are loaded as independent pairs (two partial chains), the divisions by `count` are
-    // multiplications by a host-computed reciprocal, and 1/sqrt runs in f32 on the double-precision variance
-    // (correctly rounded sqrt and division: within one ulp of the double evaluation) -- fp64 division and sqrt are
-    // long software sequences on this hardware.
+__global__ void bn_finalize_kernel(const VtFinFwd f) {
+    // (the arithmetic: vt_fin_fwd_channel, vt_fin_tail.h -- shared with the tails of the producing launches)
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && nbt) nbt[0] += 1;
-    if (c >= C) return;
-    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    if (c >= f.C) return;
+    // exact integer sums of the fixed-point replicas (vt_common.h), loaded as independent pairs
+    const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
     float rm = 0.f, rv = 0.f;
-    if (running_mean) rm = running_mean[c], rv = running_var[c];
-    // exact integer sums of the fixed-point replicas (vt_common.h)
-    const double s = vt_stat_sum(stats, c, 2L * C), ss = vt_stat_sum(stats, (long)C + c, 2L * C);
-    const double mu = s * inv_count;
-    double var = ss * inv_count - mu * mu;
-    if (var < 0.0) var = 0.0;
-    const float istd = 1.0f / sqrtf((float)(var + (double)eps));
-    const float sc = g * istd;
-    scale[c] = sc;
-    shift[c] = b - (float)mu * sc;
-    mean[c] = (float)mu;
-    invstd[c] = istd;
-    if (running_mean) {
-        running_mean[c] = (1.f - momentum) * rm + momentum * (float)mu;
-        running_var[c] = (1.f - momentum) * rv + momentum * (float)(var * unbias);
-    }
+    if (f.running_mean) rm = f.running_mean[c], rv = f.running_var[c];
+    const double s = vt_stat_sum(f.stats, c, 2L * f.C), ss = vt_stat_sum(f.stats, (long)f.C + c, 2L * f.C);
+    float sc, sf;
+    vt_fin_fwd_channel(f, c, s, ss, g, b, rm, rv, sc, sf);
 }
 
 // replicas 1.. of int64[R][n] are added into replica 0 and zeroed (n = 2 * C * 2 limbs)
@@ -471,124 +453,52 @@ bn_act_apply_pool_kernel(const T* __restrict__ z, int ldz, const float* __restri
 
 // ---------------------------------------------------------------------------------
 // Finalize INSIDE the consuming launch (round 6).  The 134 single-workgroup finalize launches of a CSPDarknet-53 step sit on
-// the critical path between a producer of statistics and the streaming pass that needs the coefficients (0.71 ms in situ).
-// Here the first workgroups of the streaming launch do that work -- 16 channels per workgroup, 16 lanes per channel (one per
-// statistics replica: exact integer sums, then the arithmetic of bn_finalize_kernel / bn_bwd_finalize_kernel, bit for bit) --
-// publish the coefficients with device-scope (sc1) stores and count themselves ready; every workgroup polls that counter
-// once (device-scope loads; every 32nd poll a read-modify-write with 0, so that a stale cache line cannot hold it back) and
-// then reads the coefficients with device-scope loads.  The finalizing workgroups are the lowest-numbered ones: dispatched
-// first, never waiting for anything, so the hand-off cannot deadlock however many workgroups of the grid are resident.
-// (Round 3 tried this with agent-scope fences and plain polls: some workgroups never saw the flag.  What one workgroup reads
-// of another inside a launch here is written and read with sc1 accesses only; no fence is involved.)
-// A poll that does not complete within ~4 ms of wall clock gives up and is counted (vt_bn_bwd_fused_timeouts): never a hang.
-__device__ unsigned vt_fin_timeouts;
+// the critical path between a producer of statistics and the streaming pass that needs the coefficients: skipping them
+// (diagnostic build) shortens the 19.8 ms step by 1.17 ms, 9 - 13 us each.  Any hand-off INSIDE a launch -- first workgroups
+// finalize and publish, the others poll (the first form of these kernels: +2.3 ms per step); the producer's last workgroup
+// finalizes behind a ticket (vt_fin_tail.h: +-0) -- costs the dependent memory-side round trips it is made of, as much as
+// the launch boundary it replaces.  Here nothing is handed over: the sums are complete when the streaming launch starts, so
+// EVERY workgroup finalizes the (at most 128) channels of its own channel group for itself -- a thread per (channel, sum),
+// its 16 replicas x 2 limbs in one round of plain loads (64 KB per workgroup, L2 hits after the first workgroup of an XCD),
+// the arithmetic of bn_finalize_kernel / bn_bwd_finalize_kernel bit for bit (vt_fin_fwd_channel / vt_fin_bwd_channel) --
+// and keeps the coefficients in LDS; the workgroups of row block 0 also store them (and the running statistics, d(gamma),
+// d(beta)) for the later passes.  The grid is cut for ~1024 workgroups instead of 4096, so that the redundant reads stay
+// small beside the tensor traffic.
+// ---------------------------------------------------------------------------------
+constexpr int kFinCg = 128;  // channels per channel group: a thread pair per channel
 
-__device__ __forceinline__ float ld_sc1(const float* p) {
-    return __hip_atomic_load((float*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_sc1(float* p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// exact integer sums over the 16 replicas of statistics entries `c` and `C + c`, one replica per lane of a 16-lane group;
-// returned (as vt_stat_sum returns them) in every lane of the group
-__device__ __forceinline__ void stat_sum16(const float* stats, int c, int C, int rp, double& s0, double& s1) {
-    const long long* q = (const long long*)stats;
-    long long hi[2], lo[2];
-#pragma unroll
-    for (int w = 0; w < 2; ++w) {
-        const long idx = (long)w * C + c + (long)rp * 2 * C;
-        hi[w] = q[2 * idx], lo[w] = q[2 * idx + 1];
-    }
-#pragma unroll
-    for (int off = 1; off < 16; off <<= 1) {
-#pragma unroll
-        for (int w = 0; w < 2; ++w) {
-            hi[w] += __shfl_xor(hi[w], off, 64);
-            lo[w] += __shfl_xor(lo[w], off, 64);
-        }
-    }
-    auto nat = [](long long h, long long l) -> double {
-        if (h >= (kStatPoison >> 2) || h <= -(kStatPoison >> 2)) return __longlong_as_double(0x7ff8000000000000LL);  // poisoned
-        return (double)h * 4096.0 + (double)l * (1.0 / 8589934592.0);
-    };
-    s0 = nat(hi[0], lo[0]), s1 = nat(hi[1], lo[1]);
-}
-// the finalizing workgroups count themselves ready; every workgroup waits for all of them
-__device__ __forceinline__ void fin_publish_and_wait(unsigned* ready, bool finalizer, unsigned nfin) {
-    if (finalizer) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's coefficient stores are performed
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (threadIdx.x == 0) {
-        const unsigned long long t0 = wall_clock64();  // 100 MHz
-        unsigned polls = 0;
-        while (((++polls & 31u) ? __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                : __hip_atomic_fetch_add(ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < nfin) {
-            __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > 400000ull) {
-                __hip_atomic_fetch_add(&vt_fin_timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-    __syncthreads();
+// the channel group of C channels: the largest divisor <= 128 that is a multiple of the 16-byte chunk (0: none)
+__host__ inline int fin_group(int C, int epc) {
+    for (int g = kFinCg / epc * epc; g >= epc; g -= epc)
+        if (C % g == 0) return (g >= 32 || g == C) ? g : 0;
+    return 0;
 }
 
-struct FinFwd {
-    const float* stats;
-    const float *gamma, *beta;
-    float *running_mean, *running_var;
-    int64_t* nbt;
-    float *scale, *shift, *mean, *invstd;
-    unsigned* ready;
-    double inv_count, unbias;
-    float eps, momentum;
-    int C;
-};
-
-// y = [relu](z*scale + shift) [+ residual] with scale / shift finalized by this launch's first workgroups
+// y = [relu](z*scale + shift) [+ residual]; grid (row blocks, channel groups of Cg channels)
 template <typename T, bool kRes>
 __global__ void __launch_bounds__(kThreads)
-bn_fin_apply_kernel(const FinFwd f, const T* __restrict__ z, int ldz, const T* __restrict__ res, int ldr, T* __restrict__ y,
-                    int ldy, long M, RowMap rm, int relu) {
+bn_fin_apply_kernel(const VtFinFwd f, const T* __restrict__ z, int ldz, const T* __restrict__ res, int ldr, T* __restrict__ y,
+                    int ldy, long M, RowMap rm, int relu, int Cg) {
     constexpr int EPC = VecIO<T>::EPC;
+    __shared__ float s_sc[kFinCg], s_sf[kFinCg];
     const int t = threadIdx.x;
-    const int nfb = (f.C + 15) / 16, nfin = min((int)gridDim.x, nfb);
-    const bool finalizer = (int)blockIdx.x < nfin;
-    if (finalizer) {
-        if (blockIdx.x == 0 && t == 0 && f.nbt) f.nbt[0] += 1;
-        for (int cb = blockIdx.x; cb < nfb; cb += nfin) {
-            const int c = cb * 16 + (t >> 4), rp = t & 15;
-            if (c >= f.C) continue;  // (whole 16-lane groups)
-            double s, ss;
-            stat_sum16(f.stats, c, f.C, rp, s, ss);
-            if (rp == 0) {  // bn_finalize_kernel, bit for bit
-                const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
-                const double mu = s * f.inv_count;
-                double var = ss * f.inv_count - mu * mu;
-                if (var < 0.0) var = 0.0;
-                const float istd = 1.0f / sqrtf((float)(var + (double)f.eps));
-                const float sc = g * istd;
-                st_sc1(f.scale + c, sc);
-                st_sc1(f.shift + c, b - (float)mu * sc);
-                f.mean[c] = (float)mu;
-                f.invstd[c] = istd;
-                if (f.running_mean) {
-                    f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mu;
-                    f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)(var * f.unbias);
-                }
-            }
-        }
-    }
-    fin_publish_and_wait(f.ready, finalizer, (unsigned)nfin);
+    const int cg0 = blockIdx.y * Cg;
+    vt_pair_sums<false>(f.stats, f.C, cg0, cg0 + Cg, [&](int c) { return vt_fin_fwd_pre(f, c); },
+                        [&](int c, double s, double ss, const VtFinFwdPre& p) {
+                            float sc, sf;
+                            vt_fin_fwd_channel(f, c, s, ss, p.g, p.b, p.rm, p.rv, sc, sf, blockIdx.x == 0);
+                            s_sc[c - cg0] = sc, s_sf[c - cg0] = sf;
+                        });
+    __syncthreads();
+    z += cg0, y += cg0;
+    if (kRes) res += cg0;
     const int r = t / rm.CT;
     if (r >= rm.RT) return;
     const long row0 = (long)(rm.rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * rm.RT * rm.iters + r;
     for (int col = t % rm.CT; col < rm.CPR; col += rm.CT) {
         float sc[EPC], sf[EPC];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) sc[e] = ld_sc1(f.scale + col * EPC + e), sf[e] = ld_sc1(f.shift + col * EPC + e);
+        for (int e = 0; e < EPC; ++e) sc[e] = s_sc[col * EPC + e], sf[e] = s_sf[col * EPC + e];
         const T* pz = z + row0 * ldz + col * EPC;
         const T* pr = kRes ? res + row0 * ldr + col * EPC : nullptr;
         T* py = y + row0 * ldy + col * EPC;
@@ -626,49 +536,24 @@ bn_fin_apply_kernel(const FinFwd f, const T* __restrict__ z, int ldz, const T* _
     }
 }
 
-struct FinBwd {
-    const float* sums;
-    const float *scale, *mean, *invstd;
-    float *dgamma, *dbeta, *coef;
-    unsigned* ready;
-    double inv_count, pscale;
-    int C, train;
-};
-
-// dz = a*g - b*z + d with (a, b, d) finalized by this launch's first workgroups
+// dz = a*g - b*z + d; grid (row blocks, channel groups of Cg channels)
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
-bn_bwd_fin_apply_kernel(const FinBwd f, const T* __restrict__ dy, int lddy, const T* __restrict__ z, int ldz,
+bn_bwd_fin_apply_kernel(const VtFinBwd f, const T* __restrict__ dy, int lddy, const T* __restrict__ z, int ldz,
                         const float* __restrict__ scale, const float* __restrict__ shift, T* __restrict__ dz, int lddz, long M,
-                        RowMap rm, int relu) {
+                        RowMap rm, int relu, int Cg) {
     constexpr int EPC = VecIO<T>::EPC;
-    const int t = threadIdx.x, C = f.C;
-    const int nfb = (C + 15) / 16, nfin = min((int)gridDim.x, nfb);
-    const bool finalizer = (int)blockIdx.x < nfin;
-    if (finalizer) {
-        for (int cb = blockIdx.x; cb < nfb; cb += nfin) {
-            const int c = cb * 16 + (t >> 4), rp = t & 15;
-            if (c >= C) continue;
-            double s1, s2;
-            stat_sum16(f.sums, c, C, rp, s1, s2);
-            if (rp == 0) {  // bn_bwd_finalize_kernel, bit for bit
-                const float a = f.scale[c], mu = f.mean[c], istd = f.invstd[c];
-                if (f.dgamma) f.dgamma[c] += (float)(s2 * f.pscale);
-                if (f.dbeta) f.dbeta[c] += (float)(s1 * f.pscale);
-                float b = 0.f, d = 0.f;
-                if (f.train) {
-                    const double c1 = s1 * f.inv_count, c2 = s2 * f.inv_count;
-                    const double bb = (double)a * c2 * (double)istd;
-                    b = (float)bb;
-                    d = (float)(bb * (double)mu - (double)a * c1);
-                }
-                st_sc1(f.coef + c, a);
-                st_sc1(f.coef + C + c, b);
-                st_sc1(f.coef + 2 * C + c, d);
-            }
-        }
-    }
-    fin_publish_and_wait(f.ready, finalizer, (unsigned)nfin);
+    __shared__ float s_a[kFinCg], s_b[kFinCg], s_d[kFinCg];
+    const int t = threadIdx.x;
+    const int cg0 = blockIdx.y * Cg;
+    vt_pair_sums<false>(f.sums, f.C, cg0, cg0 + Cg, [&](int c) { return vt_fin_bwd_pre(f, c); },
+                        [&](int c, double s1, double s2, const VtFinBwdPre& p) {
+                            float b, d;
+                            vt_fin_bwd_channel(f, c, s1, s2, p.a, p.mu, p.istd, p.dg, p.db, b, d, blockIdx.x == 0);
+                            s_a[c - cg0] = p.a, s_b[c - cg0] = b, s_d[c - cg0] = d;
+                        });
+    __syncthreads();
+    dy += cg0, z += cg0, dz += cg0, scale += cg0, shift += cg0;
     const int r = t / rm.CT;
     if (r >= rm.RT) return;
     const long row0 = (long)(rm.rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * rm.RT * rm.iters + r;
@@ -679,9 +564,7 @@ bn_bwd_fin_apply_kernel(const FinBwd f, const T* __restrict__ dy, int lddy, cons
             const int c = col * EPC + e;
             sc[e] = scale[c];
             sf[e] = shift[c];
-            ca[e] = ld_sc1(f.coef + c);
-            cb[e] = ld_sc1(f.coef + C + c);
-            cd[e] = ld_sc1(f.coef + 2 * C + c);
+            ca[e] = s_a[c], cb[e] = s_b[c], cd[e] = s_d[c];
         }
         for (int it = 0; it < rm.iters; it += kUnroll) {
             uint4 vg[kUnroll], vz[kUnroll];
@@ -722,7 +605,7 @@ __global__ void __launch_bounds__(kThreads)
 bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z, int ldz,
                      const float* __restrict__ scale, const float* __restrict__ shift,
                      const float* __restrict__ mean, const float* __restrict__ invstd, long M, int C,
-                     RowMap rm, int relu_flags, float* __restrict__ sums, int Ctot) {
+                     RowMap rm, int relu_flags, float* __restrict__ sums, int Ctot, const VtFinBwd ft) {
     const int relu = relu_flags & 1;  // bit 1: dev switch, LDS staging of every row lane (the pre-round-2 fold)
     const int act = relu_flags >> 4;  // (GEN: the activation code)
     constexpr int EPC = VecIO<T>::EPC;
@@ -828,31 +711,20 @@ bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z
         }
         __syncthreads();
     }
+    // the finalize step as this launch's tail (vt_fin_tail.h): the last workgroup of a channel group to arrive does it
+    if (ft.ticket) vt_fin_tail_bwd(ft, ft.ticket + blockIdx.y, gridDim.x, cg0 * EPC, cg0 * EPC + C, (unsigned*)sred);
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, double inv_count, double pscale,
-                                       const float* __restrict__ scale, const float* __restrict__ mean,
-                                       const float* __restrict__ invstd, int train, float* dgamma,
-                                       float* dbeta, float* coef) {
+__global__ void bn_bwd_finalize_kernel(const VtFinBwd f) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float a = scale[c], mu = mean[c], istd = invstd[c];
+    if (c >= f.C) return;
+    const float a = f.scale[c], mu = f.mean[c], istd = f.invstd[c];
     float dg = 0.f, db = 0.f;
-    if (dgamma) dg = dgamma[c];
-    if (dbeta) db = dbeta[c];
-    const double s1 = vt_stat_sum(sums, c, 2L * C), s2 = vt_stat_sum(sums, (long)C + c, 2L * C);
-    if (dgamma) dgamma[c] = dg + (float)(s2 * pscale);
-    if (dbeta) dbeta[c] = db + (float)(s1 * pscale);
-    float b = 0.f, d = 0.f;
-    if (train) {
-        const double c1 = s1 * inv_count, c2 = s2 * inv_count;
-        const double bb = (double)a * c2 * (double)istd;
-        b = (float)bb;
-        d = (float)(bb * (double)mu - (double)a * c1);
-    }
-    coef[c] = a;
-    coef[C + c] = b;
-    coef[2 * C + c] = d;
+    if (f.dgamma) dg = f.dgamma[c];
+    if (f.dbeta) db = f.dbeta[c];
+    const double s1 = vt_stat_sum(f.sums, c, 2L * f.C), s2 = vt_stat_sum(f.sums, (long)f.C + c, 2L * f.C);
+    float b, d;
+    vt_fin_bwd_channel(f, c, s1, s2, a, mu, istd, dg, db, b, d);
 }
 
 // dz = a*g - b*z + d
@@ -1749,9 +1621,9 @@ int vt_bn_finalize(const float* stats, int32_t C, double count, const float* gam
     VT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), VT_ERR_INVALID,
                "vt_bn_finalize: running_mean/var must both be given or both NULL");
     const double unbias = count > 1.0 ? count / (count - 1.0) : 1.0;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, stats, C,
-                       1.0 / count, unbias, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked,
-                       scale, shift, mean, invstd);
+    VtFinFwd f{nullptr, stats, gamma, beta, running_mean, running_var, num_batches_tracked, scale, shift, mean, invstd,
+               1.0 / count, unbias, eps, momentum, C};
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, f);
     VT_CHECK_LAUNCH("vt_bn_finalize");
     return VT_OK;
 }
@@ -1840,15 +1712,16 @@ int vt_bn_act_apply(const void* z, int32_t ldz, const float* scale, const float*
 // the two launches.  `ready`: 4 zeroed bytes.
 int vt_bn_finalize_apply(const float* stats, int32_t C, double count, const float* gamma, const float* beta, float eps,
                          float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* scale,
-                         float* shift, float* mean, float* invstd, void* ready, const void* z, int32_t ldz,
+                         float* shift, float* mean, float* invstd, const void* z, int32_t ldz,
                          const void* residual, int32_t ldr, void* y, int32_t ldy, int64_t M, int32_t relu, int32_t dtype,
                          void* stream) {
-    VT_REQUIRE(stats && scale && shift && mean && invstd && ready && C > 0 && count > 0 && M > 0, VT_ERR_INVALID,
+    VT_REQUIRE(stats && scale && shift && mean && invstd && C > 0 && count > 0 && M > 0, VT_ERR_INVALID,
                "vt_bn_finalize_apply: bad argument");
     VT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), VT_ERR_INVALID,
                "vt_bn_finalize_apply: running_mean/var must both be given or both NULL");
     VT_REQUIRE(relu >= 0 && relu <= 4, VT_ERR_INVALID, "vt_bn_finalize_apply: activation code %d", relu);
-    if (relu >= 2 || !VT_KNOB("VT_BN_FIN_APPLY", 1)) {
+    const int Cg = fin_group(C, vt_epc(dtype));
+    if (relu >= 2 || !Cg || !VT_KNOB("VT_BN_FIN_APPLY", 1)) {
         const int rc = vt_bn_finalize(stats, C, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked,
                                       scale, shift, mean, invstd, stream);
         if (rc != VT_OK) return rc;
@@ -1857,21 +1730,20 @@ int vt_bn_finalize_apply(const float* stats, int32_t C, double count, const floa
     VT_TRY(check_mat("vt_bn_finalize_apply(z)", z, ldz, C, dtype));
     VT_TRY(check_mat("vt_bn_finalize_apply(y)", y, ldy, C, dtype));
     if (residual) VT_TRY(check_mat("vt_bn_finalize_apply(residual)", residual, ldr, C, dtype));
-    RowMap rm = RowMap::make(C, vt_epc(dtype), M);
+    const int groups = C / Cg, wgs = VT_KNOB("VT_BN_FIN_APPLY_WGS", 1024);
+    RowMap rm = RowMap::make(Cg, vt_epc(dtype), M, wgs / groups > 0 ? wgs / groups : 1);
     rm.rev = (vt_bn_order() >> 0) & 1;
-    FinFwd f;
-    f.stats = stats, f.gamma = gamma, f.beta = beta, f.running_mean = running_mean, f.running_var = running_var;
-    f.nbt = num_batches_tracked, f.scale = scale, f.shift = shift, f.mean = mean, f.invstd = invstd;
-    f.ready = (unsigned*)ready, f.inv_count = 1.0 / count, f.unbias = count > 1.0 ? count / (count - 1.0) : 1.0;
-    f.eps = eps, f.momentum = momentum, f.C = C;
+    const VtFinFwd f{nullptr, stats, gamma, beta, running_mean, running_var, num_batches_tracked, scale, shift, mean, invstd,
+                     1.0 / count, count > 1.0 ? count / (count - 1.0) : 1.0, eps, momentum, C};
+    const dim3 grid(rm.blocks(M), groups);
     if (residual) {
         VT_DISPATCH_T(dtype, "vt_bn_finalize_apply",
-                      VT_LAUNCH_STOP((bn_fin_apply_kernel<T, true>), dim3(rm.blocks(M)), dim3(kThreads), 0, (hipStream_t)stream, f,
-                                     (const T*)z, ldz, (const T*)residual, ldr, (T*)y, ldy, (long)M, rm, relu));
+                      VT_LAUNCH_STOP((bn_fin_apply_kernel<T, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, f,
+                                     (const T*)z, ldz, (const T*)residual, ldr, (T*)y, ldy, (long)M, rm, relu, Cg));
     } else {
         VT_DISPATCH_T(dtype, "vt_bn_finalize_apply",
-                      VT_LAUNCH_STOP((bn_fin_apply_kernel<T, false>), dim3(rm.blocks(M)), dim3(kThreads), 0, (hipStream_t)stream, f,
-                                     (const T*)z, ldz, (const T*)residual, ldr, (T*)y, ldy, (long)M, rm, relu));
+                      VT_LAUNCH_STOP((bn_fin_apply_kernel<T, false>), grid, dim3(kThreads), 0, (hipStream_t)stream, f,
+                                     (const T*)z, ldz, (const T*)residual, ldr, (T*)y, ldy, (long)M, rm, relu, Cg));
     }
     VT_CHECK_LAUNCH("vt_bn_finalize_apply");
     return VT_OK;
@@ -1880,12 +1752,13 @@ int vt_bn_finalize_apply(const float* stats, int32_t C, double count, const floa
 // vt_bn_bwd_finalize + vt_bn_act_bwd_apply in one launch (see bn_bwd_fin_apply_kernel)
 int vt_bn_bwd_finalize_apply(const float* sums, int32_t C, double count, double pscale, const float* scale,
                              const float* shift, const float* mean, const float* invstd, int32_t train, float* dgamma,
-                             float* dbeta, float* coef, void* ready, const void* dy, int32_t lddy, const void* z, int32_t ldz,
+                             float* dbeta, float* coef, const void* dy, int32_t lddy, const void* z, int32_t ldz,
                              void* dz, int32_t lddz, int64_t M, int32_t relu, int32_t dtype, void* stream) {
-    VT_REQUIRE(sums && scale && shift && mean && invstd && coef && ready && C > 0 && count > 0 && M > 0, VT_ERR_INVALID,
+    VT_REQUIRE(sums && scale && shift && mean && invstd && coef && C > 0 && count > 0 && M > 0, VT_ERR_INVALID,
                "vt_bn_bwd_finalize_apply: bad argument");
     VT_REQUIRE(relu >= 0 && relu <= 4, VT_ERR_INVALID, "vt_bn_bwd_finalize_apply: activation code %d", relu);
-    if (relu >= 2 || !VT_KNOB("VT_BN_FIN_APPLY", 1)) {
+    const int Cg = fin_group(C, vt_epc(dtype));
+    if (relu >= 2 || !Cg || !VT_KNOB("VT_BN_FIN_APPLY", 1)) {
         const int rc = vt_bn_bwd_finalize(sums, C, count, pscale, scale, mean, invstd, train, dgamma, dbeta, coef, stream);
         if (rc != VT_OK) return rc;
         return vt_bn_act_bwd_apply(dy, lddy, z, ldz, scale, shift, coef, dz, lddz, M, C, relu, dtype, stream);
@@ -1893,28 +1766,24 @@ int vt_bn_bwd_finalize_apply(const float* sums, int32_t C, double count, double 
     VT_TRY(check_mat("vt_bn_bwd_finalize_apply(dy)", dy, lddy, C, dtype));
     VT_TRY(check_mat("vt_bn_bwd_finalize_apply(z)", z, ldz, C, dtype));
     VT_TRY(check_mat("vt_bn_bwd_finalize_apply(dz)", dz, lddz, C, dtype));
-    RowMap rm = RowMap::make(C, vt_epc(dtype), M);
+    const int groups = C / Cg, wgs = VT_KNOB("VT_BN_FIN_APPLY_WGS", 1024);
+    RowMap rm = RowMap::make(Cg, vt_epc(dtype), M, wgs / groups > 0 ? wgs / groups : 1);
     rm.rev = (vt_bn_order() >> 2) & 1;
-    FinBwd f;
-    f.sums = sums, f.scale = scale, f.mean = mean, f.invstd = invstd, f.dgamma = dgamma, f.dbeta = dbeta, f.coef = coef;
-    f.ready = (unsigned*)ready, f.inv_count = 1.0 / count, f.pscale = pscale, f.C = C, f.train = train;
+    const VtFinBwd f{nullptr, sums, scale, mean, invstd, dgamma, dbeta, coef, 1.0 / count, pscale, C, train};
     VT_DISPATCH_T(dtype, "vt_bn_bwd_finalize_apply",
-                  VT_LAUNCH_STOP(bn_bwd_fin_apply_kernel<T>, dim3(rm.blocks(M)), dim3(kThreads), 0, (hipStream_t)stream, f,
-                                 (const T*)dy, lddy, (const T*)z, ldz, scale, shift, (T*)dz, lddz, (long)M, rm, relu));
+                  VT_LAUNCH_STOP(bn_bwd_fin_apply_kernel<T>, dim3(rm.blocks(M), groups), dim3(kThreads), 0, (hipStream_t)stream, f,
+                                 (const T*)dy, lddy, (const T*)z, ldz, scale, shift, (T*)dz, lddz, (long)M, rm, relu, Cg));
     VT_CHECK_LAUNCH("vt_bn_bwd_finalize_apply");
     return VT_OK;
 }
 
-// hand-offs of the two launches above that gave up waiting (added to vt_bn_bwd_fused_timeouts' count)
-unsigned vt_fin_timeouts_host() {
-    unsigned v = 0;
-    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(vt_fin_timeouts), sizeof(v)) != hipSuccess) return 0xffffffffu;
-    return v;
-}
+// (the two launches above wait for nothing since their second form: always 0; kept for vt_bn_bwd_fused_timeouts' sum)
+unsigned vt_fin_timeouts_host() { return 0; }
 
-int vt_bn_act_bwd_reduce(const void* dy, int32_t lddy, const void* z, int32_t ldz, const float* scale,
-                         const float* shift, const float* mean, const float* invstd, int64_t M, int32_t C,
-                         int32_t relu, int32_t dtype, float* sums, void* stream) {
+// ft.ticket != NULL: the finalize step runs as the launch's tail when it fits (*tail_done = 1), else not at all
+static int bwd_reduce_impl(const void* dy, int32_t lddy, const void* z, int32_t ldz, const float* scale,
+                           const float* shift, const float* mean, const float* invstd, int64_t M, int32_t C,
+                           int32_t relu, int32_t dtype, float* sums, VtFinBwd ft, int* tail_done, void* stream) {
     VT_REQUIRE(M > 0 && scale && shift && mean && invstd && sums, VT_ERR_INVALID,
                "vt_bn_act_bwd_reduce: bad argument");
     VT_TRY(check_mat("vt_bn_act_bwd_reduce(dy)", dy, lddy, C, dtype));
@@ -1928,6 +1797,8 @@ int vt_bn_act_bwd_reduce(const void* dy, int32_t lddy, const void* z, int32_t ld
     const int target = (256) / cgroups > 0 ? (256) / cgroups : 1;
     RowMap rm = RowMap::make(Cg, epc, M, target);
     rm.rev = (vt_bn_order() >> 1) & 1;
+    if (ft.ticket && !(cgroups <= VT_FIN_TICKETS && vt_fin_tail_fits(Cg, kThreads))) ft.ticket = nullptr;
+    if (tail_done) *tail_done = ft.ticket != nullptr;
     const int inwave_env = (1);
     const bool inwave = inwave_env && rm.CT < 64 && (rm.CT & (rm.CT - 1)) == 0;  // (as in the kernel)
     const int smem = (inwave ? kThreads / 64 : rm.RT) * 2 * rm.CT * epc * (int)sizeof(float);
@@ -1936,16 +1807,43 @@ int vt_bn_act_bwd_reduce(const void* dy, int32_t lddy, const void* z, int32_t ld
         VT_DISPATCH_T(dtype, "vt_bn_act_bwd_reduce",
                       hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(rm.blocks(M), cgroups), dim3(kThreads), smem,
                                          (hipStream_t)stream, (const T*)dy, lddy, (const T*)z, ldz, scale, shift, mean,
-                                         invstd, (long)M, Cg, rm, (relu << 4) | (inwave_env ? 0 : 2), sums, C));
+                                         invstd, (long)M, Cg, rm, (relu << 4) | (inwave_env ? 0 : 2), sums, C, ft));
         VT_CHECK_LAUNCH("vt_bn_act_bwd_reduce");
         return VT_OK;
     }
     VT_DISPATCH_T(dtype, "vt_bn_act_bwd_reduce",
                   hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(rm.blocks(M), cgroups), dim3(kThreads), smem,
                                      (hipStream_t)stream, (const T*)dy, lddy, (const T*)z, ldz, scale, shift,
-                                     mean, invstd, (long)M, Cg, rm, (relu ? 1 : 0) | (inwave_env ? 0 : 2), sums, C));
+                                     mean, invstd, (long)M, Cg, rm, (relu ? 1 : 0) | (inwave_env ? 0 : 2), sums, C, ft));
     VT_CHECK_LAUNCH("vt_bn_act_bwd_reduce");
     return VT_OK;
+}
+
+int vt_bn_act_bwd_reduce(const void* dy, int32_t lddy, const void* z, int32_t ldz, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, int64_t M, int32_t C,
+                         int32_t relu, int32_t dtype, float* sums, void* stream) {
+    return bwd_reduce_impl(dy, lddy, z, ldz, scale, shift, mean, invstd, M, C, relu, dtype, sums, VtFinBwd{}, nullptr, stream);
+}
+
+// vt_bn_act_bwd_reduce + vt_bn_bwd_finalize; ONE launch where the finalize step fits the reduction's tail (vt_fin_tail.h)
+int vt_bn_act_bwd_reduce_finalize(const void* dy, int32_t lddy, const void* z, int32_t ldz, const float* scale,
+                                  const float* shift, const float* mean, const float* invstd, int64_t M, int32_t C,
+                                  int32_t relu, int32_t dtype, float* sums, double count, double pscale, int32_t train,
+                                  float* dgamma, float* dbeta, float* coef, uint32_t* tickets, void* stream) {
+    VT_REQUIRE(coef && count > 0 && C > 0, VT_ERR_INVALID, "vt_bn_act_bwd_reduce_finalize: bad argument");
+    VtFinBwd ft{(tickets && VT_KNOB("VT_FIN_TAIL", 1)) ? tickets : nullptr, sums, scale, mean, invstd, dgamma, dbeta, coef,
+                1.0 / count, pscale, C, train};
+    int tail = 0;
+#ifdef VT_TAIL_DIAG_NOWORK
+    {
+        static long calls = 0;
+        static const long after = getenv("VT_DIAG_NOWORK_AFTER") ? atol(getenv("VT_DIAG_NOWORK_AFTER")) : (1L << 60);
+        if (++calls > after) ft.train |= 0x100;
+    }
+#endif
+    VT_TRY(bwd_reduce_impl(dy, lddy, z, ldz, scale, shift, mean, invstd, M, C, relu, dtype, sums, ft, &tail, stream));
+    if (tail) return VT_OK;
+    return vt_bn_bwd_finalize(sums, C, count, pscale, scale, mean, invstd, train, dgamma, dbeta, coef, stream);
 }
 
 int vt_bn_bwd_finalize(const float* sums, int32_t C, double count, double pscale, const float* scale, const float* mean,
@@ -1953,8 +1851,8 @@ int vt_bn_bwd_finalize(const float* sums, int32_t C, double count, double pscale
                        void* stream) {
     VT_REQUIRE(sums && scale && mean && invstd && coef && C > 0 && count > 0, VT_ERR_INVALID,
                "vt_bn_bwd_finalize: bad argument");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums,
-                       C, 1.0 / count, pscale, scale, mean, invstd, train, dgamma, dbeta, coef);
+    VtFinBwd f{nullptr, sums, scale, mean, invstd, dgamma, dbeta, coef, 1.0 / count, pscale, C, train};
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, f);
     VT_CHECK_LAUNCH("vt_bn_bwd_finalize");
     return VT_OK;
 }

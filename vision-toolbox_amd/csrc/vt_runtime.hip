@@ -114,6 +114,15 @@ inline void* rp(const vt_op& op, int k, void* const* bases, int nbases, bool* ba
     return (char*)bases[p.base] + p.offset;
 }
 
+#ifdef VT_DIAG_SKIP_FIN
+// the first VT_DIAG_SKIP_FIN_AFTER finalize ops run (the coefficient rows hold real values), the later ones are skipped
+static bool vt_diag_skip_fin(int which) {  // which: 1 forward, 2 backward finalize; VT_DIAG_SKIP_FIN_WHICH: mask of the kinds skipped
+    static long calls = 0;
+    static const long after = getenv("VT_DIAG_SKIP_FIN_AFTER") ? atol(getenv("VT_DIAG_SKIP_FIN_AFTER")) : (1L << 60);
+    static const int mask = getenv("VT_DIAG_SKIP_FIN_WHICH") ? atoi(getenv("VT_DIAG_SKIP_FIN_WHICH")) : 3;
+    return ++calls > after && (mask & which);
+}
+#endif
 int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
     bool bad = false;
     void* P[VT_OP_MAX_PTR];
@@ -133,6 +142,13 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
             return vt_conv_igemm(&d, P[0], P[1], P[2], (const float*)P[3], (const float*)P[4], P[5],
                                  (float*)P[6], st);
         }
+        case VT_OP_CONV_IGEMM_FIN: {  // ptr: x w y stats gamma beta rm rv nbt scale shift mean invstd tickets | i: vt_conv_desc image | f: count eps momentum
+            vt_conv_desc d;
+            memcpy(&d, I, sizeof(d));
+            return vt_conv_igemm_finalize(&d, P[0], P[1], P[2], (float*)P[3], F[0], (const float*)P[4], (const float*)P[5], (float)F[1],
+                                          (float)F[2], (float*)P[6], (float*)P[7], (int64_t*)P[8], (float*)P[9], (float*)P[10],
+                                          (float*)P[11], (float*)P[12], (uint32_t*)P[13], st);
+        }
         case VT_OP_CONV_DGRAD_BNRED: {  // ptr: dz w dy z scale shift mean invstd sums | i: vt_conv_desc image, then ldz, relu
             vt_conv_desc d;
             memcpy(&d, I, sizeof(d));
@@ -150,6 +166,9 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
         case VT_OP_PACK_DGRAD:  // ptr: w out | i: src_dtype ldw dst_dtype nsel Cout ntaps Cin _ sel[36]
             return vt_pack_dgrad_filter(P[0], I[0], I[1], P[1], I[2], I + 8, I[3], I[4], I[5], I[6], st);
         case VT_OP_BN_FINALIZE:  // ptr: stats gamma beta rm rv nbt scale shift mean invstd | i: C | f: count eps momentum
+#ifdef VT_DIAG_SKIP_FIN  // diagnostic builds (tools/runs/r6_skipfin.sh): what the 134 finalize launches cost inside the step
+            if (vt_diag_skip_fin(1)) return VT_OK;
+#endif
             return vt_bn_finalize((const float*)P[0], I[0], F[0], (const float*)P[1], (const float*)P[2],
                                   (float)F[1], (float)F[2], (float*)P[3], (float*)P[4], (int64_t*)P[5],
                                   (float*)P[6], (float*)P[7], (float*)P[8], (float*)P[9], st);
@@ -171,7 +190,15 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
             return vt_bn_act_bwd_reduce(P[0], I[0], P[1], I[1], (const float*)P[2], (const float*)P[3],
                                         (const float*)P[4], (const float*)P[5], (int64_t)F[0], I[2], I[3],
                                         I[4], (float*)P[6], st);
+        case VT_OP_BN_BWD_REDUCE_FIN:  // ptr: dy z scale shift mean invstd sums dgamma dbeta coef tickets | i: lddy ldz C relu dtype train | f: M count pscale(0 = 1)
+            return vt_bn_act_bwd_reduce_finalize(P[0], I[0], P[1], I[1], (const float*)P[2], (const float*)P[3], (const float*)P[4],
+                                                 (const float*)P[5], (int64_t)F[0], I[2], I[3], I[4], (float*)P[6], F[1],
+                                                 F[2] == 0.0 ? 1.0 : F[2], I[5], (float*)P[7], (float*)P[8], (float*)P[9],
+                                                 (uint32_t*)P[10], st);
         case VT_OP_BN_BWD_FINALIZE:  // ptr: sums scale mean invstd dgamma dbeta coef | i: C train | f: count pscale(0 = 1)
+#ifdef VT_DIAG_SKIP_FIN
+            if (vt_diag_skip_fin(2)) return VT_OK;
+#endif
             return vt_bn_bwd_finalize((const float*)P[0], I[0], F[0], F[1] == 0.0 ? 1.0 : F[1], (const float*)P[1], (const float*)P[2],
                                       (const float*)P[3], I[1], (float*)P[4], (float*)P[5], (float*)P[6], st);
         // depthwise convolution: i: ld0 ld1 [ldr] B Hi Wi C k s pad dil dtype
@@ -183,14 +210,14 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
                                    I[10], I[11], st);
         case VT_OP_DWCONV_WGRAD:  // ptr: x dz dw | i: ldx lddz _ B Hi Wi C k s pad dil dtype
             return vt_dwconv_wgrad(P[0], I[0], P[1], I[1], (float*)P[2], I[3], I[4], I[5], I[6], I[7], I[8], I[9], I[10], I[11], st);
-        case VT_OP_BN_FIN_APPLY:  // ptr: stats gamma beta rm rv nbt scale shift mean invstd ready z residual y | i: C ldz ldr ldy relu dtype | f: count eps momentum M
+        case VT_OP_BN_FIN_APPLY:  // ptr: stats gamma beta rm rv nbt scale shift mean invstd z residual y | i: C ldz ldr ldy relu dtype | f: count eps momentum M
             return vt_bn_finalize_apply((const float*)P[0], I[0], F[0], (const float*)P[1], (const float*)P[2], (float)F[1], (float)F[2],
                                         (float*)P[3], (float*)P[4], (int64_t*)P[5], (float*)P[6], (float*)P[7], (float*)P[8],
-                                        (float*)P[9], P[10], P[11], I[1], P[12], I[2], P[13], I[3], (int64_t)F[3], I[4], I[5], st);
-        case VT_OP_BN_BWD_FIN_APPLY:  // ptr: sums scale shift mean invstd dgamma dbeta coef ready dy z dz | i: C train lddy ldz lddz relu dtype | f: count pscale(0 = 1) M
+                                        (float*)P[9], P[10], I[1], P[11], I[2], P[12], I[3], (int64_t)F[3], I[4], I[5], st);
+        case VT_OP_BN_BWD_FIN_APPLY:  // ptr: sums scale shift mean invstd dgamma dbeta coef dy z dz | i: C train lddy ldz lddz relu dtype | f: count pscale(0 = 1) M
             return vt_bn_bwd_finalize_apply((const float*)P[0], I[0], F[0], F[1] == 0.0 ? 1.0 : F[1], (const float*)P[1],
                                             (const float*)P[2], (const float*)P[3], (const float*)P[4], I[1], (float*)P[5],
-                                            (float*)P[6], (float*)P[7], P[8], P[9], I[2], P[10], I[3], P[11], I[4], (int64_t)F[2],
+                                            (float*)P[6], (float*)P[7], P[8], I[2], P[9], I[3], P[10], I[4], (int64_t)F[2],
                                             I[5], I[6], st);
         case VT_OP_BN_BWD_FUSED:  // ptr: dy z scale shift mean invstd sums sync dgamma dbeta coef dz | i: lddy ldz lddz C relu dtype train | f: M count pscale(0 = 1)
             return vt_bn_act_bwd_fused(P[0], I[0], P[1], I[1], (const float*)P[2], (const float*)P[3], (const float*)P[4],

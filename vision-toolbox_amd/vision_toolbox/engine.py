@@ -312,12 +312,18 @@ class Builder:
         self.bn_bwd_fused = os.environ.get("VT_BN_BWD_FUSED", "0") != "0"
         self._last_dgrad: dict[int, tuple] = {}  # id(gradient Buf) -> (op, c0, c1)
         # The finalize launches folded into the streaming launches that consume their coefficients (vt_bn_finalize_apply,
-        # vt_bn_bwd_finalize_apply: the first workgroups finalize and publish, every workgroup polls once).  Not with
-        # SyncBatchNorm (the statistics are exchanged in front of the finalize).  OFF by default: bit-identical, and 2.3 ms
-        # SLOWER in the step -- the coefficients reach every one of up to 4096 workgroups through device-scope (cache-bypassing)
-        # loads behind a polled counter, two dependent round trips at the head of every workgroup, against one ~5 us launch
-        # (NOTEBOOK R6.6).  VT_BN_FIN_APPLY=1 turns it on.
-        self.bn_fin_apply = os.environ.get("VT_BN_FIN_APPLY", "0") != "0"
+        # vt_bn_bwd_finalize_apply): every workgroup of the pass finalizes the channels of its own channel group from the
+        # (complete) sums -- nothing is handed over inside the launch -- and the single-workgroup finalize launch between a
+        # producer of statistics and its consumer disappears: 98 of the 134 of a CSPDarknet-53 step, 19.997 -> 19.55 ms
+        # (NOTEBOOK R6.10).  Bit-identical.  Not with SyncBatchNorm (the statistics are exchanged in front of the finalize).
+        # VT_BN_FIN_APPLY=0 keeps the separate launches.  (The first form -- the first workgroups finalize and publish, all
+        # others poll -- measured 2.3 ms SLOWER, R6.6.)
+        self.bn_fin_apply = os.environ.get("VT_BN_FIN_APPLY", "1") != "0"
+        # The finalize step as the TAIL of the launch that produces its sums (vt_bn_act_bwd_reduce_finalize,
+        # vt_conv_igemm_finalize, csrc/vt_fin_tail.h): every workgroup takes a ticket and the last one finalizes; nobody waits.
+        # Bit-identical, and NO faster than the launch it replaces (19.60 against 19.58 ms: the tail is the same chain of
+        # dependent memory-side round trips, NOTEBOOK R6.10): off; VT_FIN_TAIL=1 turns it on where VT_BN_FIN_APPLY does not apply.
+        self.fin_tail = os.environ.get("VT_FIN_TAIL", "0") != "0"
         self._wg_expect: dict[tuple, int] = {}   # shape key -> units seen in forward and not yet released
         self._wg_pending: dict[tuple, list] = {}  # shape key -> [(x addr, dz addr, dw addr, desc, ldw)]
         # SyncBatchNorm (configs/base.yaml:22): the trainer all-reduces every layer's statistics
@@ -688,10 +694,21 @@ class Builder:
             if unit_training:
                 stats = self.zeroed_f32(N.stat_floats(Cout), "stats")
                 d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, z.ld, ldw, N.VT_CONV_STATS, dil=dil)
-                self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, z.addr(), None, None, None, self.bp(stats)], desc=d)
                 fin_fwd = (self.bn_fin_apply and self.bn_world == 1 and not generic_act and
                            not (pool_out is not None and not generic_act))
-                if not fin_fwd:
+                if self.fin_tail and self.bn_world == 1 and not fin_fwd:
+                    # conv + finalize: the finalize step is the tail of the convolution launch where its kernel has one
+                    # (vt_conv_igemm_finalize, csrc/vt_fin_tail.h), a second launch inside the same op elsewhere
+                    self.emit(N.OP_CONV_IGEMM_FIN,
+                              [x.addr(), wptr, z.addr(), self.bp(stats), g, b_, rm, rv, nbt, *cp,
+                               self.bp(self.zeroed_f32(N.VT_FIN_TICKETS, "fintickets"))],
+                              flts=[M * self.bn_world, norm.eps, norm.momentum], desc=d)
+                    fin_fwd = None  # (finalized)
+                else:
+                    self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, z.addr(), None, None, None, self.bp(stats)], desc=d)
+                if fin_fwd is None:
+                    fin_fwd = False
+                elif not fin_fwd:
                     self.emit(N.OP_BN_FINALIZE,
                               [self.bp(stats), g, b_, rm, rv, nbt, *cp],
                               [Cout], [M * self.bn_world, norm.eps, norm.momentum])
@@ -709,9 +726,8 @@ class Builder:
                            self.bp(pool_am)],
                           [z.ld, residual.ld if residual else 0, y.ld, Cout, int(relu), dt, pool_out.ld, B, Ho, Wo], [M])
             elif fin_fwd:
-                ready = self.zeroed_f32(4, "finready")
                 self.emit(N.OP_BN_FIN_APPLY,
-                          [self.bp(stats), g, b_, rm, rv, nbt, *cp, self.bp(ready), z.addr(),
+                          [self.bp(stats), g, b_, rm, rv, nbt, *cp, z.addr(),
                            residual.addr() if residual else None, y.addr()],
                           [Cout, z.ld, residual.ld if residual else 0, y.ld, int(relu), dt],
                           [M * self.bn_world, norm.eps, norm.momentum, M])
@@ -821,6 +837,7 @@ class Builder:
                                    self.pgrad(norm.weight), self.pgrad(norm.bias), self.bp(bcoef), dz.addr()],
                                   [dy.ld, z.ld, dz.ld, Cout, int(relu), dt, int(training)], [M, M * self.bn_world, 1.0 / self.bn_world])
                     else:
+                        tail_fin = False
                         if fused_red:
                             # d(y) came out of ONE data-gradient launch and nothing was added to it since: that launch also forms
                             # this unit's backward sums (the op is patched in place: ptr dz w dy | z scale shift mean invstd sums)
@@ -831,15 +848,25 @@ class Builder:
                             k0 = C.sizeof(N.ConvDesc) // 4
                             fop.i[k0], fop.i[k0 + 1] = z.ld, int(relu)
                             self._last_dgrad.pop(id(dy.buf), None)
+                        elif self.fin_tail and self.bn_world == 1 and pool_grad is None and not self.bn_fin_apply:
+                            # reduce + finalize: the finalize step is the tail of the reduction launch (vt_fin_tail.h)
+                            tail_fin = True
+                            self.emit(N.OP_BN_BWD_REDUCE_FIN,
+                                      [g_.addr(), z.addr(), cp[0], cp[1], cp[2], cp[3], self.bp(sums), self.pgrad(norm.weight),
+                                       self.pgrad(norm.bias), self.bp(bcoef), self.bp(self.zeroed_f32(N.VT_FIN_TICKETS, "fintickets"))],
+                                      [g_.ld, z.ld, Cout, int(relu), dt, int(training)], [M, M * self.bn_world, 1.0 / self.bn_world])
                         else:
                             self.emit(N.OP_BN_BWD_REDUCE,
                                       [g_.addr(), z.addr(), cp[0], cp[1], cp[2], cp[3], self.bp(sums)] + am_,
                                       [g_.ld, z.ld, Cout, int(relu), dt] + geo, [M])
-                        if self.bn_fin_apply and self.bn_world == 1 and pool_grad is None and not generic_act:
-                            ready = self.zeroed_f32(4, "finready")
+                        if tail_fin:
+                            self.emit(N.OP_BN_BWD_APPLY,
+                                      [g_.addr(), z.addr(), cp[0], cp[1], self.bp(bcoef), dz.addr()] + am_,
+                                      [g_.ld, z.ld, dz.ld, Cout, int(relu), dt] + geo, [M])
+                        elif self.bn_fin_apply and self.bn_world == 1 and pool_grad is None and not generic_act:
                             self.emit(N.OP_BN_BWD_FIN_APPLY,
                                       [self.bp(sums), cp[0], cp[1], cp[2], cp[3], self.pgrad(norm.weight), self.pgrad(norm.bias),
-                                       self.bp(bcoef), self.bp(ready), g_.addr(), z.addr(), dz.addr()],
+                                       self.bp(bcoef), g_.addr(), z.addr(), dz.addr()],
                                       [Cout, int(training), g_.ld, z.ld, dz.ld, int(relu), dt],
                                       [M * self.bn_world, 1.0 / self.bn_world, M])
                         else:
