@@ -218,11 +218,12 @@ def test_config1_darknet19_forward_on_cpu(golden_dir):
 @pytest.mark.parametrize("mode", ["train", "eval"])
 def test_necks_cpu_vs_reference(golden_dir, mode):
     """FPN / PAN on CPU tensors (same dispatch rule) against the unmodified reference's fixtures"""
-    from test_necks import CASES, _inputs, _loss  # same case table as the oracle / GPU tests
+    from test_necks import CASES, _case, _inputs, _loss, _make  # same case table as the oracle / GPU tests
 
     g = np.load(golden_dir / "necks.npz")
-    for name, (kind, ins, outc, td, sizes, B) in CASES.items():
-        m = necks.FPN(list(ins), outc, top_down=td) if kind == "fpn" else necks.PAN(list(ins), outc)
+    for name in CASES:  # (round 6: fuse_fn="concat" and interpolation_mode="bilinear" cases too)
+        kind, ins, outc, td, sizes, B, fuse, interp = _case(name)
+        m = _make(necks, name)
         filler.fill_module(m, name + ".")
         m.train(mode == "train")
         xs = _inputs(name, ins, sizes, B)
@@ -245,11 +246,12 @@ def test_frozen_batchnorm_and_requires_grad_reach_the_compiled_program():
     x = torch.zeros(2, 3, 64, 64)
     p0 = r.program(x, N.VT_F32, True, True)
     n_units = p0.n_units
-    assert p0.kind_histogram["bn_finalize"] == n_units and p0.kind_histogram["conv_wgrad"] == n_units
+    # (round 6: the finalize step of a training-mode BatchNorm runs inside the normalise pass, vt_bn_finalize_apply)
+    assert p0.kind_histogram["bn_fin_apply"] == n_units and p0.kind_histogram["conv_wgrad"] == n_units
     m.stem.norm.eval()  # frozen BatchNorm: running statistics, which must not be updated
     p1 = r.program(x, N.VT_F32, True, True)
     assert p1 is not p0
-    assert p1.kind_histogram["bn_finalize"] == n_units - 1 and p1.kind_histogram["bn_eval_coeffs"] == 1
+    assert p1.kind_histogram["bn_fin_apply"] == n_units - 1 and p1.kind_histogram["bn_eval_coeffs"] == 1
     m.stem.conv.weight.requires_grad_(False)
     p2 = r.program(x, N.VT_F32, True, True)
     assert p2 is not p1 and p2.kind_histogram["conv_wgrad"] == n_units - 1
