@@ -372,6 +372,35 @@ int vt_pw_bwd_reduce(const vt_pw_desc* d, const float* coef, const void* const* 
 int vt_pw_bwd_apply(const vt_pw_desc* d, const float* coef, const void* const* dy, const int32_t* lddy,
                     const float* const* bcoef, void* dx, int32_t lddx, const void* addend, int32_t ldadd,
                     float* const* dw, const int32_t* lddw, void* const* dz, const int32_t* lddz, void* stream);
+/* The two apply passes with the BatchNorm finalize step of every group INSIDE them (round 6; as vt_bn_finalize_apply): a
+ * workgroup stages the coefficients in LDS anyway, so every workgroup computes them itself from the complete sums of the pass
+ * before, and workgroup 0 stores what the later passes read.  Same values bit for bit as
+ *   vt_bn_finalize(fin[g].stats, C[g], fin[g].count, gamma, beta, eps, momentum, running_mean, running_var,
+ *                  num_batches_tracked, coef + off_g, coef + N + off_g, coef + 2N + off_g, coef + 3N + off_g) per group, then
+ *   vt_pw_fwd_apply(d, coef, ...)                                              (off_g = 0 | C[0], N = C[0] + C[1]);
+ *   vt_bn_bwd_finalize(fin[g].sums, C[g], fin[g].count, fin[g].pscale, coef + off_g, coef + 2N + off_g, coef + 3N + off_g,
+ *                      fin[g].train, fin[g].dgamma, fin[g].dbeta, bcoef[g]) per group, then vt_pw_bwd_apply(d, coef, ...).
+ * Those calls run where N > 128 or with the knob VT_BN_FIN_APPLY = 0.  `fin` has ngroups entries. */
+typedef struct vt_bn_fin_fwd {
+    const float* stats; /* statistics buffer of the group (vt_pw_fwd_stats) */
+    double count;
+    const float *gamma, *beta; /* NULL: 1 / 0 */
+    float eps, momentum;
+    float *running_mean, *running_var; /* both or neither */
+    int64_t* num_batches_tracked;      /* optional */
+} vt_bn_fin_fwd;
+typedef struct vt_bn_fin_bwd {
+    const float* sums; /* sums buffer of the group (vt_pw_bwd_reduce) */
+    double count, pscale;
+    int32_t train;
+    float *dgamma, *dbeta; /* optional, accumulated */
+} vt_bn_fin_bwd;
+int vt_pw_fwd_apply_finalize(const vt_pw_desc* d, const vt_bn_fin_fwd* fin, float* coef, void* const* y, const int32_t* ldy,
+                             const void* const* res, const int32_t* ldr, void* stream);
+int vt_pw_bwd_apply_finalize(const vt_pw_desc* d, const float* coef, const void* const* dy, const int32_t* lddy,
+                             const vt_bn_fin_bwd* fin, float* const* bcoef, void* dx, int32_t lddx, const void* addend,
+                             int32_t ldadd, float* const* dw, const int32_t* lddw, void* const* dz, const int32_t* lddz,
+                             void* stream);
 
 /* ---- pooling ------------------------------------------------------------ */
 /* The normalise pass fused with the MaxPool2d(3, 2, 1) that reads its output (VoVNet: `stage.max_pool` on the previous
@@ -495,7 +524,7 @@ int vt_nhwc_to_nchw(const void* y, int32_t ldy, float* x, int32_t B, int32_t C, 
  * the list once per (model, input shape) and replays it with one call, or as a
  * captured hipGraph.  Pointers are (base, byte offset) pairs so one list serves
  * any arena placement. */
-#define VT_OP_MAX_PTR 16
+#define VT_OP_MAX_PTR 24
 #define VT_OP_MAX_INT 110
 #define VT_OP_MAX_FLT 8
 #define VT_MAX_BASES 16
@@ -550,6 +579,8 @@ enum vt_op_kind {
     VT_OP_DWCONV_WGRAD,     /* vt_dwconv_wgrad */
     VT_OP_BN_BWD_REDUCE_FIN, /* vt_bn_act_bwd_reduce_finalize */
     VT_OP_CONV_IGEMM_FIN,    /* vt_conv_igemm_finalize */
+    VT_OP_PW_APPLY_FIN,      /* vt_pw_fwd_apply_finalize */
+    VT_OP_PW_BWD_FIN,        /* vt_pw_bwd_apply_finalize */
     VT_OP_KIND_END
 };
 

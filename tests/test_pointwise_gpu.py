@@ -243,3 +243,88 @@ def test_apply_pass_on_the_80_channel_shapes(M, K, slack, relu, with_res):
     # the statistics / backward passes have no such shapes: they must refuse, not run a wrong kernel
     stats = N.stats_buffer(Cout)
     assert lib.vt_pw_fwd_stats(C.byref(d), _vps([stats]), stream()) == N.VT_ERR_UNSUPPORTED
+
+
+FIN_CASES = [c for c in CASES if sum(c[2]) <= 128] + [(1555, 160, [160], 0, True)]  # (160 channels: the separate launches inside)
+
+
+@pytest.mark.parametrize("case", FIN_CASES, ids=lambda c: f"M{c[0]}_K{c[1]}_C{'+'.join(map(str, c[2]))}_s{c[3]}_r{int(c[4])}")
+def test_apply_passes_that_finalize_for_themselves_are_bit_identical(case):
+    """vt_pw_fwd_apply_finalize / vt_pw_bwd_apply_finalize (round 6: every workgroup finalizes the BatchNorm coefficients in its
+    prologue) against vt_bn_finalize + vt_pw_fwd_apply and vt_bn_bwd_finalize + vt_pw_bwd_apply per group: every output EQUAL
+    (coefficients, running statistics, batch counters, y; d(gamma), d(beta), the backward coefficients, dx, dz; dW up to
+    the order of its f32 atomics), one launch
+    instead of 1 + ngroups."""
+    M, K, Cs, slack, relu = case
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(M + K)
+    G, Nn = len(Cs), sum(Cs)
+    lib, st = N.lib(), stream()
+    x = _rows(M, K, slack, gen)
+    ws = [(torch.randn(c, K, device="cuda", generator=gen) * (2.0 / K) ** 0.5).to(BF) for c in Cs]
+    pd = _desc(x, ws, relu)
+    gammas = [torch.rand(c, device="cuda", generator=gen) + 0.5 for c in Cs]
+    betas = [torch.randn(c, device="cuda", generator=gen) * 0.2 for c in Cs]
+    ress = [_rows(M, c, 0, gen) for c in Cs]
+    dys = [_rows(M, c, 0, gen) for c in Cs]
+    add = _rows(M, K, 0, gen)
+    stats = [N.stats_buffer(c) for c in Cs]
+    N.check(lib.vt_pw_fwd_stats(C.byref(pd), _vps(stats), st))
+    full = Nn * K <= 4096
+    offs = [0, Cs[0]]
+    ldy = _arr(C.c_int32, Cs)
+
+    def run(fused):
+        coef = torch.full((4, Nn), float("nan"), device="cuda")
+        rms, rvs = [torch.full((c,), 0.1, device="cuda") for c in Cs], [torch.full((c,), 0.9, device="cuda") for c in Cs]
+        nbts = [torch.full((1,), 3 + g, dtype=torch.int64, device="cuda") for g in range(G)]
+        ys = [torch.full((M, c), float("nan"), device="cuda", dtype=BF) for c in Cs]
+        before = N.launch_count()
+        if fused:
+            fin = (N.BnFinFwd * G)()
+            for g in range(G):
+                fin[g] = N.BnFinFwd(stats[g].data_ptr(), float(M), gammas[g].data_ptr(), betas[g].data_ptr(), 1e-5, 0.1, rms[g].data_ptr(),
+                                    rvs[g].data_ptr(), nbts[g].data_ptr())
+            N.check(lib.vt_pw_fwd_apply_finalize(C.byref(pd), fin, coef.data_ptr(), _vps(ys), ldy, _vps(ress), ldy, st))
+        else:
+            for g in range(G):
+                rows = [coef[i, offs[g]:offs[g] + Cs[g]].data_ptr() for i in range(4)]
+                N.check(lib.vt_bn_finalize(stats[g].data_ptr(), Cs[g], float(M), gammas[g].data_ptr(), betas[g].data_ptr(), 1e-5, 0.1,
+                                           rms[g].data_ptr(), rvs[g].data_ptr(), nbts[g].data_ptr(), *rows, st))
+            N.check(lib.vt_pw_fwd_apply(C.byref(pd), coef.data_ptr(), _vps(ys), ldy, _vps(ress), ldy, st))
+        torch.cuda.synchronize()
+        n_fwd = N.launch_count() - before
+        # backward on the coefficients just made
+        sums = [N.stats_buffer(c) for c in Cs]
+        N.check(lib.vt_pw_bwd_reduce(C.byref(pd), coef.data_ptr(), _vps(dys), ldy, _vps(sums), st))
+        dgs, dbs = [torch.full((c,), 0.25, device="cuda") for c in Cs], [torch.full((c,), -0.5, device="cuda") for c in Cs]
+        bcoefs = [torch.full((3, c), float("nan"), device="cuda") for c in Cs]
+        dx = torch.full((M, K), float("nan"), device="cuda", dtype=BF)
+        dws = [torch.full((c, K), 0.5, device="cuda") if full else None for c in Cs]
+        dzs = [None if full else torch.full((M, c), float("nan"), device="cuda", dtype=BF) for c in Cs]
+        tail = (dx.data_ptr(), K, add.data_ptr(), K, _vps(dws), _arr(C.c_int32, [K] * G), _vps(dzs), ldy, st)
+        before = N.launch_count()
+        if fused:
+            bfin = (N.BnFinBwd * G)()
+            for g in range(G):
+                bfin[g] = N.BnFinBwd(sums[g].data_ptr(), float(M), 0.5, 1, dgs[g].data_ptr(), dbs[g].data_ptr())
+            N.check(lib.vt_pw_bwd_apply_finalize(C.byref(pd), coef.data_ptr(), _vps(dys), ldy, bfin, _vps(bcoefs), *tail))
+        else:
+            for g in range(G):
+                sl = slice(offs[g], offs[g] + Cs[g])
+                N.check(lib.vt_bn_bwd_finalize(sums[g].data_ptr(), Cs[g], float(M), 0.5, coef[0, sl].data_ptr(), coef[2, sl].data_ptr(),
+                                               coef[3, sl].data_ptr(), 1, dgs[g].data_ptr(), dbs[g].data_ptr(), bcoefs[g].data_ptr(), st))
+            N.check(lib.vt_pw_bwd_apply(C.byref(pd), coef.data_ptr(), _vps(dys), ldy, _vps(bcoefs), *tail))
+        torch.cuda.synchronize()
+        n_bwd = N.launch_count() - before
+        outs = [coef, *rms, *rvs, *nbts, *ys, *dgs, *dbs, *bcoefs, dx, *[t for t in dzs if t is not None]]
+        return outs, [t for t in dws if t is not None], n_fwd, n_bwd
+
+    ref, dw0, nf0, nb0 = run(False)
+    got, dw1, nf1, nb1 = run(True)
+    for a, b in zip(dw1, dw0):  # (f32 atomics across workgroups: equal up to the order of the partial sums)
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * b.abs().max().item())
+    assert (nf0, nb0) == (1 + G, 1 + G)
+    assert (nf1, nb1) == ((1, 1) if Nn <= 128 else (1 + G, 1 + G))
+    for a, b in zip(got, ref):
+        assert torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())) and torch.equal(torch.isnan(a.float()), torch.isnan(b.float()))

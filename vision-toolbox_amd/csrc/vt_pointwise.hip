@@ -47,6 +47,7 @@
 #include <hip/hip_ext.h>
 
 #include "vt_common.h"
+#include "vt_fin_tail.h"
 
 namespace {
 
@@ -94,6 +95,12 @@ struct PwArgs {
     // outputs beyond them do not exist (zero rows / columns of the LDS image, masked stores), and an x or residual load
     // beyond them reads the pixel's first 16 bytes instead (times a zero filter column / never stored)
     int Nr, Kr;
+    // vt_pw_fwd_apply_finalize / vt_pw_bwd_apply_finalize: the BatchNorm finalize step of each group runs in the prologue of
+    // EVERY workgroup (it stages the coefficients in LDS anyway), from the complete sums of the pass before -- see
+    // vt_bn_finalize_apply in vt_elementwise.hip; workgroup 0 stores the results.  N <= 128 (a thread pair per channel).
+    int fin;
+    VtFinFwd ffin[2];  // APPLY
+    VtFinBwd bfin[2];  // BWD
 };
 
 __device__ __forceinline__ uint4 ldg16(const bf16_t* p) { return *(const uint4*)p; }
@@ -147,7 +154,43 @@ __global__ void __launch_bounds__(256) pw_kernel(const PwArgs a) {
         const bool real = n < a.Nr && ch * 8 < a.Kr;
         *(uint4*)(sW + n * PITCH + ch * 16) = real ? ldg16(src) : make_uint4(0, 0, 0, 0);
     }
-    if (MODE != PW_STATS) {
+    bool fin_done = false;
+    if constexpr ((MODE == PW_APPLY || MODE == PW_BWD) && N <= 128) {
+        if (a.fin) {
+            // thread pair (w, n): the two sums of channel n, 16 replicas x 2 limbs in one round of loads
+            fin_done = true;
+            const int w = tid & 1, n = tid >> 1;
+            const bool on = n < a.Nr;
+            const int g = (on && n >= N0) ? 1 : 0, lc = on ? n - (g ? N0 : 0) : 0;
+            if constexpr (MODE == PW_APPLY) {
+                const VtFinFwd& f = a.ffin[g];
+                const VtFinFwdPre pre = vt_fin_fwd_pre(f, lc);
+                const double v = vt_replica_sum<false>(f.stats, (long)w * f.C + lc, 2L * f.C);
+                const double o = __shfl_xor(v, 1, 64);
+                if (on && w == 0) {
+                    float sc, sf;
+                    vt_fin_fwd_channel(f, lc, v, o, pre.g, pre.b, pre.rm, pre.rv, sc, sf, blockIdx.x == 0);
+                    sCoef[n] = sc, sCoef[N + n] = sf;
+                }
+            } else {
+                const VtFinBwd& f = a.bfin[g];
+                const VtFinBwdPre pre = vt_fin_bwd_pre(f, lc);
+                const float sh = on ? a.coef[N + n] : 0.f;
+                const double v = vt_replica_sum<false>(f.sums, (long)w * f.C + lc, 2L * f.C);
+                const double o = __shfl_xor(v, 1, 64);
+                if (on && w == 0) {
+                    float b, d;
+                    vt_fin_bwd_channel(f, lc, v, o, pre.a, pre.mu, pre.istd, pre.dg, pre.db, b, d, blockIdx.x == 0);
+                    sCoef[n] = pre.a, sCoef[N + n] = sh, sCoef[2 * N + n] = pre.a, sCoef[3 * N + n] = b, sCoef[4 * N + n] = d;
+                }
+            }
+            for (int i = tid; i < 5 * N; i += 256) {  // rows and channels the pairs above do not own
+                const int which = i / N, n2 = i - which * N;
+                if (n2 >= a.Nr || which >= (MODE == PW_APPLY ? 2 : 5)) sCoef[i] = 0.f;
+            }
+        }
+    }
+    if (MODE != PW_STATS && !fin_done) {
         for (int i = tid; i < 5 * N; i += 256) {
             const int which = i / N, n = i - which * N;
             float v = 0.f;
@@ -610,13 +653,25 @@ int vt_pw_fwd_stats(const vt_pw_desc* d, float* const* stats, void* stream) {
     return dispatch_pw<PW_STATS>(a.N0 + (d->ngroups == 2 ? d->C[1] : 0), d->K, a, (hipStream_t)stream, "vt_pw_fwd_stats");
 }
 
-int vt_pw_fwd_apply(const vt_pw_desc* d, const float* coef, void* const* y, const int32_t* ldy, const void* const* res,
-                    const int32_t* ldr, void* stream) {
+static int pw_fwd_apply_impl(const vt_pw_desc* d, const float* coef, void* const* y, const int32_t* ldy, const void* const* res,
+                             const int32_t* ldr, const vt_bn_fin_fwd* fin, void* stream) {
     PwArgs a;
     int rc = fill_common(a, d, "vt_pw_fwd_apply", true);
     if (rc != VT_OK) return rc;
     VT_REQUIRE(coef && y && ldy, VT_ERR_INVALID, "vt_pw_fwd_apply: null argument");
     a.coef = coef;
+    if (fin) {  // (checked by vt_pw_fwd_apply_finalize)
+        const int Ntot = d->C[0] + (d->ngroups == 2 ? d->C[1] : 0);
+        a.fin = 1;
+        for (int g = 0; g < d->ngroups; ++g) {
+            const int off = g ? d->C[0] : 0;
+            float* c = (float*)coef;
+            a.ffin[g] = VtFinFwd{nullptr, fin[g].stats, fin[g].gamma, fin[g].beta, fin[g].running_mean, fin[g].running_var,
+                                 fin[g].num_batches_tracked, c + off, c + Ntot + off, c + 2 * Ntot + off, c + 3 * Ntot + off,
+                                 1.0 / fin[g].count, fin[g].count > 1.0 ? fin[g].count / (fin[g].count - 1.0) : 1.0, fin[g].eps,
+                                 fin[g].momentum, d->C[g]};
+        }
+    }
     const bool any_res = res && (res[0] || (d->ngroups == 2 && res[1]));
     for (int g = 0; g < d->ngroups; ++g) {
         VT_REQUIRE(!any_res || res[g], VT_ERR_UNSUPPORTED, "vt_pw_fwd_apply: a residual for every group or for none");
@@ -631,6 +686,33 @@ int vt_pw_fwd_apply(const vt_pw_desc* d, const float* coef, void* const* y, cons
         }
     }
     return dispatch_pw<PW_APPLY>(a.N0 + (d->ngroups == 2 ? d->C[1] : 0), d->K, a, (hipStream_t)stream, "vt_pw_fwd_apply");
+}
+
+int vt_pw_fwd_apply(const vt_pw_desc* d, const float* coef, void* const* y, const int32_t* ldy, const void* const* res,
+                    const int32_t* ldr, void* stream) {
+    return pw_fwd_apply_impl(d, coef, y, ldy, res, ldr, nullptr, stream);
+}
+
+int vt_pw_fwd_apply_finalize(const vt_pw_desc* d, const vt_bn_fin_fwd* fin, float* coef, void* const* y, const int32_t* ldy,
+                             const void* const* res, const int32_t* ldr, void* stream) {
+    VT_REQUIRE(d && fin && coef && (d->ngroups == 1 || d->ngroups == 2), VT_ERR_INVALID, "vt_pw_fwd_apply_finalize: null argument");
+    const int N = d->C[0] + (d->ngroups == 2 ? d->C[1] : 0);
+    for (int g = 0; g < d->ngroups; ++g) {
+        VT_REQUIRE(fin[g].stats && fin[g].count > 0, VT_ERR_INVALID, "vt_pw_fwd_apply_finalize: bad statistics of group %d", g);
+        VT_REQUIRE((fin[g].running_mean == nullptr) == (fin[g].running_var == nullptr), VT_ERR_INVALID,
+                   "vt_pw_fwd_apply_finalize: running_mean/var must both be given or both NULL");
+    }
+    if (N > 128 || !VT_KNOB("VT_BN_FIN_APPLY", 1)) {
+        for (int g = 0; g < d->ngroups; ++g) {
+            const int off = g ? d->C[0] : 0;
+            const int rc = vt_bn_finalize(fin[g].stats, d->C[g], fin[g].count, fin[g].gamma, fin[g].beta, fin[g].eps, fin[g].momentum,
+                                          fin[g].running_mean, fin[g].running_var, fin[g].num_batches_tracked, coef + off,
+                                          coef + N + off, coef + 2 * N + off, coef + 3 * N + off, stream);
+            if (rc != VT_OK) return rc;
+        }
+        return pw_fwd_apply_impl(d, coef, y, ldy, res, ldr, nullptr, stream);
+    }
+    return pw_fwd_apply_impl(d, coef, y, ldy, res, ldr, fin, stream);
 }
 
 int vt_pw_bwd_reduce(const vt_pw_desc* d, const float* coef, const void* const* dy, const int32_t* lddy,
@@ -650,14 +732,24 @@ int vt_pw_bwd_reduce(const vt_pw_desc* d, const float* coef, const void* const* 
     return dispatch_pw<PW_REDUCE>(a.N0 + (d->ngroups == 2 ? d->C[1] : 0), d->K, a, (hipStream_t)stream, "vt_pw_bwd_reduce");
 }
 
-int vt_pw_bwd_apply(const vt_pw_desc* d, const float* coef, const void* const* dy, const int32_t* lddy,
-                    const float* const* bcoef, void* dx, int32_t lddx, const void* addend, int32_t ldadd,
-                    float* const* dw, const int32_t* lddw, void* const* dz, const int32_t* lddz, void* stream) {
+static int pw_bwd_apply_impl(const vt_pw_desc* d, const float* coef, const void* const* dy, const int32_t* lddy,
+                             const float* const* bcoef, void* dx, int32_t lddx, const void* addend, int32_t ldadd,
+                             float* const* dw, const int32_t* lddw, void* const* dz, const int32_t* lddz,
+                             const vt_bn_fin_bwd* fin, void* stream) {
     PwArgs a;
     int rc = fill_common(a, d, "vt_pw_bwd_apply");
     if (rc != VT_OK) return rc;
     VT_REQUIRE(coef && dy && lddy && bcoef, VT_ERR_INVALID, "vt_pw_bwd_apply: null argument");
     const int N = a.N0 + (d->ngroups == 2 ? d->C[1] : 0);
+    if (fin) {  // (checked by vt_pw_bwd_apply_finalize)
+        a.fin = 1;
+        for (int g = 0; g < d->ngroups; ++g) {
+            const int off = g ? d->C[0] : 0;
+            VT_REQUIRE(bcoef[g], VT_ERR_INVALID, "vt_pw_bwd_apply_finalize: null coefficients");
+            a.bfin[g] = VtFinBwd{nullptr, fin[g].sums, coef + off, coef + 2 * N + off, coef + 3 * N + off, fin[g].dgamma, fin[g].dbeta,
+                                 (float*)bcoef[g], 1.0 / fin[g].count, fin[g].pscale, d->C[g], fin[g].train};
+        }
+    }
     const bool full = (int64_t)N * d->K <= 4096;
     a.coef = coef;
     VT_REQUIRE(dx && vt_aligned16(dx) && lddx % 8 == 0 && lddx >= d->K, VT_ERR_INVALID, "vt_pw_bwd_apply: bad dx");
@@ -691,6 +783,33 @@ int vt_pw_bwd_apply(const vt_pw_desc* d, const float* coef, const void* const* d
         }
     }
     return dispatch_pw<PW_BWD>(N, d->K, a, (hipStream_t)stream, "vt_pw_bwd_apply");
+}
+
+int vt_pw_bwd_apply(const vt_pw_desc* d, const float* coef, const void* const* dy, const int32_t* lddy,
+                    const float* const* bcoef, void* dx, int32_t lddx, const void* addend, int32_t ldadd,
+                    float* const* dw, const int32_t* lddw, void* const* dz, const int32_t* lddz, void* stream) {
+    return pw_bwd_apply_impl(d, coef, dy, lddy, bcoef, dx, lddx, addend, ldadd, dw, lddw, dz, lddz, nullptr, stream);
+}
+
+int vt_pw_bwd_apply_finalize(const vt_pw_desc* d, const float* coef, const void* const* dy, const int32_t* lddy,
+                             const vt_bn_fin_bwd* fin, float* const* bcoef, void* dx, int32_t lddx, const void* addend,
+                             int32_t ldadd, float* const* dw, const int32_t* lddw, void* const* dz, const int32_t* lddz,
+                             void* stream) {
+    VT_REQUIRE(d && fin && coef && bcoef && (d->ngroups == 1 || d->ngroups == 2), VT_ERR_INVALID,
+               "vt_pw_bwd_apply_finalize: null argument");
+    const int N = d->C[0] + (d->ngroups == 2 ? d->C[1] : 0);
+    for (int g = 0; g < d->ngroups; ++g)
+        VT_REQUIRE(fin[g].sums && fin[g].count > 0 && bcoef[g], VT_ERR_INVALID, "vt_pw_bwd_apply_finalize: bad sums of group %d", g);
+    if (N > 128 || !VT_KNOB("VT_BN_FIN_APPLY", 1)) {
+        for (int g = 0; g < d->ngroups; ++g) {
+            const int off = g ? d->C[0] : 0;
+            const int rc = vt_bn_bwd_finalize(fin[g].sums, d->C[g], fin[g].count, fin[g].pscale, coef + off, coef + 2 * N + off,
+                                              coef + 3 * N + off, fin[g].train, fin[g].dgamma, fin[g].dbeta, bcoef[g], stream);
+            if (rc != VT_OK) return rc;
+        }
+        return pw_bwd_apply_impl(d, coef, dy, lddy, bcoef, dx, lddx, addend, ldadd, dw, lddw, dz, lddz, nullptr, stream);
+    }
+    return pw_bwd_apply_impl(d, coef, dy, lddy, bcoef, dx, lddx, addend, ldadd, dw, lddw, dz, lddz, fin, stream);
 }
 
 }  // extern "C"

@@ -292,8 +292,11 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
         case VT_OP_PW_STATS:    // ptr: x w0 w1 stats0 stats1
         case VT_OP_PW_APPLY:    // ptr: x w0 w1 coef y0 y1 res0 res1 | i[8..11]: ldy0 ldy1 ldr0 ldr1
         case VT_OP_PW_REDUCE:   // ptr: x w0 w1 coef dy0 dy1 sums0 sums1 | i[8..9]: lddy0 lddy1
-        case VT_OP_PW_BWD: {    // ptr: x w0 w1 coef dy0 dy1 bcoef0 bcoef1 dx addend dw0 dw1 dz0 dz1
+        case VT_OP_PW_BWD:      // ptr: x w0 w1 coef dy0 dy1 bcoef0 bcoef1 dx addend dw0 dw1 dz0 dz1
                                 // i[8..]: lddy0 lddy1 lddx ldadd lddw0 lddw1 lddz0 lddz1
+        // ... with the BatchNorm finalize step of every group inside the pass:
+        case VT_OP_PW_APPLY_FIN:  // as PW_APPLY + ptr[8..]: (stats gamma beta rm rv nbt) x 2 | f: M count eps0 momentum0 eps1 momentum1
+        case VT_OP_PW_BWD_FIN: {  // as PW_BWD + ptr[14..]: (sums dgamma dbeta) x 2 | i[16]: train | f: M count pscale(0 = 1)
             vt_pw_desc d;
             memset(&d, 0, sizeof(d));
             d.dtype = VT_BF16;
@@ -311,6 +314,17 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
                 const int32_t ldy2[2] = {I[8], I[9]}, ldr2[2] = {I[10], I[11]};
                 return vt_pw_fwd_apply(&d, (const float*)P[3], y2, ldy2, r2, ldr2, st);
             }
+            if (op.kind == VT_OP_PW_APPLY_FIN) {
+                void* y2[2] = {P[4], P[5]};
+                const void* r2[2] = {P[6], P[7]};
+                const int32_t ldy2[2] = {I[8], I[9]}, ldr2[2] = {I[10], I[11]};
+                vt_bn_fin_fwd fin[2];
+                for (int g = 0; g < 2; ++g)
+                    fin[g] = vt_bn_fin_fwd{(const float*)P[8 + 6 * g], F[1], (const float*)P[9 + 6 * g], (const float*)P[10 + 6 * g],
+                                           (float)F[2 + 2 * g], (float)F[3 + 2 * g], (float*)P[11 + 6 * g], (float*)P[12 + 6 * g],
+                                           (int64_t*)P[13 + 6 * g]};
+                return vt_pw_fwd_apply_finalize(&d, fin, (float*)P[3], y2, ldy2, r2, ldr2, st);
+            }
             const void* dy2[2] = {P[4], P[5]};
             const int32_t lddy2[2] = {I[8], I[9]};
             if (op.kind == VT_OP_PW_REDUCE) {
@@ -321,6 +335,14 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
             float* dw2[2] = {(float*)P[10], (float*)P[11]};
             void* dz2[2] = {P[12], P[13]};
             const int32_t lddw2[2] = {I[12], I[13]}, lddz2[2] = {I[14], I[15]};
+            if (op.kind == VT_OP_PW_BWD_FIN) {
+                vt_bn_fin_bwd fin[2];
+                for (int g = 0; g < 2; ++g)
+                    fin[g] = vt_bn_fin_bwd{(const float*)P[14 + 3 * g], F[1], F[2] == 0.0 ? 1.0 : F[2], I[16], (float*)P[15 + 3 * g],
+                                           (float*)P[16 + 3 * g]};
+                return vt_pw_bwd_apply_finalize(&d, (const float*)P[3], dy2, lddy2, fin, (float* const*)bc2, P[8], I[10], P[9], I[11],
+                                                dw2, lddw2, dz2, lddz2, st);
+            }
             return vt_pw_bwd_apply(&d, (const float*)P[3], dy2, lddy2, bc2, P[8], I[10], P[9], I[11], dw2, lddw2, dz2, lddz2, st);
         }
         default:

@@ -51,7 +51,7 @@ def stats_encode(buf, which: int, values, replica: int = 0):
     buf[replica, which, :, 1] += torch.round((v - hi * 4096.0) * float(1 << 33)).to(torch.int64)
 
 
-VT_OP_MAX_PTR, VT_OP_MAX_INT, VT_OP_MAX_FLT, VT_MAX_BASES = 16, 110, 8, 16
+VT_OP_MAX_PTR, VT_OP_MAX_INT, VT_OP_MAX_FLT, VT_MAX_BASES = 24, 110, 8, 16
 
 (
     OP_MEMSET,
@@ -102,7 +102,9 @@ VT_OP_MAX_PTR, VT_OP_MAX_INT, VT_OP_MAX_FLT, VT_MAX_BASES = 16, 110, 8, 16
     OP_DWCONV_WGRAD,
     OP_BN_BWD_REDUCE_FIN,
     OP_CONV_IGEMM_FIN,
-) = range(1, 49)
+    OP_PW_APPLY_FIN,
+    OP_PW_BWD_FIN,
+) = range(1, 51)
 OP_SIDE_STREAM = 0x10000  # OR-ed into Op.kind: enqueue on the side stream
 
 OP_NAMES = {
@@ -134,6 +136,8 @@ OP_NAMES = {
     OP_DWCONV_WGRAD: "dwconv_wgrad",
     OP_BN_BWD_REDUCE_FIN: "bn_bwd_reduce_fin",
     OP_CONV_IGEMM_FIN: "conv_igemm_fin",
+    OP_PW_APPLY_FIN: "pw_apply_fin",
+    OP_PW_BWD_FIN: "pw_bwd_fin",
     OP_SGD: "sgd",
     OP_COPY2D: "copy2d",
     OP_NCHW_TO_NHWC: "nchw_to_nhwc",
@@ -185,6 +189,21 @@ class PwDesc(C.Structure):
         ("w", C.c_void_p * 2),
         ("ldw", C.c_int32 * 2),
     ]  # fmt: skip
+
+
+class BnFinFwd(C.Structure):
+    """vt_bn_fin_fwd"""
+
+    _fields_ = [("stats", C.c_void_p), ("count", C.c_double), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float),
+                ("momentum", C.c_float), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("num_batches_tracked", C.c_void_p)]
+
+
+class BnFinBwd(C.Structure):
+    """vt_bn_fin_bwd"""
+
+    _fields_ = [("sums", C.c_void_p), ("count", C.c_double), ("pscale", C.c_double), ("train", C.c_int32),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
 
 
 class PackItem(C.Structure):
@@ -275,6 +294,10 @@ SYMBOLS = {
     "vt_pw_bwd_reduce": (_i32, [C.POINTER(PwDesc), _vp, C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_vp), _vp]),
     "vt_pw_bwd_apply": (_i32, [C.POINTER(PwDesc), _vp, C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_vp), _vp, _i32, _vp, _i32,
                                C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_vp), C.POINTER(_i32), _vp]),
+    "vt_pw_fwd_apply_finalize": (_i32, [C.POINTER(PwDesc), C.POINTER(BnFinFwd), _vp, C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_vp),
+                                        C.POINTER(_i32), _vp]),
+    "vt_pw_bwd_apply_finalize": (_i32, [C.POINTER(PwDesc), _vp, C.POINTER(_vp), C.POINTER(_i32), C.POINTER(BnFinBwd), C.POINTER(_vp),
+                                        _vp, _i32, _vp, _i32, C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_vp), C.POINTER(_i32), _vp]),
     "vt_bn_act_apply_pool": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                     _vp]),
     "vt_bn_act_bwd_reduce_pool": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp,

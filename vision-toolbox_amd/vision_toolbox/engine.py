@@ -1139,10 +1139,17 @@ class Builder:
         wps = [self.pref(c.weight, mirror=True) for c in convs]
         pad2 = lambda v, fill=None: list(v) + [fill] * (2 - len(v))
         head_i = [K, G, int(relu)] + pad2(Cs, 0) + [x.ld] + pad2([K] * G, 0)
+        # the finalize step of every group inside the apply passes (vt_pw_fwd_apply_finalize / vt_pw_bwd_apply_finalize)
+        pw_fin = self.bn_fin_apply and self.bn_world == 1 and Ntot <= 128
+        fin_p = []
         if unit_training:
             stats = [self.zeroed_f32(N.stat_floats(c), "stats") for c in Cs]
             self.emit(N.OP_PW_STATS, [x.addr(), *pad2(wps), *pad2([self.bp(s_) for s_ in stats])], head_i, [M])
             for g, norm in enumerate(norms):
+                if pw_fin:
+                    fin_p += [self.bp(stats[g]), self.pref(norm.weight), self.pref(norm.bias), self.pref(norm.running_mean),
+                              self.pref(norm.running_var), self.pref(norm.num_batches_tracked)]
+                    continue
                 self.emit(N.OP_BN_FINALIZE,
                           [self.bp(stats[g]), self.pref(norm.weight), self.pref(norm.bias), self.pref(norm.running_mean),
                            self.pref(norm.running_var), self.pref(norm.num_batches_tracked), *cps[g]],
@@ -1152,10 +1159,18 @@ class Builder:
                 self.emit(N.OP_BN_EVAL_COEFFS, [self.pref(norm.weight), self.pref(norm.bias), self.pref(norm.running_mean),
                                                 self.pref(norm.running_var), *cps[g]], [Cs[g]], [norm.eps])
         ress = [sp[3] for sp in specs]
-        self.emit(N.OP_PW_APPLY,
-                  [x.addr(), *pad2(wps), self.bp(coef), *pad2([y.addr() for y in ys]),
-                   *pad2([r.addr() if r is not None else None for r in ress])],
-                  head_i + pad2([y.ld for y in ys], 0) + pad2([r.ld if r is not None else 0 for r in ress], 0), [M])
+        if fin_p:
+            epsmom = [v for norm in norms for v in (norm.eps, norm.momentum)]
+            self.emit(N.OP_PW_APPLY_FIN,
+                      [x.addr(), *pad2(wps), self.bp(coef), *pad2([y.addr() for y in ys]),
+                       *pad2([r.addr() if r is not None else None for r in ress]), *fin_p],
+                      head_i + pad2([y.ld for y in ys], 0) + pad2([r.ld if r is not None else 0 for r in ress], 0),
+                      [M, M * self.bn_world] + epsmom)
+        else:
+            self.emit(N.OP_PW_APPLY,
+                      [x.addr(), *pad2(wps), self.bp(coef), *pad2([y.addr() for y in ys]),
+                       *pad2([r.addr() if r is not None else None for r in ress])],
+                      head_i + pad2([y.ld for y in ys], 0) + pad2([r.ld if r is not None else 0 for r in ress], 0), [M])
         if self.need_grad:
             tag = self.tag
 
@@ -1176,7 +1191,11 @@ class Builder:
                 self.emit(N.OP_PW_REDUCE, [x.addr(), *pad2(wps), self.bp(coef), *dy_p, *pad2([self.bp(s_) for s_ in sums])],
                           head_i + dy_ld, [M])
                 bcoefs = [self.f32(3 * c, "bwdcoef") for c in Cs]
+                bfin_p = []
                 for g, norm in enumerate(norms):
+                    if pw_fin:
+                        bfin_p += [self.bp(sums[g]), self.pgrad(norm.weight), self.pgrad(norm.bias)]
+                        continue
                     self.emit(N.OP_BN_BWD_FINALIZE,
                               [self.bp(sums[g]), cps[g][0], cps[g][2], cps[g][3], self.pgrad(norm.weight), self.pgrad(norm.bias),
                                self.bp(bcoefs[g])], [Cs[g], int(unit_training)], [M * self.bn_world, 1.0 / self.bn_world])
@@ -1185,12 +1204,13 @@ class Builder:
                 dws = [self.pgrad(c.weight) if (mode == 2 and w_) else None for c, w_ in zip(convs, want_dw)]
                 dzs = [self.act(x.B, x.H, x.W, c, sp[5] + ".dz") if (mode == 1 and w_) else None
                        for c, sp, w_ in zip(Cs, specs, want_dw)]
-                self.emit(N.OP_PW_BWD,
+                self.emit(N.OP_PW_BWD_FIN if bfin_p else N.OP_PW_BWD,
                           [x.addr(), *pad2(wps), self.bp(coef), *dy_p, *pad2([self.bp(b_) for b_ in bcoefs]), gx.addr(),
                            res.addr() if res is not None else None, *pad2(dws),
-                           *pad2([d.addr() if d is not None else None for d in dzs])],
+                           *pad2([d.addr() if d is not None else None for d in dzs]), *bfin_p],
                           head_i + dy_ld + [gx.ld, res.ld if res is not None else 0] + pad2([K] * G, 0) +
-                          pad2([d.ld if d is not None else 0 for d in dzs], 0), [M])
+                          pad2([d.ld if d is not None else 0 for d in dzs], 0) + [int(unit_training)],
+                          [M, M * self.bn_world, 1.0 / self.bn_world])
                 self.grad_written(x)
                 if mode == 1 and any(d is not None for d in dzs):
                     # the filter gradient does not fit the kernel's accumulators: dz was written, the usual kernel takes it
