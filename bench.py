@@ -261,7 +261,7 @@ def hbm_layers_insitu(ts, batch):
 
     def pw_match(kind, K, C0, C1, M):
         def m(op):  # i: K, groups, relu, C0, C1, ldx, ...; f: M
-            return (op.kind & 0xFFFF) == kind and (op.i[0], op.i[3], op.i[4]) == (K, C0, C1) and int(op.f[0]) == M
+            return (op.kind & 0xFFFF) in kind and (op.i[0], op.i[3], op.i[4]) == (K, C0, C1) and int(op.f[0]) == M
         return m
 
     out = []
@@ -273,13 +273,13 @@ def hbm_layers_insitu(ts, batch):
         ("data gradient of conv3x3 s2 32->64: 2x2 taps over dz 64 ch @112x112, depth-to-space store of 32 ch @224x224", "bwd",
          conv_match(64, 128, 4, 112, 1), 2.0 * (px(112) * 64 + px(224) * 32 + 128 * 256)),
         ("conv3x3 s1 64->64 @56x56 forward", "fwd", conv_match(64, 64, 9, 56, 1), 2.0 * (px(56) * 128 + 64 * 576)),
-        ("pointwise pair 64->32|32 @112x112, statistics pass (reads x)", "fwd", pw_match(N.OP_PW_STATS, 64, 32, 32, px(112)), 2.0 * px(112) * 64),
-        ("pointwise pair 64->32|32 @112x112, normalise pass (reads x, writes both outputs)", "fwd", pw_match(N.OP_PW_APPLY, 64, 32, 32, px(112)),
+        ("pointwise pair 64->32|32 @112x112, statistics pass (reads x)", "fwd", pw_match((N.OP_PW_STATS,), 64, 32, 32, px(112)), 2.0 * px(112) * 64),
+        ("pointwise pair 64->32|32 @112x112, normalise pass (reads x, writes both outputs)", "fwd", pw_match((N.OP_PW_APPLY, N.OP_PW_APPLY_FIN), 64, 32, 32, px(112)),
          2.0 * px(112) * 128),
-        ("pointwise pair 64->32|32 @112x112, backward reduction (reads x, dy)", "bwd", pw_match(N.OP_PW_REDUCE, 64, 32, 32, px(112)),
+        ("pointwise pair 64->32|32 @112x112, backward reduction (reads x, dy)", "bwd", pw_match((N.OP_PW_REDUCE,), 64, 32, 32, px(112)),
          2.0 * px(112) * 128),
         ("pointwise pair 64->32|32 @112x112, backward apply (reads x, dy; writes dx; dW in registers)", "bwd",
-         pw_match(N.OP_PW_BWD, 64, 32, 32, px(112)), 2.0 * px(112) * 192),
+         pw_match((N.OP_PW_BWD, N.OP_PW_BWD_FIN), 64, 32, 32, px(112)), 2.0 * px(112) * 192),
     ]
     for name, which, match, nbytes in rows:
         ms, n = insitu_op_times(ts, which, match)

@@ -96,6 +96,16 @@ def main():
                 algo_bytes[name] += nb
                 desc = f"C {op.i[3]:4d} M {int(op.f[0])}{' +res' if op.ptr[3].base >= 0 else ''}{' +pool' if op.ptr[5].base >= 0 else ''}"
                 work = f"{nb / ms / 1e9:6.2f} TB/s ideal {nb / PEAK_HBM * 1e3:6.3f} excess {ms - nb / PEAK_HBM * 1e3:6.3f}"
+            elif kind == N.OP_BN_FIN_APPLY:  # (round 6) ptr 11 = residual | i: C ldz ldr ldy relu dtype | f: count eps momentum M
+                nb = 2.0 * op.f[3] * op.i[0] * (2 + (1 if op.ptr[11].base >= 0 else 0))
+                algo_bytes[name] += nb
+                desc = f"C {op.i[0]:4d} M {int(op.f[3])}{' +res' if op.ptr[11].base >= 0 else ''}"
+                work = f"{nb / ms / 1e9:6.2f} TB/s ideal {nb / PEAK_HBM * 1e3:6.3f} excess {ms - nb / PEAK_HBM * 1e3:6.3f}"
+            elif kind == N.OP_BN_BWD_FIN_APPLY:  # (round 6) i: C train lddy ldz lddz relu dtype | f: count pscale M
+                nb = 2.0 * op.f[2] * op.i[0] * 3
+                algo_bytes[name] += nb
+                desc = f"C {op.i[0]:4d} M {int(op.f[2])}"
+                work = f"{nb / ms / 1e9:6.2f} TB/s ideal {nb / PEAK_HBM * 1e3:6.3f} excess {ms - nb / PEAK_HBM * 1e3:6.3f}"
             elif kind == N.OP_BN_BWD_REDUCE:  # i: lddy ldz C relu dtype | f: M
                 pooled = op.ptr[7].base >= 0
                 nb = 2.0 * op.f[0] * op.i[2] * (1.25 + 0.125 if pooled else 2)
@@ -108,10 +118,11 @@ def main():
                 algo_bytes[name] += nb
                 desc = f"C {op.i[3]:4d} M {int(op.f[0])}{' pooled-dy' if pooled else ''}"
                 work = f"{nb / ms / 1e9:6.2f} TB/s ideal {nb / PEAK_HBM * 1e3:6.3f} excess {ms - nb / PEAK_HBM * 1e3:6.3f}"
-            elif kind in (N.OP_PW_STATS, N.OP_PW_APPLY, N.OP_PW_REDUCE, N.OP_PW_BWD):
+            elif kind in (N.OP_PW_STATS, N.OP_PW_APPLY, N.OP_PW_REDUCE, N.OP_PW_BWD, N.OP_PW_APPLY_FIN, N.OP_PW_BWD_FIN):
                 # i: K ngroups relu C0 C1 ldx ... | f: M.  x once; y / dy once; residual / addend and dz where present
                 K, Nn, M_ = op.i[0], op.i[3] + op.i[4], op.f[0]
                 nb = 2.0 * M_ * K
+                kind = {N.OP_PW_APPLY_FIN: N.OP_PW_APPLY, N.OP_PW_BWD_FIN: N.OP_PW_BWD}.get(kind, kind)  # (same operands)
                 if kind == N.OP_PW_APPLY:
                     nb += 2.0 * M_ * Nn + sum(2.0 * M_ * op.i[3 + g] for g in range(2) if op.ptr[6 + g].base >= 0)
                 elif kind == N.OP_PW_REDUCE:
@@ -129,6 +140,8 @@ def main():
                 npix = d.B * max(d.Ho * d.Wo, d.oH * d.oW if kind == N.OP_CONV_IGEMM else 0)
             elif kind in (N.OP_BN_ACT_APPLY, N.OP_BN_BWD_REDUCE, N.OP_BN_BWD_APPLY, N.OP_PW_STATS, N.OP_PW_APPLY, N.OP_PW_REDUCE, N.OP_PW_BWD):
                 npix = int(op.f[0])
+            elif kind in (N.OP_BN_FIN_APPLY, N.OP_BN_BWD_FIN_APPLY):
+                npix = int(op.f[3] if kind == N.OP_BN_FIN_APPLY else op.f[2])
             elif kind == N.OP_STEM_BWD_REDUCE:
                 npix = op.i[1] * op.i[2] * op.i[3]
             else:

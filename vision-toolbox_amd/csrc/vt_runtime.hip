@@ -480,8 +480,9 @@ static int run_ops_impl(const vt_op* ops, int32_t n, void* const* bases, int32_t
             fork_ev = nullptr;
         } else if (stop_events && two && !bag && !on_side && i + 1 < n && ops[i + 1].kind == VT_OP_FORK &&
                    (op.kind == VT_OP_BN_BWD_APPLY || op.kind == VT_OP_BN_ACT_APPLY || op.kind == VT_OP_PW_BWD ||
-                    op.kind == VT_OP_BN_BWD_FUSED || op.kind == VT_OP_BN_FIN_APPLY || op.kind == VT_OP_BN_BWD_FIN_APPLY)) {
-            // (single-launch ops only: the event must belong to the LAST kernel of the op)
+                    op.kind == VT_OP_BN_BWD_FUSED || op.kind == VT_OP_BN_FIN_APPLY || op.kind == VT_OP_BN_BWD_FIN_APPLY ||
+                    op.kind == VT_OP_PW_BWD_FIN)) {
+            // (the event must belong to the LAST kernel of the op: the only launch of these ops that takes the pending event)
             hipError_t e = hipSuccess;
             hipEvent_t ev = take_event(nullptr, &e);
             if (e == hipSuccess) vt_pending_stop_event = ev;
