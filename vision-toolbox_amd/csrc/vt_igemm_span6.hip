@@ -225,6 +225,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
     const int bid = blockIdx.x, xcd = bid & 7, l = bid >> 3;
     // MODE 1 with a finalize tail (vt_fin_tail.h): EVERY workgroup of the grid takes a ticket, the idle ones included
     auto fin_tail = [&]() {
+#ifndef VT_SPAN6_NO_FIN_TAIL  // (A/B builds: tools/runs/r6_s6tail_ab.sh)
         if constexpr (MODE == 1) {
             ArgsPtr Q = fresh_args();
             if (Q->p.fin.ticket) {
@@ -237,6 +238,7 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
                 vt_fin_tail_fwd(f, f.ticket, gridDim.x, 0, f.C, (unsigned*)smem);
             }
         }
+#endif
     };
     if (l >= a.rslots * p.tiles_n) {  // (tiles_n does not divide 32)
         fin_tail();
