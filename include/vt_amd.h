@@ -236,27 +236,6 @@ int vt_bn_act_bwd_reduce(const void* dy, int32_t lddy, const void* z, int32_t ld
 int vt_bn_bwd_finalize(const float* sums, int32_t C, double count, double pscale,
                        const float* scale, const float* mean, const float* invstd, int32_t train,
                        float* dgamma, float* dbeta, float* coef, void* stream);
-/* vt_bn_act_bwd_reduce followed by vt_bn_bwd_finalize -- same values bit for bit (the sums are exact integers) -- with the
- * finalize step run as the TAIL of the reduction launch (round 6, csrc/vt_fin_tail.h): every workgroup takes a ticket once
- * its statistics atomics are performed, and the one that draws the last ticket finalizes while the rest of the grid has
- * retired.  Nobody waits inside the launch, and the single-workgroup finalize launch between two streaming passes (8.7 us
- * of the step each, 134 per CSPDarknet-53 step) disappears.  `tickets`: VT_FIN_TICKETS uint32 words owned by the caller,
- * ZERO before the call and left zero by it (a channel group of the reduction's grid uses one each).  One launch where the
- * tail is at most two batches of loads (C <= 128 per channel group: every layer of the models here); two launches otherwise,
- * with tickets == NULL, or with the knob VT_FIN_TAIL = 0. */
-#define VT_FIN_TICKETS 32
-/* The forward counterpart: vt_conv_igemm with VT_CONV_STATS followed by vt_bn_finalize(stats, Cout, count, ...) -- same values
- * bit for bit -- with the finalize step as the convolution launch's tail where the kernel that takes the launch has one
- * (round 6: the two-group persistent 3x3 kernel, up to 256 output channels); two launches everywhere else.  `tickets` as
- * above (one word is used). */
-int vt_conv_igemm_finalize(const vt_conv_desc* d, const void* x, const void* w, void* y, float* stats, double count,
-                           const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
-                           float* running_var, int64_t* num_batches_tracked, float* scale, float* shift, float* mean,
-                           float* invstd, uint32_t* tickets, void* stream);
-int vt_bn_act_bwd_reduce_finalize(const void* dy, int32_t lddy, const void* z, int32_t ldz, const float* scale,
-                                  const float* shift, const float* mean, const float* invstd, int64_t M, int32_t C,
-                                  int32_t relu, int32_t dtype, float* sums, double count, double pscale, int32_t train,
-                                  float* dgamma, float* dbeta, float* coef, uint32_t* tickets, void* stream);
 /* dz = coef0[c]*g - coef1[c]*z + coef2[c], g = dy * act'(z*scale + shift).
  * scale, shift and coef ALL NULL: dz = dy * act'(z) -- the activation of a ConvNormAct built with norm="none"
  * (reference components.py:36: nn.Identity between the biased conv and the activation). */
@@ -577,8 +556,6 @@ enum vt_op_kind {
     VT_OP_DWCONV_FWD,       /* vt_dwconv_fwd */
     VT_OP_DWCONV_DGRAD,     /* vt_dwconv_dgrad */
     VT_OP_DWCONV_WGRAD,     /* vt_dwconv_wgrad */
-    VT_OP_BN_BWD_REDUCE_FIN, /* vt_bn_act_bwd_reduce_finalize */
-    VT_OP_CONV_IGEMM_FIN,    /* vt_conv_igemm_finalize */
     VT_OP_PW_APPLY_FIN,      /* vt_pw_fwd_apply_finalize */
     VT_OP_PW_BWD_FIN,        /* vt_pw_bwd_apply_finalize */
     VT_OP_KIND_END

@@ -293,9 +293,9 @@ def test_inlist_collectives_layout_of_the_launch_lists(monkeypatch):
                 s, f = ops[i - 1], ops[i]
                 assert (s.kind & 0xFFFF) == N.OP_STAT_SYNC and (s.kind & N.OP_SIDE_STREAM) == (f.kind & N.OP_SIDE_STREAM)
                 assert (s.ptr[0].base, s.ptr[0].offset, s.i[0]) == (f.ptr[0].base, f.ptr[0].offset, f.i[0])
-        # nothing else was added or lost against the single-GPU lists (whose BatchNorm-backward finalize steps sit inside
-        # the apply passes: with SyncBatchNorm they are launches of their own again, behind the exchange)
-        skip = (N.OP_STAT_SYNC, N.OP_ALLREDUCE, N.OP_FORK, N.OP_JOIN, N.OP_BN_BWD_FINALIZE)
+        # nothing else was added or lost against the single-GPU lists (whose BatchNorm finalize steps sit inside the
+        # normalise / apply passes: with SyncBatchNorm they are launches of their own again, behind the exchange)
+        skip = (N.OP_STAT_SYNC, N.OP_ALLREDUCE, N.OP_FORK, N.OP_JOIN, N.OP_BN_FINALIZE, N.OP_BN_BWD_FINALIZE)
         pops = plain.prog.fwd_ops if fin == N.OP_BN_FINALIZE else plain.prog.bwd_ops
         assert sum(k not in skip for k in kinds) == sum((pops[i].kind & 0xFFFF) not in skip for i in range(n_plain))
     ops, n = ts.prog.bwd_ops, ts.prog.n_bwd

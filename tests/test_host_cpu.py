@@ -169,10 +169,9 @@ def test_cspdarknet53_program_structure():
     # as do the pointwise units' apply passes; the stem keeps a finalize launch of its own
     assert h["bn_fin_apply"] == h["bn_bwd_fin_apply"] == 66 - pw_units and "bn_act_apply" not in h and "bn_bwd_apply" not in h
     assert h["bn_finalize"] == h["bn_bwd_finalize"] == 1  # (the stem)
-    # (three other fused forms exist and are off by default, each measured no faster in the step -- VT_FUSE_BNRED=1 moves
+    # (two other fused forms exist and are off by default, each measured no faster in the step -- VT_FUSE_BNRED=1 moves
     #  the reduction of DarknetBlock.conv1's backward into conv2's data-gradient launch, VT_BN_BWD_FUSED=1 makes the whole
-    #  BatchNorm backward of a unit one launch, VT_FIN_TAIL=1 finalizes in the tail of the launch that produces the sums;
-    #  test_fused_backward_forms_change_the_program_as_documented)
+    #  BatchNorm backward of a unit one launch; test_fused_backward_forms_change_the_program_as_documented)
     assert h["bn_bwd_reduce"] == 66 - pw_units
     # residual adds are folded into the normalise pass and torch.cat is elided: the ONLY
     # elementwise launches are one normalise pass (bn_fin_apply) per remaining unit; the only copies are the bf16 weight
@@ -201,10 +200,6 @@ def test_fused_backward_forms_change_the_program_as_documented(monkeypatch):
     h = _dry_program("cspdarknet53", N.VT_BF16, True, True).kind_histogram
     assert h["bn_act_apply"] == h["bn_bwd_apply"] == h["bn_bwd_reduce"] == 66 - 17 and h["bn_finalize"] == h["bn_bwd_finalize"] == 67
     assert "bn_fin_apply" not in h and "bn_bwd_fin_apply" not in h
-    monkeypatch.setenv("VT_FIN_TAIL", "1")  # ... or the finalize step in the tail of the launch that produces the sums
-    h = _dry_program("cspdarknet53", N.VT_BF16, True, True).kind_histogram
-    assert h["bn_bwd_reduce_fin"] == 66 - 17 and "bn_bwd_reduce" not in h and h["bn_bwd_finalize"] == 67 - (66 - 17)
-    assert h["conv_igemm_fin"] == 66 - 17 and h["bn_finalize"] == 67 - (66 - 17) and h["bn_act_apply"] == h["bn_bwd_apply"] == 66 - 17
 
 
 def test_inference_program_is_fully_fused():

@@ -11,7 +11,7 @@
 #include <hip/hip_ext.h>
 
 #include "vt_common.h"
-#include "vt_fin_tail.h"
+#include "vt_bn_fin.h"
 
 namespace {
 
@@ -61,7 +61,7 @@ __device__ __forceinline__ void st16(T* p, const uint4& v) { *(uint4*)p = v; }
 // BatchNorm finalize (training): stats -> mean / invstd / scale / shift + running stats
 // ---------------------------------------------------------------------------------
 __global__ void bn_finalize_kernel(const VtFinFwd f) {
-    // (the arithmetic: vt_fin_fwd_channel, vt_fin_tail.h -- shared with the tails of the producing launches)
+    // (the arithmetic: vt_fin_fwd_channel, vt_bn_fin.h -- shared with the passes that finalize for themselves)
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= f.C) return;
     // exact integer sums of the fixed-point replicas (vt_common.h), loaded as independent pairs
@@ -456,7 +456,7 @@ bn_act_apply_pool_kernel(const T* __restrict__ z, int ldz, const float* __restri
 // the critical path between a producer of statistics and the streaming pass that needs the coefficients: skipping them
 // (diagnostic build) shortens the 19.8 ms step by 1.17 ms, 9 - 13 us each.  Any hand-off INSIDE a launch -- first workgroups
 // finalize and publish, the others poll (the first form of these kernels: +2.3 ms per step); the producer's last workgroup
-// finalizes behind a ticket (vt_fin_tail.h: +-0) -- costs the dependent memory-side round trips it is made of, as much as
+// finalizes behind a ticket (NOTEBOOK R6.10: +-0, removed) -- costs the dependent memory-side round trips it is made of, as much as
 // the launch boundary it replaces.  Here nothing is handed over: the sums are complete when the streaming launch starts, so
 // EVERY workgroup finalizes the (at most 128) channels of its own channel group for itself -- a thread per (channel, sum),
 // its 16 replicas x 2 limbs in one round of plain loads (64 KB per workgroup, L2 hits after the first workgroup of an XCD),
@@ -605,7 +605,7 @@ __global__ void __launch_bounds__(kThreads)
 bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z, int ldz,
                      const float* __restrict__ scale, const float* __restrict__ shift,
                      const float* __restrict__ mean, const float* __restrict__ invstd, long M, int C,
-                     RowMap rm, int relu_flags, float* __restrict__ sums, int Ctot, const VtFinBwd ft) {
+                     RowMap rm, int relu_flags, float* __restrict__ sums, int Ctot) {
     const int relu = relu_flags & 1;  // bit 1: dev switch, LDS staging of every row lane (the pre-round-2 fold)
     const int act = relu_flags >> 4;  // (GEN: the activation code)
     constexpr int EPC = VecIO<T>::EPC;
@@ -711,8 +711,6 @@ bn_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ z
         }
         __syncthreads();
     }
-    // the finalize step as this launch's tail (vt_fin_tail.h): the last workgroup of a channel group to arrive does it
-    if (ft.ticket) vt_fin_tail_bwd(ft, ft.ticket + blockIdx.y, gridDim.x, cg0 * EPC, cg0 * EPC + C, (unsigned*)sred);
 }
 
 __global__ void bn_bwd_finalize_kernel(const VtFinBwd f) {
@@ -1621,7 +1619,7 @@ int vt_bn_finalize(const float* stats, int32_t C, double count, const float* gam
     VT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), VT_ERR_INVALID,
                "vt_bn_finalize: running_mean/var must both be given or both NULL");
     const double unbias = count > 1.0 ? count / (count - 1.0) : 1.0;
-    VtFinFwd f{nullptr, stats, gamma, beta, running_mean, running_var, num_batches_tracked, scale, shift, mean, invstd,
+    VtFinFwd f{stats, gamma, beta, running_mean, running_var, num_batches_tracked, scale, shift, mean, invstd,
                1.0 / count, unbias, eps, momentum, C};
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, f);
     VT_CHECK_LAUNCH("vt_bn_finalize");
@@ -1733,7 +1731,7 @@ int vt_bn_finalize_apply(const float* stats, int32_t C, double count, const floa
     const int groups = C / Cg, wgs = VT_KNOB("VT_BN_FIN_APPLY_WGS", 1024);
     RowMap rm = RowMap::make(Cg, vt_epc(dtype), M, wgs / groups > 0 ? wgs / groups : 1);
     rm.rev = (vt_bn_order() >> 0) & 1;
-    const VtFinFwd f{nullptr, stats, gamma, beta, running_mean, running_var, num_batches_tracked, scale, shift, mean, invstd,
+    const VtFinFwd f{stats, gamma, beta, running_mean, running_var, num_batches_tracked, scale, shift, mean, invstd,
                      1.0 / count, count > 1.0 ? count / (count - 1.0) : 1.0, eps, momentum, C};
     const dim3 grid(rm.blocks(M), groups);
     if (residual) {
@@ -1769,7 +1767,7 @@ int vt_bn_bwd_finalize_apply(const float* sums, int32_t C, double count, double 
     const int groups = C / Cg, wgs = VT_KNOB("VT_BN_FIN_APPLY_WGS", 1024);
     RowMap rm = RowMap::make(Cg, vt_epc(dtype), M, wgs / groups > 0 ? wgs / groups : 1);
     rm.rev = (vt_bn_order() >> 2) & 1;
-    const VtFinBwd f{nullptr, sums, scale, mean, invstd, dgamma, dbeta, coef, 1.0 / count, pscale, C, train};
+    const VtFinBwd f{sums, scale, mean, invstd, dgamma, dbeta, coef, 1.0 / count, pscale, C, train};
     VT_DISPATCH_T(dtype, "vt_bn_bwd_finalize_apply",
                   VT_LAUNCH_STOP(bn_bwd_fin_apply_kernel<T>, dim3(rm.blocks(M), groups), dim3(kThreads), 0, (hipStream_t)stream, f,
                                  (const T*)dy, lddy, (const T*)z, ldz, scale, shift, (T*)dz, lddz, (long)M, rm, relu, Cg));
@@ -1780,10 +1778,9 @@ int vt_bn_bwd_finalize_apply(const float* sums, int32_t C, double count, double 
 // (the two launches above wait for nothing since their second form: always 0; kept for vt_bn_bwd_fused_timeouts' sum)
 unsigned vt_fin_timeouts_host() { return 0; }
 
-// ft.ticket != NULL: the finalize step runs as the launch's tail when it fits (*tail_done = 1), else not at all
-static int bwd_reduce_impl(const void* dy, int32_t lddy, const void* z, int32_t ldz, const float* scale,
-                           const float* shift, const float* mean, const float* invstd, int64_t M, int32_t C,
-                           int32_t relu, int32_t dtype, float* sums, VtFinBwd ft, int* tail_done, void* stream) {
+int vt_bn_act_bwd_reduce(const void* dy, int32_t lddy, const void* z, int32_t ldz, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, int64_t M, int32_t C,
+                         int32_t relu, int32_t dtype, float* sums, void* stream) {
     VT_REQUIRE(M > 0 && scale && shift && mean && invstd && sums, VT_ERR_INVALID,
                "vt_bn_act_bwd_reduce: bad argument");
     VT_TRY(check_mat("vt_bn_act_bwd_reduce(dy)", dy, lddy, C, dtype));
@@ -1797,8 +1794,6 @@ static int bwd_reduce_impl(const void* dy, int32_t lddy, const void* z, int32_t 
     const int target = (256) / cgroups > 0 ? (256) / cgroups : 1;
     RowMap rm = RowMap::make(Cg, epc, M, target);
     rm.rev = (vt_bn_order() >> 1) & 1;
-    if (ft.ticket && !(cgroups <= VT_FIN_TICKETS && vt_fin_tail_fits(Cg, kThreads))) ft.ticket = nullptr;
-    if (tail_done) *tail_done = ft.ticket != nullptr;
     const int inwave_env = (1);
     const bool inwave = inwave_env && rm.CT < 64 && (rm.CT & (rm.CT - 1)) == 0;  // (as in the kernel)
     const int smem = (inwave ? kThreads / 64 : rm.RT) * 2 * rm.CT * epc * (int)sizeof(float);
@@ -1807,43 +1802,16 @@ static int bwd_reduce_impl(const void* dy, int32_t lddy, const void* z, int32_t 
         VT_DISPATCH_T(dtype, "vt_bn_act_bwd_reduce",
                       hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(rm.blocks(M), cgroups), dim3(kThreads), smem,
                                          (hipStream_t)stream, (const T*)dy, lddy, (const T*)z, ldz, scale, shift, mean,
-                                         invstd, (long)M, Cg, rm, (relu << 4) | (inwave_env ? 0 : 2), sums, C, ft));
+                                         invstd, (long)M, Cg, rm, (relu << 4) | (inwave_env ? 0 : 2), sums, C));
         VT_CHECK_LAUNCH("vt_bn_act_bwd_reduce");
         return VT_OK;
     }
     VT_DISPATCH_T(dtype, "vt_bn_act_bwd_reduce",
                   hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(rm.blocks(M), cgroups), dim3(kThreads), smem,
                                      (hipStream_t)stream, (const T*)dy, lddy, (const T*)z, ldz, scale, shift,
-                                     mean, invstd, (long)M, Cg, rm, (relu ? 1 : 0) | (inwave_env ? 0 : 2), sums, C, ft));
+                                     mean, invstd, (long)M, Cg, rm, (relu ? 1 : 0) | (inwave_env ? 0 : 2), sums, C));
     VT_CHECK_LAUNCH("vt_bn_act_bwd_reduce");
     return VT_OK;
-}
-
-int vt_bn_act_bwd_reduce(const void* dy, int32_t lddy, const void* z, int32_t ldz, const float* scale,
-                         const float* shift, const float* mean, const float* invstd, int64_t M, int32_t C,
-                         int32_t relu, int32_t dtype, float* sums, void* stream) {
-    return bwd_reduce_impl(dy, lddy, z, ldz, scale, shift, mean, invstd, M, C, relu, dtype, sums, VtFinBwd{}, nullptr, stream);
-}
-
-// vt_bn_act_bwd_reduce + vt_bn_bwd_finalize; ONE launch where the finalize step fits the reduction's tail (vt_fin_tail.h)
-int vt_bn_act_bwd_reduce_finalize(const void* dy, int32_t lddy, const void* z, int32_t ldz, const float* scale,
-                                  const float* shift, const float* mean, const float* invstd, int64_t M, int32_t C,
-                                  int32_t relu, int32_t dtype, float* sums, double count, double pscale, int32_t train,
-                                  float* dgamma, float* dbeta, float* coef, uint32_t* tickets, void* stream) {
-    VT_REQUIRE(coef && count > 0 && C > 0, VT_ERR_INVALID, "vt_bn_act_bwd_reduce_finalize: bad argument");
-    VtFinBwd ft{(tickets && VT_KNOB("VT_FIN_TAIL", 1)) ? tickets : nullptr, sums, scale, mean, invstd, dgamma, dbeta, coef,
-                1.0 / count, pscale, C, train};
-    int tail = 0;
-#ifdef VT_TAIL_DIAG_NOWORK
-    {
-        static long calls = 0;
-        static const long after = getenv("VT_DIAG_NOWORK_AFTER") ? atol(getenv("VT_DIAG_NOWORK_AFTER")) : (1L << 60);
-        if (++calls > after) ft.train |= 0x100;
-    }
-#endif
-    VT_TRY(bwd_reduce_impl(dy, lddy, z, ldz, scale, shift, mean, invstd, M, C, relu, dtype, sums, ft, &tail, stream));
-    if (tail) return VT_OK;
-    return vt_bn_bwd_finalize(sums, C, count, pscale, scale, mean, invstd, train, dgamma, dbeta, coef, stream);
 }
 
 int vt_bn_bwd_finalize(const float* sums, int32_t C, double count, double pscale, const float* scale, const float* mean,
@@ -1851,7 +1819,7 @@ int vt_bn_bwd_finalize(const float* sums, int32_t C, double count, double pscale
                        void* stream) {
     VT_REQUIRE(sums && scale && mean && invstd && coef && C > 0 && count > 0, VT_ERR_INVALID,
                "vt_bn_bwd_finalize: bad argument");
-    VtFinBwd f{nullptr, sums, scale, mean, invstd, dgamma, dbeta, coef, 1.0 / count, pscale, C, train};
+    VtFinBwd f{sums, scale, mean, invstd, dgamma, dbeta, coef, 1.0 / count, pscale, C, train};
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, f);
     VT_CHECK_LAUNCH("vt_bn_bwd_finalize");
     return VT_OK;

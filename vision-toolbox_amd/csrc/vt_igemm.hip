@@ -496,10 +496,9 @@ static void fill_args(IgemmArgs& a, const vt_conv_desc* d, const void* x, const 
 
 }
 
-// `a`: the caller's argument block (out: a.fin_done, see vt_igemm_args.h); fin: the finalize step wanted after a STATS launch
-static int conv_igemm_impl(IgemmArgs& a, const vt_conv_desc* d, const void* x, const void* w, void* y,
-                           const float* scale, const float* shift, const void* residual,
-                           float* stats, const VtFinFwd* fin, void* stream) {
+extern "C" int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w, void* y,
+                             const float* scale, const float* shift, const void* residual,
+                             float* stats, void* stream) {
     VT_REQUIRE(d && x && w && (y || (d->flags & VT_CONV_NOSTORE)), VT_ERR_INVALID, "vt_conv_igemm: null argument");
     VT_REQUIRE(!(d->flags & VT_CONV_NOSTORE) || (d->flags & VT_CONV_STATS), VT_ERR_INVALID,
                "vt_conv_igemm: NOSTORE is the statistics-only pass");
@@ -545,8 +544,8 @@ static int conv_igemm_impl(IgemmArgs& a, const vt_conv_desc* d, const void* x, c
                    "vt_conv_igemm: STATS is only defined on the raw conv output");
     }
 
+    IgemmArgs a;
     fill_args(a, d, x, w, y, scale, shift, residual, stats);
-    if (fin) a.fin = *fin;
 
     hipStream_t st = (hipStream_t)stream;
     if (!d2s) {  // (these kernels write dense rows only)
@@ -592,35 +591,6 @@ static int conv_igemm_impl(IgemmArgs& a, const vt_conv_desc* d, const void* x, c
     }
     if (d->Cout > 32) return launch<float, 128, 64, 2, 2, 2>(a, st);
     return launch<float, 128, 32, 4, 1, 2>(a, st);
-}
-
-extern "C" int vt_conv_igemm(const vt_conv_desc* d, const void* x, const void* w, void* y,
-                             const float* scale, const float* shift, const void* residual,
-                             float* stats, void* stream) {
-    IgemmArgs a;
-    return conv_igemm_impl(a, d, x, w, y, scale, shift, residual, stats, nullptr, stream);
-}
-
-// vt_conv_igemm with VT_CONV_STATS followed by vt_bn_finalize -- same values bit for bit -- with the finalize step run as
-// the tail of the convolution launch where the kernel that takes the launch has one (vt_fin_tail.h; round 6: the two-group
-// persistent kernel, up to 256 output channels); two launches everywhere else, with tickets == NULL or VT_FIN_TAIL = 0.
-extern "C" int vt_conv_igemm_finalize(const vt_conv_desc* d, const void* x, const void* w, void* y, float* stats, double count,
-                                      const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
-                                      float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
-                                      float* mean, float* invstd, uint32_t* tickets, void* stream) {
-    VT_REQUIRE(d && (d->flags & VT_CONV_STATS) && stats && scale && shift && mean && invstd && count > 0, VT_ERR_INVALID,
-               "vt_conv_igemm_finalize: a STATS launch and the outputs of vt_bn_finalize are needed");
-    VT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), VT_ERR_INVALID,
-               "vt_conv_igemm_finalize: running_mean/var must both be given or both NULL");
-    const double unbias = count > 1.0 ? count / (count - 1.0) : 1.0;
-    const VtFinFwd fin{(tickets && VT_KNOB("VT_FIN_TAIL", 1)) ? tickets : nullptr, stats, gamma, beta, running_mean, running_var,
-                       num_batches_tracked, scale, shift, mean, invstd, 1.0 / count, unbias, eps, momentum, d->Cout};
-    IgemmArgs a;
-    const int rc = conv_igemm_impl(a, d, x, w, y, nullptr, nullptr, nullptr, stats, &fin, stream);
-    if (rc != VT_OK) return rc;
-    if (a.fin_done) return VT_OK;
-    return vt_bn_finalize(stats, d->Cout, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, scale,
-                          shift, mean, invstd, stream);
 }
 
 // A data gradient that also reduces the BatchNorm backward of the unit whose output it differentiates (round 6): see

@@ -1,7 +1,6 @@
 // vt_igemm_args.h -- kernel argument block shared by the implicit-GEMM conv kernels.
 #pragma once
 #include "vt_common.h"
-#include "vt_fin_tail.h"
 
 // internal epilogue flag (never in a caller's vt_conv_desc.flags): the launch is vt_conv_dgrad_bnred's fused form
 #define VT_CONV_BNRED 0x1000
@@ -27,11 +26,6 @@ struct IgemmArgs {
     // VT_CONV_BNRED (vt_conv_dgrad_bnred): mean / invstd of the unit whose d(y) this launch produces
     const float* aux0;
     const float* aux1;
-    // vt_conv_igemm_finalize: the BatchNorm finalize step that follows this launch's statistics.  fin.ticket != NULL asks the
-    // kernel to run it as its tail (vt_fin_tail.h); a dispatcher whose kernel does sets fin_done, every other one ignores both
-    // (the caller then launches vt_bn_finalize).
-    VtFinFwd fin;
-    int fin_done;
 };
 
 // element offset of output column n relative to the row's base pixel: n itself, or under VT_CONV_D2S the pixel

@@ -223,37 +223,14 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
 
     // ---- this workgroup's share: a contiguous range of 32-row units of one XCD, one filter column tile ----
     const int bid = blockIdx.x, xcd = bid & 7, l = bid >> 3;
-    // MODE 1 with a finalize tail (vt_fin_tail.h): EVERY workgroup of the grid takes a ticket, the idle ones included
-    auto fin_tail = [&]() {
-#ifndef VT_SPAN6_NO_FIN_TAIL  // (A/B builds: tools/runs/r6_s6tail_ab.sh)
-        if constexpr (MODE == 1) {
-            ArgsPtr Q = fresh_args();
-            if (Q->p.fin.ticket) {
-                VtFinFwd f;  // (member by member: the kernarg segment is address space 4)
-                f.ticket = Q->p.fin.ticket, f.stats = Q->p.fin.stats, f.gamma = Q->p.fin.gamma, f.beta = Q->p.fin.beta;
-                f.running_mean = Q->p.fin.running_mean, f.running_var = Q->p.fin.running_var, f.nbt = Q->p.fin.nbt;
-                f.scale = Q->p.fin.scale, f.shift = Q->p.fin.shift, f.mean = Q->p.fin.mean, f.invstd = Q->p.fin.invstd;
-                f.inv_count = Q->p.fin.inv_count, f.unbias = Q->p.fin.unbias, f.eps = Q->p.fin.eps, f.momentum = Q->p.fin.momentum;
-                f.C = Q->p.fin.C;
-                vt_fin_tail_fwd(f, f.ticket, gridDim.x, 0, f.C, (unsigned*)smem);
-            }
-        }
-#endif
-    };
-    if (l >= a.rslots * p.tiles_n) {  // (tiles_n does not divide 32)
-        fin_tail();
-        return;
-    }
+    if (l >= a.rslots * p.tiles_n) return;  // (tiles_n does not divide 32)
     const int tn = l % p.tiles_n, rs = l / p.tiles_n;
     const int ux0 = xcd * a.upx, ux1 = min(a.units, ux0 + a.upx);
     const int nx = max(0, ux1 - ux0);
     const int ua = __builtin_amdgcn_readfirstlane(ux0 + (int)((unsigned)rs * (unsigned)nx / (unsigned)a.rslots));
     const int ub = __builtin_amdgcn_readfirstlane(ux0 + (int)((unsigned)(rs + 1) * (unsigned)nx / (unsigned)a.rslots));
     const int nun = ub - ua;
-    if (nun <= 0) {
-        fin_tail();
-        return;
-    }
+    if (nun <= 0) return;
     // group 0 takes the first ceil(nun/2) units, group 1 the rest; both cut their range into the SAME number of
     // tiles (the two groups run one schedule), heights within a group differing by at most one unit
     const int nun0 = KSPLIT ? nun : (nun + 1) >> 1;
@@ -1010,7 +987,6 @@ __global__ void __launch_bounds__(768, 3) span6_kernel(const S6Args a) {
         }
     }
     if (!KSPLIT && grp == 0) wg_barrier();  // tick 2S: group 1's last MFMA tick
-    fin_tail();  // (the eight compute waves: the loaders have retired; at most 256 channels, span6_run)
     if (VT_DBG(16) && wave == 0 && lane == 0 && blockIdx.x < 512) {
         vt_span6_stamps[blockIdx.x * 16 + 15] = cwait;
         vt_span6_stamps[blockIdx.x * 16 + 3] = cR;
@@ -1146,9 +1122,6 @@ static int span6_run(IgemmArgs& a0, int dtype, void* stream, bool dry) {
         if (rc != VT_OK) return rc;
     }
     if (dry) return VT_OK;
-    // the finalize tail: statistics launches of at most 256 channels (a thread pair of the 512 compute threads per channel)
-    if (p.fin.ticket && mode == 1 && p.Cout <= 256 && VT_KNOB("VT_FIN_TAIL_SPAN6", 1)) a0.fin_done = 1;
-    else p.fin.ticket = nullptr;
     vt_note_kernel(ksplit ? "span6_kernel<bf16,2x4+4 waves,FM%d,masked,ksplit>"
                           : (masked ? "span6_kernel<bf16,2x4+4 waves,FM%d,masked>" : "span6_kernel<bf16,2x4+4 waves,FM%d>"), kFMX);
     hipLaunchKernelGGL(kern, dim3(8 * 32), dim3(768), smem, (hipStream_t)stream, a);

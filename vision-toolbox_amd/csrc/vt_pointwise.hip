@@ -47,7 +47,7 @@
 #include <hip/hip_ext.h>
 
 #include "vt_common.h"
-#include "vt_fin_tail.h"
+#include "vt_bn_fin.h"
 
 namespace {
 
@@ -666,7 +666,7 @@ static int pw_fwd_apply_impl(const vt_pw_desc* d, const float* coef, void* const
         for (int g = 0; g < d->ngroups; ++g) {
             const int off = g ? d->C[0] : 0;
             float* c = (float*)coef;
-            a.ffin[g] = VtFinFwd{nullptr, fin[g].stats, fin[g].gamma, fin[g].beta, fin[g].running_mean, fin[g].running_var,
+            a.ffin[g] = VtFinFwd{fin[g].stats, fin[g].gamma, fin[g].beta, fin[g].running_mean, fin[g].running_var,
                                  fin[g].num_batches_tracked, c + off, c + Ntot + off, c + 2 * Ntot + off, c + 3 * Ntot + off,
                                  1.0 / fin[g].count, fin[g].count > 1.0 ? fin[g].count / (fin[g].count - 1.0) : 1.0, fin[g].eps,
                                  fin[g].momentum, d->C[g]};
@@ -746,7 +746,7 @@ static int pw_bwd_apply_impl(const vt_pw_desc* d, const float* coef, const void*
         for (int g = 0; g < d->ngroups; ++g) {
             const int off = g ? d->C[0] : 0;
             VT_REQUIRE(bcoef[g], VT_ERR_INVALID, "vt_pw_bwd_apply_finalize: null coefficients");
-            a.bfin[g] = VtFinBwd{nullptr, fin[g].sums, coef + off, coef + 2 * N + off, coef + 3 * N + off, fin[g].dgamma, fin[g].dbeta,
+            a.bfin[g] = VtFinBwd{fin[g].sums, coef + off, coef + 2 * N + off, coef + 3 * N + off, fin[g].dgamma, fin[g].dbeta,
                                  (float*)bcoef[g], 1.0 / fin[g].count, fin[g].pscale, d->C[g], fin[g].train};
         }
     }

@@ -142,13 +142,6 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
             return vt_conv_igemm(&d, P[0], P[1], P[2], (const float*)P[3], (const float*)P[4], P[5],
                                  (float*)P[6], st);
         }
-        case VT_OP_CONV_IGEMM_FIN: {  // ptr: x w y stats gamma beta rm rv nbt scale shift mean invstd tickets | i: vt_conv_desc image | f: count eps momentum
-            vt_conv_desc d;
-            memcpy(&d, I, sizeof(d));
-            return vt_conv_igemm_finalize(&d, P[0], P[1], P[2], (float*)P[3], F[0], (const float*)P[4], (const float*)P[5], (float)F[1],
-                                          (float)F[2], (float*)P[6], (float*)P[7], (int64_t*)P[8], (float*)P[9], (float*)P[10],
-                                          (float*)P[11], (float*)P[12], (uint32_t*)P[13], st);
-        }
         case VT_OP_CONV_DGRAD_BNRED: {  // ptr: dz w dy z scale shift mean invstd sums | i: vt_conv_desc image, then ldz, relu
             vt_conv_desc d;
             memcpy(&d, I, sizeof(d));
@@ -190,11 +183,6 @@ int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
             return vt_bn_act_bwd_reduce(P[0], I[0], P[1], I[1], (const float*)P[2], (const float*)P[3],
                                         (const float*)P[4], (const float*)P[5], (int64_t)F[0], I[2], I[3],
                                         I[4], (float*)P[6], st);
-        case VT_OP_BN_BWD_REDUCE_FIN:  // ptr: dy z scale shift mean invstd sums dgamma dbeta coef tickets | i: lddy ldz C relu dtype train | f: M count pscale(0 = 1)
-            return vt_bn_act_bwd_reduce_finalize(P[0], I[0], P[1], I[1], (const float*)P[2], (const float*)P[3], (const float*)P[4],
-                                                 (const float*)P[5], (int64_t)F[0], I[2], I[3], I[4], (float*)P[6], F[1],
-                                                 F[2] == 0.0 ? 1.0 : F[2], I[5], (float*)P[7], (float*)P[8], (float*)P[9],
-                                                 (uint32_t*)P[10], st);
         case VT_OP_BN_BWD_FINALIZE:  // ptr: sums scale mean invstd dgamma dbeta coef | i: C train | f: count pscale(0 = 1)
 #ifdef VT_DIAG_SKIP_FIN
             if (vt_diag_skip_fin(2)) return VT_OK;

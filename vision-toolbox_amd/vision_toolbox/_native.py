@@ -19,7 +19,6 @@ VT_F32, VT_BF16, VT_I64 = 0, 1, 2  # (VT_I64: collectives only)
 VT_MAX_TAPS = 36
 VT_CONV_RELU, VT_CONV_STATS, VT_CONV_RESIDUAL, VT_CONV_AFFINE, VT_CONV_D2S, VT_CONV_NOSTORE = 1, 2, 4, 8, 16, 32
 VT_STAT_REPLICAS = 16
-VT_FIN_TICKETS = 32  # uint32 ticket words of a vt_*_finalize tail (vt_amd.h)
 # a statistics buffer is int64[VT_STAT_REPLICAS][2][C][2]: value = hi * 2^12 + lo / 2^33 (vt_amd.h)
 
 
@@ -100,11 +99,9 @@ VT_OP_MAX_PTR, VT_OP_MAX_INT, VT_OP_MAX_FLT, VT_MAX_BASES = 24, 110, 8, 16
     OP_DWCONV_FWD,
     OP_DWCONV_DGRAD,
     OP_DWCONV_WGRAD,
-    OP_BN_BWD_REDUCE_FIN,
-    OP_CONV_IGEMM_FIN,
     OP_PW_APPLY_FIN,
     OP_PW_BWD_FIN,
-) = range(1, 51)
+) = range(1, 49)
 OP_SIDE_STREAM = 0x10000  # OR-ed into Op.kind: enqueue on the side stream
 
 OP_NAMES = {
@@ -134,8 +131,6 @@ OP_NAMES = {
     OP_DWCONV_FWD: "dwconv_fwd",
     OP_DWCONV_DGRAD: "dwconv_dgrad",
     OP_DWCONV_WGRAD: "dwconv_wgrad",
-    OP_BN_BWD_REDUCE_FIN: "bn_bwd_reduce_fin",
-    OP_CONV_IGEMM_FIN: "conv_igemm_fin",
     OP_PW_APPLY_FIN: "pw_apply_fin",
     OP_PW_BWD_FIN: "pw_bwd_fin",
     OP_SGD: "sgd",
@@ -244,8 +239,6 @@ SYMBOLS = {
     "vt_set_knob": (_i32, [C.c_char_p, _i32]),
     "vt_memset": (_i32, [_vp, _i32, _u64, _vp]),
     "vt_conv_igemm": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "vt_conv_igemm_finalize": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _f64, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
-                                      _vp, _vp, _vp]),
     "vt_conv_dgrad_bnred": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "vt_conv_wgrad": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i32, _vp]),
     "vt_dwconv_fwd": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp] + [_i32] * 9 + [_vp]),
@@ -274,8 +267,6 @@ SYMBOLS = {
     "vt_bn_eval_coeffs": (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "vt_bn_act_apply": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "vt_bn_act_bwd_reduce": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
-    "vt_bn_act_bwd_reduce_finalize": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _f64, _f64, _i32,
-                                             _vp, _vp, _vp, _vp, _vp]),
     "vt_bn_bwd_finalize": (_i32, [_vp, _i32, _f64, _f64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "vt_conv_wgrad_slabs": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i32, _vp, _i64, _vp]),
     "vt_conv_wgrad_group": (_i32, [C.POINTER(ConvDesc), _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i32, _vp]),

@@ -319,17 +319,16 @@ class Builder:
         # VT_BN_FIN_APPLY=0 keeps the separate launches.  (The first form -- the first workgroups finalize and publish, all
         # others poll -- measured 2.3 ms SLOWER, R6.6.)
         self.bn_fin_apply = os.environ.get("VT_BN_FIN_APPLY", "1") != "0"
-        # The finalize step as the TAIL of the launch that produces its sums (vt_bn_act_bwd_reduce_finalize,
-        # vt_conv_igemm_finalize, csrc/vt_fin_tail.h): every workgroup takes a ticket and the last one finalizes; nobody waits.
-        # Bit-identical, and NO faster than the launch it replaces (19.60 against 19.58 ms: the tail is the same chain of
-        # dependent memory-side round trips, NOTEBOOK R6.10): off; VT_FIN_TAIL=1 turns it on where VT_BN_FIN_APPLY does not apply.
-        self.fin_tail = os.environ.get("VT_FIN_TAIL", "0") != "0"
+        # (A third form -- the finalize step as the TAIL of the launch that produces the sums: every workgroup takes a ticket,
+        # the last one finalizes, nobody waits -- was bit-identical and NO faster than the launch it replaced, and its unused code
+        # at the end of the MFMA kernel cost 0.09 ms per step: removed, NOTEBOOK R6.10.)
         self._wg_expect: dict[tuple, int] = {}   # shape key -> units seen in forward and not yet released
         self._wg_pending: dict[tuple, list] = {}  # shape key -> [(x addr, dz addr, dw addr, desc, ldw)]
         # SyncBatchNorm (configs/base.yaml:22): the trainer all-reduces every layer's statistics
         # between the kernel that accumulates them and the finalize kernel; the finalize kernels
         # are then told the GLOBAL sample count (and scale the affine gradients by 1/world)
         self.bn_world = 1
+        self.bn_sync = False  # SyncBatchNorm: the sums are exchanged in front of every finalize step, which stays a launch of its own
         # feature-map inputs of programs that do not start from an image (necks): the runner copies
         # the caller's tensors into these buffers before the forward list and reads their gradients
         # (ext_grads, filled by build_backward) after the backward list
@@ -694,21 +693,10 @@ class Builder:
             if unit_training:
                 stats = self.zeroed_f32(N.stat_floats(Cout), "stats")
                 d = self._conv_desc(x, Cout, Ho, Wo, s, pad, k, z.ld, ldw, N.VT_CONV_STATS, dil=dil)
-                fin_fwd = (self.bn_fin_apply and self.bn_world == 1 and not generic_act and
+                fin_fwd = (self.bn_fin_apply and not self.bn_sync and not generic_act and
                            not (pool_out is not None and not generic_act))
-                if self.fin_tail and self.bn_world == 1 and not fin_fwd:
-                    # conv + finalize: the finalize step is the tail of the convolution launch where its kernel has one
-                    # (vt_conv_igemm_finalize, csrc/vt_fin_tail.h), a second launch inside the same op elsewhere
-                    self.emit(N.OP_CONV_IGEMM_FIN,
-                              [x.addr(), wptr, z.addr(), self.bp(stats), g, b_, rm, rv, nbt, *cp,
-                               self.bp(self.zeroed_f32(N.VT_FIN_TICKETS, "fintickets"))],
-                              flts=[M * self.bn_world, norm.eps, norm.momentum], desc=d)
-                    fin_fwd = None  # (finalized)
-                else:
-                    self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, z.addr(), None, None, None, self.bp(stats)], desc=d)
-                if fin_fwd is None:
-                    fin_fwd = False
-                elif not fin_fwd:
+                self.emit(N.OP_CONV_IGEMM, [x.addr(), wptr, z.addr(), None, None, None, self.bp(stats)], desc=d)
+                if not fin_fwd:
                     self.emit(N.OP_BN_FINALIZE,
                               [self.bp(stats), g, b_, rm, rv, nbt, *cp],
                               [Cout], [M * self.bn_world, norm.eps, norm.momentum])
@@ -827,7 +815,7 @@ class Builder:
                                                                 not generic_act and self._cur is self.bwd) else None
                     fused_red = rec is not None and rec[1] == dy.coff and rec[2] == dy.coff + dy.C and any(o is rec[0] for o in self.bwd)
                     one_launch = (self.bn_bwd_fused and not fused_red and pool_grad is None and dt == N.VT_BF16 and
-                                  not generic_act and self.bn_world == 1)
+                                  not generic_act and not self.bn_sync)
                     bcoef = self.f32(3 * Cout, "bwdcoef")
                     dz = self.act(B, Ho, Wo, Cout, name + ".dz")
                     if one_launch:
@@ -837,7 +825,6 @@ class Builder:
                                    self.pgrad(norm.weight), self.pgrad(norm.bias), self.bp(bcoef), dz.addr()],
                                   [dy.ld, z.ld, dz.ld, Cout, int(relu), dt, int(training)], [M, M * self.bn_world, 1.0 / self.bn_world])
                     else:
-                        tail_fin = False
                         if fused_red:
                             # d(y) came out of ONE data-gradient launch and nothing was added to it since: that launch also forms
                             # this unit's backward sums (the op is patched in place: ptr dz w dy | z scale shift mean invstd sums)
@@ -848,22 +835,11 @@ class Builder:
                             k0 = C.sizeof(N.ConvDesc) // 4
                             fop.i[k0], fop.i[k0 + 1] = z.ld, int(relu)
                             self._last_dgrad.pop(id(dy.buf), None)
-                        elif self.fin_tail and self.bn_world == 1 and pool_grad is None and not self.bn_fin_apply:
-                            # reduce + finalize: the finalize step is the tail of the reduction launch (vt_fin_tail.h)
-                            tail_fin = True
-                            self.emit(N.OP_BN_BWD_REDUCE_FIN,
-                                      [g_.addr(), z.addr(), cp[0], cp[1], cp[2], cp[3], self.bp(sums), self.pgrad(norm.weight),
-                                       self.pgrad(norm.bias), self.bp(bcoef), self.bp(self.zeroed_f32(N.VT_FIN_TICKETS, "fintickets"))],
-                                      [g_.ld, z.ld, Cout, int(relu), dt, int(training)], [M, M * self.bn_world, 1.0 / self.bn_world])
                         else:
                             self.emit(N.OP_BN_BWD_REDUCE,
                                       [g_.addr(), z.addr(), cp[0], cp[1], cp[2], cp[3], self.bp(sums)] + am_,
                                       [g_.ld, z.ld, Cout, int(relu), dt] + geo, [M])
-                        if tail_fin:
-                            self.emit(N.OP_BN_BWD_APPLY,
-                                      [g_.addr(), z.addr(), cp[0], cp[1], self.bp(bcoef), dz.addr()] + am_,
-                                      [g_.ld, z.ld, dz.ld, Cout, int(relu), dt] + geo, [M])
-                        elif self.bn_fin_apply and self.bn_world == 1 and pool_grad is None and not generic_act:
+                        if self.bn_fin_apply and not self.bn_sync and pool_grad is None and not generic_act:
                             self.emit(N.OP_BN_BWD_FIN_APPLY,
                                       [self.bp(sums), cp[0], cp[1], cp[2], cp[3], self.pgrad(norm.weight), self.pgrad(norm.bias),
                                        self.bp(bcoef), g_.addr(), z.addr(), dz.addr()],
@@ -1140,7 +1116,7 @@ class Builder:
         pad2 = lambda v, fill=None: list(v) + [fill] * (2 - len(v))
         head_i = [K, G, int(relu)] + pad2(Cs, 0) + [x.ld] + pad2([K] * G, 0)
         # the finalize step of every group inside the apply passes (vt_pw_fwd_apply_finalize / vt_pw_bwd_apply_finalize)
-        pw_fin = self.bn_fin_apply and self.bn_world == 1 and Ntot <= 128
+        pw_fin = self.bn_fin_apply and not self.bn_sync and Ntot <= 128
         fin_p = []
         if unit_training:
             stats = [self.zeroed_f32(N.stat_floats(c), "stats") for c in Cs]

@@ -237,6 +237,7 @@ class TrainStep:
         # strictly sequential collectives per unit (67 + 67 for CSPDarknet-53).
         self.sync_bn = bool(sync_bn) and self.dp
         b.bn_world = self.world if self.sync_bn else 1
+        b.bn_sync = bool(self.sync_bn)
         self.mix = bool(mix)  # MixUp / CutMix applied on device from a per-step parameter block
         x = b.input_images(batch_size, 3, image_size, image_size, mix=self.mix)
         fmap = backbone._vt_emit_maps(b, x)[-1]
