@@ -348,7 +348,7 @@ struct Graph {
 
 extern "C" {
 
-int vt_version(void) { return 103; }  // 103: round 6 (vt_conv_dgrad_bnred; vt_debug_hog left the library: tools/diag/vt_diag_hog.hip)
+int vt_version(void) { return 104; }  // 104: round 6 (finalize inside the passes, vt_op carries 24 pointers; 103: vt_conv_dgrad_bnred, vt_debug_hog left the library)
 int vt_set_knob(const char* name, int32_t value) {
     VT_REQUIRE(name && strlen(name) < 48, VT_ERR_INVALID, "vt_set_knob: bad name");
     // (a knob set before its first use overrides the environment: the slot exists from here on)

@@ -314,8 +314,8 @@ class Builder:
         # The finalize launches folded into the streaming launches that consume their coefficients (vt_bn_finalize_apply,
         # vt_bn_bwd_finalize_apply): every workgroup of the pass finalizes the channels of its own channel group from the
         # (complete) sums -- nothing is handed over inside the launch -- and the single-workgroup finalize launch between a
-        # producer of statistics and its consumer disappears: 98 of the 134 of a CSPDarknet-53 step, 19.997 -> 19.55 ms
-        # (NOTEBOOK R6.10).  Bit-identical.  Not with SyncBatchNorm (the statistics are exchanged in front of the finalize).
+        # producer of statistics and its consumer disappears: 114 of the 134 of a CSPDarknet-53 step, 132 with the pointwise
+        # passes (pw_units); same-box 20.36 -> 19.79 ms (NOTEBOOK R6.10).  Bit-identical.  Not with SyncBatchNorm (the statistics are exchanged in front of the finalize).
         # VT_BN_FIN_APPLY=0 keeps the separate launches.  (The first form -- the first workgroups finalize and publish, all
         # others poll -- measured 2.3 ms SLOWER, R6.6.)
         self.bn_fin_apply = os.environ.get("VT_BN_FIN_APPLY", "1") != "0"
