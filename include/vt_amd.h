@@ -264,7 +264,7 @@ int vt_bn_bwd_fused_timeouts(uint32_t* count);
  * of loads, the same arithmetic bit for bit -- and keeps the coefficients in LDS; the workgroups of row block 0 also store
  * them, the running statistics and d(gamma) / d(beta).  The single-workgroup finalize launch between a producer of
  * statistics and the pass that needs the coefficients (9 - 13 us of the step each, 134 per CSPDarknet-53 step) disappears;
- * the grid is cut for ~1024 workgroups (knob VT_BN_FIN_APPLY_WGS) so that the redundant reads stay small.  Same arguments,
+ * the grid is cut for ~1536 workgroups (knob VT_BN_FIN_APPLY_WGS) so that the redundant reads stay small.  Same arguments,
  * same results (bit-identical) as the two calls each replaces.  Those two calls run for activation codes >= 2, for channel
  * counts without a divisor in [32, 128] that is a multiple of the 16-byte chunk (other than C itself), and with the knob
  * VT_BN_FIN_APPLY = 0.  (The first form of these launches -- the first workgroups finalize and publish, all others poll a

@@ -462,8 +462,8 @@ bn_act_apply_pool_kernel(const T* __restrict__ z, int ldz, const float* __restri
 // its 16 replicas x 2 limbs in one round of plain loads (64 KB per workgroup, L2 hits after the first workgroup of an XCD),
 // the arithmetic of bn_finalize_kernel / bn_bwd_finalize_kernel bit for bit (vt_fin_fwd_channel / vt_fin_bwd_channel) --
 // and keeps the coefficients in LDS; the workgroups of row block 0 also store them (and the running statistics, d(gamma),
-// d(beta)) for the later passes.  The grid is cut for ~1024 workgroups instead of 4096, so that the redundant reads stay
-// small beside the tensor traffic.
+// d(beta)) for the later passes.  The grid is cut for ~1536 workgroups instead of 4096, so that the redundant reads stay
+// small beside the tensor traffic (step: 1024 -> 19.50, 1536 -> 19.47, 3072 -> 19.59, 4096 -> 19.81 ms).
 // ---------------------------------------------------------------------------------
 constexpr int kFinCg = 128;  // channels per channel group: a thread pair per channel
 
@@ -1728,7 +1728,7 @@ int vt_bn_finalize_apply(const float* stats, int32_t C, double count, const floa
     VT_TRY(check_mat("vt_bn_finalize_apply(z)", z, ldz, C, dtype));
     VT_TRY(check_mat("vt_bn_finalize_apply(y)", y, ldy, C, dtype));
     if (residual) VT_TRY(check_mat("vt_bn_finalize_apply(residual)", residual, ldr, C, dtype));
-    const int groups = C / Cg, wgs = VT_KNOB("VT_BN_FIN_APPLY_WGS", 1024);
+    const int groups = C / Cg, wgs = VT_KNOB("VT_BN_FIN_APPLY_WGS", 1536);
     RowMap rm = RowMap::make(Cg, vt_epc(dtype), M, wgs / groups > 0 ? wgs / groups : 1);
     rm.rev = (vt_bn_order() >> 0) & 1;
     const VtFinFwd f{stats, gamma, beta, running_mean, running_var, num_batches_tracked, scale, shift, mean, invstd,
@@ -1764,7 +1764,7 @@ int vt_bn_bwd_finalize_apply(const float* sums, int32_t C, double count, double 
     VT_TRY(check_mat("vt_bn_bwd_finalize_apply(dy)", dy, lddy, C, dtype));
     VT_TRY(check_mat("vt_bn_bwd_finalize_apply(z)", z, ldz, C, dtype));
     VT_TRY(check_mat("vt_bn_bwd_finalize_apply(dz)", dz, lddz, C, dtype));
-    const int groups = C / Cg, wgs = VT_KNOB("VT_BN_FIN_APPLY_WGS", 1024);
+    const int groups = C / Cg, wgs = VT_KNOB("VT_BN_FIN_APPLY_WGS", 1536);
     RowMap rm = RowMap::make(Cg, vt_epc(dtype), M, wgs / groups > 0 ? wgs / groups : 1);
     rm.rev = (vt_bn_order() >> 2) & 1;
     const VtFinBwd f{sums, scale, mean, invstd, dgamma, dbeta, coef, 1.0 / count, pscale, C, train};
@@ -1791,7 +1791,10 @@ int vt_bn_act_bwd_reduce(const void* dy, int32_t lddy, const void* z, int32_t ld
     // channel groups of 64 on the small maps with many channels (see the kernel): the row splits shrink by the same factor
     const int cgroups = (M <= 65536 && C >= 256 && C % 64 == 0) ? C / 64 : 1;
     const int Cg = C / cgroups;
-    const int target = (256) / cgroups > 0 ? (256) / cgroups : 1;
+    // (round 6, beside the CU-owning filter-gradient kernels of the side stream: 128 -> 19.74, 256 -> 19.49, 512 / 1024 -> 19.45,
+    //  2048 -> 19.55 ms per step)
+    const int blocks_knob = VT_KNOB("VT_BN_RED_BLOCKS", 1024);
+    const int target = blocks_knob / cgroups > 0 ? blocks_knob / cgroups : 1;
     RowMap rm = RowMap::make(Cg, epc, M, target);
     rm.rev = (vt_bn_order() >> 1) & 1;
     const int inwave_env = (1);
