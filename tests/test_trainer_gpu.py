@@ -372,12 +372,13 @@ def test_captured_data_parallel_segments_equal_the_eager_schedule(bucket_mb):
 
 @pytest.mark.parametrize("flag", ["VT_FUSE_BNRED", "VT_BN_BWD_FUSED", "VT_BN_FIN_APPLY"])
 def test_fused_batchnorm_forms_leave_the_step_alone(flag, monkeypatch):
-    """Round 6 built three launch fusions of the BatchNorm passes that are OFF by default (each measured slower in the step,
-    NOTEBOOK R6.4-R6.6): the backward reduction inside the data-gradient launch in front of it (VT_FUSE_BNRED), the whole
-    backward of a unit as one launch with grid barriers (VT_BN_BWD_FUSED), the finalize step inside the launch that consumes
-    its coefficients (VT_BN_FIN_APPLY).  Their kernels have parity tests of their own; this is the ENGINE side: with a flag on,
-    the program really contains the fused ops, and loss, every parameter gradient and the running statistics of a bf16 train
-    step equal the default program's (the sums are the same terms in another order; VT_BN_FIN_APPLY is bit-identical)."""
+    """Round 6 built three launch fusions of the BatchNorm passes: the backward reduction inside the data-gradient launch in
+    front of it (VT_FUSE_BNRED) and the whole backward of a unit as one launch with grid barriers (VT_BN_BWD_FUSED) -- OFF by
+    default, each measured slower in the step (NOTEBOOK R6.4 / R6.5) -- and the finalize step inside the passes that consume its
+    coefficients (VT_BN_FIN_APPLY: every workgroup finalizes for itself; ON by default since R6.10).  Their kernels have parity
+    tests of their own; this is the ENGINE side: against the program with all three off (the launches of rounds 1-5), a program
+    with one of them on really contains the fused ops, and loss, every parameter gradient and the running statistics of a bf16
+    train step are equal (the sums are the same terms in another order; VT_BN_FIN_APPLY is bit-identical)."""
     import ctypes
 
     ncls, B, S = 16, 8, 96
