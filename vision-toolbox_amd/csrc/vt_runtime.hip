@@ -122,6 +122,26 @@ static bool vt_diag_skip_fin(int which) {  // which: 1 forward, 2 backward final
     static const int mask = getenv("VT_DIAG_SKIP_FIN_WHICH") ? atoi(getenv("VT_DIAG_SKIP_FIN_WHICH")) : 3;
     return ++calls > after && (mask & which);
 }
+// any op kinds (VT_DIAG_SKIP_KINDS = comma-separated kind numbers) skipped after the first VT_DIAG_SKIP_AFTER_OPS ops of the
+// process: what a kernel family costs INSIDE the step (tools/runs/r6_skipkinds.sh; the skipped ops' outputs keep the values of the
+// warm-up steps -- same batch, nearly the same weights)
+static bool vt_diag_skip_kind(int kind) {
+    static long calls = 0;
+    static const long after = getenv("VT_DIAG_SKIP_AFTER_OPS") ? atol(getenv("VT_DIAG_SKIP_AFTER_OPS")) : (1L << 60);
+    static bool skip[256];
+    static const bool init = []() {
+        const char* e = getenv("VT_DIAG_SKIP_KINDS");
+        while (e && *e) {
+            const int k = atoi(e);
+            if (k > 0 && k < 256) skip[k] = true;
+            e = strchr(e, ',');
+            if (e) ++e;
+        }
+        return true;
+    }();
+    (void)init;
+    return ++calls > after && kind > 0 && kind < 256 && skip[kind];
+}
 #endif
 int run_one(const vt_op& op, void* const* bases, int nbases, void* st) {
     bool bad = false;
@@ -451,6 +471,11 @@ static int run_ops_impl(const vt_op* ops, int32_t n, void* const* bases, int32_t
         const bool on_side = (op.kind & VT_OP_SIDE_STREAM) != 0;
         op.kind &= ~VT_OP_SIDE_STREAM;
         int rc = VT_OK;
+#ifdef VT_DIAG_SKIP_FIN  // (diagnostic builds: a kernel family left out of the step, batched / grouped launches included)
+        if (op.kind != VT_OP_FORK && op.kind != VT_OP_FORK_MARK && op.kind != VT_OP_FORK_WAIT && op.kind != VT_OP_JOIN &&
+            vt_diag_skip_kind(op.kind))
+            continue;
+#endif
         if (on_side && op.kind != VT_OP_FORK && op.kind != VT_OP_FORK_MARK && op.kind != VT_OP_FORK_WAIT && op.kind != VT_OP_JOIN) {
             rc = capture_fork();
             if (rc != VT_OK) return rc;
