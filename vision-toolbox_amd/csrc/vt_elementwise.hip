@@ -15,7 +15,10 @@
 
 namespace {
 
-constexpr int kThreads = 256;
+#ifndef VT_EW_THREADS
+#define VT_EW_THREADS 256
+#endif
+constexpr int kThreads = VT_EW_THREADS;
 constexpr int kUnroll = 4;  // rows in flight per thread in the streaming kernels
 
 // thread -> (channel chunk column, row lane) for an [M][C] matrix of 16-byte chunks
@@ -465,7 +468,7 @@ bn_act_apply_pool_kernel(const T* __restrict__ z, int ldz, const float* __restri
 // d(beta)) for the later passes.  The grid is cut for ~1536 workgroups instead of 4096, so that the redundant reads stay
 // small beside the tensor traffic (step: 1024 -> 19.50, 1536 -> 19.47, 3072 -> 19.59, 4096 -> 19.81 ms).
 // ---------------------------------------------------------------------------------
-constexpr int kFinCg = 128;  // channels per channel group: a thread pair per channel
+constexpr int kFinCg = kThreads / 2;  // channels per channel group: a thread pair per channel
 
 // the channel group of C channels: the largest divisor <= 128 that is a multiple of the 16-byte chunk (0: none)
 __host__ inline int fin_group(int C, int epc) {
